@@ -1,0 +1,90 @@
+"""Deterministic synthetic PLM weights, keyed by HF parameter name.
+
+There are no pretrained checkpoints offline, so parity and bench
+runs use seeded weights that can be regenerated bit-identically on the GPU box
+instead of shipping ~440 MB.  Every tensor draws from its own
+``numpy.random.Generator(PCG64([seed, crc32(name)]))`` stream so the values do
+not depend on generation order.
+
+Key names follow HF ``BertModel`` / ``RobertaModel`` state_dict, which is what sits
+under ``news_encoder.text_encoder.plm_model.`` in reference checkpoints
+(reference manner/models/components/news_encoder.py:20).
+"""
+from __future__ import annotations
+
+import hashlib
+import zlib
+from typing import Dict, Iterator, Tuple
+
+import numpy as np
+
+from .config import EncoderConfig
+
+
+def plm_param_shapes(cfg: EncoderConfig, with_pooler: bool = True) -> Iterator[Tuple[str, Tuple[int, ...]]]:
+    h, i = cfg.hidden, cfg.intermediate
+    yield "embeddings.word_embeddings.weight", (cfg.vocab, h)
+    yield "embeddings.position_embeddings.weight", (cfg.max_pos, h)
+    yield "embeddings.token_type_embeddings.weight", (cfg.type_vocab, h)
+    yield "embeddings.LayerNorm.weight", (h,)
+    yield "embeddings.LayerNorm.bias", (h,)
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            yield p + f"attention.self.{n}.weight", (h, h)
+            yield p + f"attention.self.{n}.bias", (h,)
+        yield p + "attention.output.dense.weight", (h, h)
+        yield p + "attention.output.dense.bias", (h,)
+        yield p + "attention.output.LayerNorm.weight", (h,)
+        yield p + "attention.output.LayerNorm.bias", (h,)
+        yield p + "intermediate.dense.weight", (i, h)
+        yield p + "intermediate.dense.bias", (i,)
+        yield p + "output.dense.weight", (h, i)
+        yield p + "output.dense.bias", (h,)
+        yield p + "output.LayerNorm.weight", (h,)
+        yield p + "output.LayerNorm.bias", (h,)
+    if with_pooler:
+        # computed by HF but dropped by the reference (news_encoder.py:34); kept for key parity
+        yield "pooler.dense.weight", (h, h)
+        yield "pooler.dense.bias", (h,)
+
+
+def _stream(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def make_plm_weights(cfg: EncoderConfig, seed: int = 42, std: float = 0.02,
+                     with_pooler: bool = True) -> Dict[str, np.ndarray]:
+    """fp32 numpy tensors for every PLM parameter.
+
+    Matrices ~ N(0, std^2) (HF ``initializer_range`` is 0.02; a larger ``std`` gives
+    "trained-like" activations with more spread between news).  Unlike HF's init,
+    biases and LayerNorm affine terms are non-trivial (bias ~ N(0, 0.02^2),
+    gamma ~ 1 + N(0, 0.05^2)) so that a kernel which drops one of them fails parity.
+    """
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in plm_param_shapes(cfg, with_pooler):
+        g = _stream(seed, name)
+        if name.endswith("LayerNorm.weight"):
+            w = 1.0 + 0.05 * g.standard_normal(shape, dtype=np.float32)
+        elif name.endswith(".bias"):
+            w = 0.02 * g.standard_normal(shape, dtype=np.float32)
+        else:
+            w = std * g.standard_normal(shape, dtype=np.float32)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def make_additive_attention_weights(input_dim: int, query_dim: int, seed: int = 42,
+                                    prefix: str = "additive_attention.") -> Dict[str, np.ndarray]:
+    """Parameters of reference AdditiveAttention (attention.py:9-10): linear [Q,D], [Q]; query [Q]."""
+    g = _stream(seed, prefix + "linear.weight")
+    bound = 1.0 / np.sqrt(input_dim)
+    w = g.uniform(-bound, bound, (query_dim, input_dim)).astype(np.float32)
+    b = _stream(seed, prefix + "linear.bias").uniform(-bound, bound, (query_dim,)).astype(np.float32)
+    q = _stream(seed, prefix + "query").uniform(-0.1, 0.1, (query_dim,)).astype(np.float32)
+    return {prefix + "linear.weight": w, prefix + "linear.bias": b, prefix + "query": q}
+
+
+def tensor_sha256(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

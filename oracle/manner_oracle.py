@@ -1,0 +1,255 @@
+"""CPU ORACLE for the MANNeR news-encoding + candidate-scoring hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it,
+and only as the checker / reported CPU baseline.  The product path
+(``manner_amd``) never routes through it and has no CPU fallback.
+
+It is a plain PyTorch fp32 (CPU) restatement of the reference's algorithm; each
+function cites the reference lines it follows.  The encoder arithmetic lives in
+a third-party dependency of the reference (``transformers`` ``BertModel`` /
+``RobertaModel``, pinned only as ``>=4.29.2`` in reference requirements.txt:25;
+the container has 5.15.0), so that part restates the published BERT algorithm
+and is anchored on the reference's call site news_encoder.py:20,30-34.
+``to_dense_batch`` (torch_geometric) and ``RetrievalNormalizedDCG`` (torchmetrics)
+are not installed and are restated from their documented semantics.
+
+Pinning: the reference ships no tests or golden vectors.  The
+oracle is pinned by outputs of the reference itself, run in the build container:
+``tests/golden/make_golden.py`` imports the reference's leaf modules
+(MannerNewsEncoder / AdditiveAttention / NAMLUserEncoder / DotProduct) and HF
+``BertModel`` / ``RobertaModel`` on seeded inputs and commits inputs + outputs under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them.
+The Lightning-level forwards (cr_module.py:105-131, ensemble_module.py:95-151)
+cannot be imported here (lightning / torch_geometric / torchmetrics absent) and
+are restated line by line; for those the fixtures pin self-consistency only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+ARCH_BERT, ARCH_ROBERTA = 0, 1
+
+
+def _t(x) -> Tensor:
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(x)
+
+
+# --------------------------------------------------------------------------- encoder (K1-K7)
+
+def position_ids(ids: Tensor, arch: int, pad_id: int) -> Tensor:
+    """BERT: arange(L) (transformers/models/bert/modeling_bert.py:65,83-84).
+    RoBERTa: cumsum(ids != pad) * (ids != pad) + pad
+    (transformers/models/roberta/modeling_roberta.py:142-155)."""
+    n, l = ids.shape
+    if arch == ARCH_BERT:
+        return torch.arange(l).unsqueeze(0).expand(n, l)
+    m = ids.ne(pad_id).int()
+    return (torch.cumsum(m, dim=1).type_as(m) * m).long() + pad_id
+
+
+def embeddings(ids: Tensor, w: Dict[str, Tensor], cfg) -> Tensor:
+    """K1: LN(word[ids] + type[0] + pos[position_ids]) — modeling_bert.py:68-108.
+    token_type is all zeros because the reference collate passes
+    return_token_type_ids=False (mind_rec_dataset.py:134-137)."""
+    pos = position_ids(ids, cfg.arch, cfg.pad_id)
+    x = w["embeddings.word_embeddings.weight"][ids]
+    x = x + w["embeddings.token_type_embeddings.weight"][0]
+    x = x + w["embeddings.position_embeddings.weight"][pos]
+    return F.layer_norm(x, (cfg.hidden,), w["embeddings.LayerNorm.weight"],
+                        w["embeddings.LayerNorm.bias"], cfg.ln_eps)
+
+
+def encoder_layer(x: Tensor, add_mask: Tensor, w: Dict[str, Tensor], l: int, cfg) -> Tensor:
+    """K2-K6: one BertLayer (modeling_bert.py:175-203, 289-293, 334-337, 347-351)."""
+    p = f"encoder.layer.{l}."
+    n, s, h = x.shape
+    a, d = cfg.heads, cfg.head_dim
+
+    def lin(t, name):
+        return F.linear(t, w[p + name + ".weight"], w[p + name + ".bias"])
+
+    q = lin(x, "attention.self.query").view(n, s, a, d).transpose(1, 2)
+    k = lin(x, "attention.self.key").view(n, s, a, d).transpose(1, 2)
+    v = lin(x, "attention.self.value").view(n, s, a, d).transpose(1, 2)
+    att = torch.matmul(q, k.transpose(2, 3)) * (d ** -0.5) + add_mask       # :128-131
+    att = F.softmax(att, dim=-1)
+    ctx = torch.matmul(att, v).transpose(1, 2).reshape(n, s, h)
+    x = F.layer_norm(lin(ctx, "attention.output.dense") + x, (h,),
+                     w[p + "attention.output.LayerNorm.weight"],
+                     w[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
+    inter = F.gelu(lin(x, "intermediate.dense"))                             # exact erf GeLU
+    x = F.layer_norm(lin(inter, "output.dense") + x, (h,),
+                     w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], cfg.ln_eps)
+    return x
+
+
+def encode_tokens(ids: Tensor, mask: Tensor, w: Dict[str, Tensor], cfg,
+                  layers: Optional[int] = None) -> Tensor:
+    """last_hidden_state [N,L,H] of BertModel.forward (modeling_bert.py:623-686) in eval mode."""
+    ids, mask = _t(ids).long(), _t(mask)
+    w = {k: _t(v) for k, v in w.items()}
+    x = embeddings(ids, w, cfg)
+    # additive padding mask over keys (create_bidirectional_mask, modeling_bert.py:704-708)
+    add_mask = torch.zeros(mask.shape, dtype=torch.float32)
+    add_mask = add_mask.masked_fill(mask == 0, torch.finfo(torch.float32).min)[:, None, None, :]
+    for l in range(cfg.layers if layers is None else layers):
+        x = encoder_layer(x, add_mask, w, l, cfg)
+    return x
+
+
+def encode_cls(ids, mask, w, cfg) -> Tensor:
+    """K7: MannerTextEncoder.forward (reference news_encoder.py:29-37): CLS slice of the
+    PLM's last hidden state; dropout is identity in eval()."""
+    with torch.no_grad():
+        return encode_tokens(ids, mask, w, cfg)[:, 0, :].contiguous()
+
+
+# --------------------------------------------------------------------------- pooler / scorer
+
+def additive_attention(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:
+    """K11: AdditiveAttention.forward (reference attention.py:21-27), no padding mask (Q2)."""
+    x, lin_w, lin_b, query = _t(x), _t(lin_w), _t(lin_b), _t(query)
+    att = torch.tanh(F.linear(x, lin_w, lin_b))
+    wts = F.softmax(torch.matmul(att, query), dim=1)
+    return torch.bmm(wts.unsqueeze(1), x).squeeze(1)
+
+
+def dot_product(user: Tensor, cand: Tensor) -> Tensor:
+    """K12: DotProduct.forward (reference click_predictors.py:9-12): user [B,1,D], cand [B,D,C]."""
+    return torch.bmm(_t(user), _t(cand)).squeeze(1)
+
+
+def to_dense_batch(x: Tensor, batch: Tensor) -> Tuple[Tensor, Tensor]:
+    """K9: torch_geometric.utils.to_dense_batch restated: ``batch`` sorted
+    ascending segment ids; output zero-filled [B, max_count, *] + bool mask."""
+    x, batch = _t(x), _t(batch).long()
+    b = int(batch.max()) + 1 if batch.numel() else 0
+    counts = torch.bincount(batch, minlength=b)
+    mx = int(counts.max()) if b else 0
+    starts = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(batch.numel()) - starts[batch]
+    out = torch.zeros((b, mx) + tuple(x.shape[1:]), dtype=x.dtype)
+    mask = torch.zeros((b, mx), dtype=torch.bool)
+    out[batch, pos] = x
+    mask[batch, pos] = True
+    return out, mask
+
+
+def cr_scores(hist_vec: Tensor, batch_hist: Tensor, cand_vec: Tensor, batch_cand: Tensor,
+              late_fusion: bool = True,
+              user_encoder: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
+    """CRModule.forward after the two news_encoder calls (reference cr_module.py:108-131).
+    Returns scores [B, Cmax]; padded candidate slots score exactly 0."""
+    hist_agg, mask_hist = to_dense_batch(hist_vec, batch_hist)
+    cand_agg, _ = to_dense_batch(cand_vec, batch_cand)
+    if late_fusion:
+        hist_size = mask_hist.sum(dim=1)                                    # :117-120
+        user = torch.div(hist_agg.sum(dim=1), hist_size.unsqueeze(-1))      # :121-123
+    else:
+        user = additive_attention(hist_agg, *user_encoder)                  # :125
+    return dot_product(user.unsqueeze(1), cand_agg.permute(0, 2, 1))        # :127-129
+
+
+def zscore(scores: Tensor, mask_cand: Tensor) -> Tensor:
+    """K13: EnsembleModule._submodel_forward z-normalisation (reference ensemble_module.py:138-149):
+    mean = sum over the PADDED row / c_i (Q3), std = unbiased torch.std over valid entries."""
+    cand_size = mask_cand.sum(dim=1)
+    std = torch.stack([torch.std(scores[i][mask_cand[i]]) for i in range(mask_cand.shape[0])]).unsqueeze(-1)
+    mean = torch.div(torch.sum(scores, dim=1), cand_size).unsqueeze(-1).expand_as(scores)
+    return torch.div(scores - mean, std)
+
+
+def ensemble_scores(module_vecs: Sequence[Tuple[Tensor, Tensor]], batch_hist: Tensor,
+                    batch_cand: Tensor, weights: Sequence[float]) -> Tensor:
+    """K14: EnsembleModule.forward (reference ensemble_module.py:95-109).
+    ``module_vecs[k] = (hist_vec, cand_vec)`` of module k (CR first); ``weights[k-1]`` is the
+    weight of module k>=1; a zero weight skips the module exactly as the reference does."""
+    _, mask_cand = to_dense_batch(torch.zeros(_t(batch_cand).numel()), batch_cand)
+
+    def sub(k):
+        s = cr_scores(module_vecs[k][0], batch_hist, module_vecs[k][1], batch_cand, late_fusion=True)
+        return zscore(s, mask_cand)
+
+    scores = sub(0)
+    for k, wk in enumerate(weights, start=1):
+        if wk != 0:
+            scores = scores + wk * sub(k)      # reference does `scores += w * s` in place
+    return scores
+
+
+def ragged(scores: Tensor, batch_cand: Tensor) -> Tensor:
+    """Flatten [B,Cmax] back to the ragged candidate order (what cr_module.py:267-273 feeds
+    to the metrics via the candidate mask)."""
+    _, mask = to_dense_batch(torch.zeros(_t(batch_cand).numel()), batch_cand)
+    return scores[mask]
+
+
+# --------------------------------------------------------------------------- ranking / nDCG (K15)
+
+def topk_indices(scores: Tensor, offsets: Sequence[int], k: int) -> List[List[int]]:
+    """Per impression, candidate positions sorted by descending score (stable: ties keep the
+    lower position first), truncated to k."""
+    out = []
+    for i in range(len(offsets) - 1):
+        s = scores[offsets[i]:offsets[i + 1]]
+        order = torch.argsort(s, descending=True, stable=True)
+        out.append(order[:k].tolist())
+    return out
+
+
+def ndcg_at_k(scores: Tensor, target: Tensor, offsets: Sequence[int], k: int) -> Tuple[float, Tensor]:
+    """RetrievalNormalizedDCG(top_k=k) restated (constructed at reference cr_module.py:83-84):
+    per impression DCG@k = sum_{r<k} target_r / log2(r+2) on preds sorted descending, IDCG@k on
+    targets sorted descending, impressions without a positive score 0.0
+    (empty_target_action='neg'), mean over impressions.  Tie-free semantics."""
+    per = []
+    for i in range(len(offsets) - 1):
+        s = scores[offsets[i]:offsets[i + 1]]
+        t = target[offsets[i]:offsets[i + 1]].double()
+        if t.sum() == 0:
+            per.append(0.0)
+            continue
+        order = torch.argsort(s, descending=True, stable=True)[:k]
+        disc = 1.0 / torch.log2(torch.arange(order.numel(), dtype=torch.float64) + 2.0)
+        dcg = (t[order] * disc).sum()
+        ideal = torch.sort(t, descending=True).values[:k]
+        idcg = (ideal * disc[: ideal.numel()]).sum()
+        per.append(float(dcg / idcg))
+    per_t = torch.tensor(per, dtype=torch.float64)
+    return float(per_t.mean()) if per else 0.0, per_t
+
+
+# --------------------------------------------------------------------------- whole-path drivers
+
+def offsets_to_batch(offsets: Sequence[int]) -> Tensor:
+    """_make_batch_assignees (reference mind_rec_dataset.py:171-174) from CSR offsets."""
+    sizes = torch.tensor([offsets[i + 1] - offsets[i] for i in range(len(offsets) - 1)])
+    return torch.repeat_interleave(torch.arange(len(sizes)), sizes)
+
+
+def reference_faithful_scores(ids: Tensor, mask: Tensor, hist_idx: Tensor, hist_off: Sequence[int],
+                              cand_idx: Tensor, cand_off: Sequence[int], w, cfg,
+                              chunk: int = 64) -> Tensor:
+    """Mode R: every history and candidate OCCURRENCE is encoded, as
+    cr_module.py:107,113 does, then late-fusion mean + dot.  ``ids/mask`` is the news pool
+    [Nn, Lp]; ``*_idx`` index into it.  Returns ragged scores [sum c_i]."""
+
+    def enc(idx):
+        outs = []
+        for s in range(0, idx.numel(), chunk):
+            j = idx[s:s + chunk]
+            m = mask[j]
+            lp = int(m.sum(dim=1).max())           # tokenizer pads to the batch max (mind_rec_dataset.py:136)
+            outs.append(encode_cls(ids[j][:, :lp], m[:, :lp], w, cfg))
+        return torch.cat(outs)
+
+    ids, mask = _t(ids), _t(mask)
+    hv, cv = enc(_t(hist_idx).long()), enc(_t(cand_idx).long())
+    bh, bc = offsets_to_batch(hist_off), offsets_to_batch(cand_off)
+    return ragged(cr_scores(hv, bh, cv, bc, late_fusion=True), bc)

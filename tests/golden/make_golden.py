@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference and transformers):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's own leaf modules (manner/models/components/
+{news_encoder,attention,user_encoder,click_predictors}.py) and HF BertModel /
+RobertaModel, feeds them seeded synthetic inputs and the seeded weights of
+``manner_amd.weights``, and stores inputs + reference outputs as small .npz
+files.  The reference never travels to the GPU box; these vectors do.
+
+Fixtures whose ``source`` field says "oracle" restate Lightning-level code that
+cannot be imported here (lightning / torch_geometric / torchmetrics are absent);
+they pin regressions of the restatement, not the reference.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from manner_amd.config import ARCH_BERT, PRESETS  # noqa: E402
+from manner_amd.synth import synth_news_tokens  # noqa: E402
+from manner_amd.weights import (make_additive_attention_weights, make_plm_weights,  # noqa: E402
+                                tensor_sha256)
+
+from manner.models.components.attention import AdditiveAttention  # noqa: E402
+from manner.models.components.click_predictors import DotProduct  # noqa: E402
+from manner.models.components.news_encoder import MannerNewsEncoder  # noqa: E402
+from manner.models.components.user_encoder import NAMLUserEncoder  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def hf_model_dir(cfg, weights, tmp):
+    from transformers import BertConfig, BertModel, RobertaConfig, RobertaModel
+    kw = dict(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+              num_attention_heads=cfg.heads, intermediate_size=cfg.intermediate,
+              max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
+              layer_norm_eps=cfg.ln_eps, pad_token_id=cfg.pad_id, hidden_act="gelu")
+    if cfg.arch == ARCH_BERT:
+        model = BertModel(BertConfig(**kw))
+    else:
+        model = RobertaModel(RobertaConfig(**kw))
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in m or "token_type_ids" in m for m in missing), missing
+    model.save_pretrained(tmp)
+    return tmp
+
+
+def reference_news_encoder(plm_dir, hidden):
+    enc = MannerNewsEncoder(plm_model=plm_dir, frozen_layers=[0], dropout_probability=0.2,
+                            use_entities=False, entity_embeddings=None, entity_embedding_dim=100,
+                            num_attention_heads=10, query_vector_dim=200, text_embedding_dim=hidden)
+    return enc.eval()
+
+
+def gen_encoder(name, preset, n, lp, seed, std, lengths=None):
+    cfg = PRESETS[preset]
+    w = make_plm_weights(cfg, seed=seed, std=std)
+    ids, mask = synth_news_tokens(n, cfg, seed=seed, max_len=lp, lengths=lengths)
+    with tempfile.TemporaryDirectory() as tmp:
+        enc = reference_news_encoder(hf_model_dir(cfg, w, tmp), cfg.hidden)
+        from transformers import BatchEncoding
+        news = {"text": BatchEncoding({"input_ids": torch.from_numpy(ids),
+                                       "attention_mask": torch.from_numpy(mask)})}
+        out = enc(news).numpy()
+        keys = sorted(enc.state_dict().keys())
+    np.savez_compressed(
+        os.path.join(HERE, f"{name}.npz"), ids=ids, mask=mask, out=out,
+        meta=json.dumps({"source": "reference MannerNewsEncoder (news_encoder.py:75-129) over HF "
+                                   "transformers " + __import__("transformers").__version__,
+                         "preset": preset, "seed": seed, "std": std,
+                         "sha256": {k: tensor_sha256(w[k]) for k in
+                                    ("embeddings.word_embeddings.weight",
+                                     "encoder.layer.0.attention.self.query.weight",
+                                     "encoder.layer.%d.output.dense.bias" % (cfg.layers - 1))}}))
+    print(name, out.shape, float(np.abs(out).mean()))
+    return keys
+
+
+def gen_components(seed=42):
+    g = np.random.Generator(np.random.PCG64(seed))
+    d, q = 768, 200
+    aw = make_additive_attention_weights(d, q, seed=seed)
+    att = AdditiveAttention(d, q).eval()
+    att.load_state_dict({k[len("additive_attention."):]: torch.from_numpy(v) for k, v in aw.items()})
+    ue = NAMLUserEncoder(news_embedding_dim=d, query_vector_dim=q).eval()
+    ue.load_state_dict({k: torch.from_numpy(v) for k, v in aw.items()})
+    x = g.standard_normal((4, 30, d), dtype=np.float32)
+    x[1, 12:] = 0.0                      # zero-padded history rows (Q2: padding changes the result)
+    x[3, 1:] = 0.0
+    out = att(torch.from_numpy(x)).numpy()
+    out_ue = ue(torch.from_numpy(x)).numpy()
+    assert np.array_equal(out, out_ue)
+    x1 = g.standard_normal((3, 1, d), dtype=np.float32)   # S = 1
+    out1 = att(torch.from_numpy(x1)).numpy()
+    np.savez_compressed(os.path.join(HERE, "additive_attention.npz"), x=x, out=out, x1=x1, out1=out1,
+                        meta=json.dumps({"source": "reference AdditiveAttention (attention.py:6-29) / "
+                                                   "NAMLUserEncoder (user_encoder.py:9-21)", "seed": seed,
+                                         "input_dim": d, "query_dim": q}))
+    user = g.standard_normal((4, 1, d), dtype=np.float32)
+    cand = g.standard_normal((4, d, 37), dtype=np.float32)
+    sc = DotProduct()(torch.from_numpy(user), torch.from_numpy(cand)).numpy()
+    np.savez_compressed(os.path.join(HERE, "dot_product.npz"), user=user, cand=cand, out=sc,
+                        meta=json.dumps({"source": "reference DotProduct (click_predictors.py:5-12)"}))
+    print("components", out.shape, sc.shape)
+    return sorted(ue.state_dict().keys())
+
+
+def gen_pipeline(seed=42):
+    """Lightning-level restatement fixtures (source: oracle)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import manner_oracle as O
+    from manner_amd.synth import synth_impressions
+    g = np.random.Generator(np.random.PCG64(seed))
+    nn_, d = 300, 64
+    tables = [g.standard_normal((nn_, d), dtype=np.float32) for _ in range(3)]
+    imp = synth_impressions(8, nn_, seed=seed, max_cand=40)
+    hi, ho, ci, co, lab = imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"], imp["labels"]
+    bh, bc = O.offsets_to_batch(ho.tolist()), O.offsets_to_batch(co.tolist())
+    vecs = [(torch.from_numpy(t[hi]), torch.from_numpy(t[ci])) for t in tables]
+    lf = O.cr_scores(vecs[0][0], bh, vecs[0][1], bc, late_fusion=True)
+    aw = make_additive_attention_weights(d, 20, seed=seed)
+    ue = tuple(torch.from_numpy(aw["additive_attention." + k]) for k in ("linear.weight", "linear.bias", "query"))
+    ef = O.cr_scores(vecs[0][0], bh, vecs[0][1], bc, late_fusion=False, user_encoder=ue)
+    ens = {}
+    for wts in ((0.0, 0.0), (-0.3, 0.0), (-0.3, 0.2)):
+        ens["ens_%g_%g" % wts] = O.ragged(O.ensemble_scores(vecs, bh, bc, wts), bc).numpy()
+    flat = torch.from_numpy(ens["ens_-0.3_0.2"])
+    n10, per10 = O.ndcg_at_k(flat, torch.from_numpy(lab), co.tolist(), 10)
+    n5, per5 = O.ndcg_at_k(flat, torch.from_numpy(lab), co.tolist(), 5)
+    top10 = O.topk_indices(flat, co.tolist(), 10)
+    top10_arr = np.full((len(top10), 10), -1, dtype=np.int32)
+    for i, t in enumerate(top10):
+        top10_arr[i, :len(t)] = t
+    np.savez_compressed(
+        os.path.join(HERE, "pipeline.npz"), tables=np.stack(tables), hist_idx=hi, hist_off=ho,
+        cand_idx=ci, cand_off=co, labels=lab, late=O.ragged(lf, bc).numpy(), early=O.ragged(ef, bc).numpy(),
+        late_dense=lf.numpy(), ue_w=ue[0].numpy(), ue_b=ue[1].numpy(), ue_q=ue[2].numpy(),
+        ndcg10=np.float64(n10), ndcg5=np.float64(n5), per10=per10.numpy(), per5=per5.numpy(),
+        top10=top10_arr, **ens,
+        meta=json.dumps({"source": "oracle restatement of cr_module.py:105-131, ensemble_module.py:95-151, "
+                                   "RetrievalNormalizedDCG (not importable here)", "seed": seed}))
+    print("pipeline", lf.shape, n10, n5)
+
+
+if __name__ == "__main__":
+    keys = {}
+    keys["tiny-bert"] = gen_encoder("enc_tiny_bert", "tiny-bert", n=12, lp=40, seed=42, std=0.05)
+    gen_encoder("enc_tiny_roberta", "tiny-roberta", n=12, lp=40, seed=43, std=0.05)
+    # N=16 news with lengths spread over 5..96, bert-base architecture
+    lens = np.array([5, 9, 12, 16, 17, 23, 31, 32, 33, 47, 48, 64, 65, 80, 95, 96])
+    keys["bert-base-uncased"] = gen_encoder("enc_bert_base", "bert-base-uncased", n=16, lp=96, seed=42,
+                                            std=0.02, lengths=lens)
+    gen_encoder("enc_bert_base_spread", "bert-base-uncased", n=16, lp=96, seed=44, std=0.05, lengths=lens)
+    keys["user_encoder"] = gen_components()
+    gen_pipeline()
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)

@@ -1,0 +1,114 @@
+"""The CPU oracle against vectors produced by the reference itself (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import manner_oracle as O
+from manner_amd.config import PRESETS
+from manner_amd.weights import (make_additive_attention_weights, make_plm_weights, plm_param_shapes,
+                                tensor_sha256)
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_bert_base", "enc_bert_base_spread"])
+def test_encoder_matches_reference(golden_dir, name):
+    z, meta = _load(golden_dir, name)
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    for k, h in meta["sha256"].items():           # the seeded weights regenerate bit-identically
+        assert tensor_sha256(w[k]) == h, k
+    out = O.encode_cls(z["ids"], z["mask"], w, cfg).numpy()
+    assert out.shape == z["out"].shape
+    # same arithmetic, different op order/threads: fp32 rounding only
+    assert np.abs(out - z["out"]).max() < 2e-5
+
+
+def test_encoder_padding_invariance(golden_dir):
+    """Q5: the CLS output does not depend on how far the batch is padded (what makes
+    varlen packing in the HIP path legitimate)."""
+    z, meta = _load(golden_dir, "enc_tiny_bert")
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    ids = np.pad(z["ids"], ((0, 0), (0, 17)), constant_values=cfg.pad_id)
+    mask = np.pad(z["mask"], ((0, 0), (0, 17)))
+    out = O.encode_cls(ids, mask, w, cfg).numpy()
+    assert np.abs(out - z["out"]).max() < 2e-5
+
+
+def test_additive_attention_matches_reference(golden_dir):
+    z, meta = _load(golden_dir, "additive_attention")
+    aw = make_additive_attention_weights(meta["input_dim"], meta["query_dim"], seed=meta["seed"])
+    p = [aw["additive_attention." + k] for k in ("linear.weight", "linear.bias", "query")]
+    assert np.abs(O.additive_attention(z["x"], *p).numpy() - z["out"]).max() < 1e-5
+    assert np.abs(O.additive_attention(z["x1"], *p).numpy() - z["out1"]).max() < 1e-6
+
+
+def test_dot_product_matches_reference(golden_dir):
+    z, _ = _load(golden_dir, "dot_product")
+    assert np.abs(O.dot_product(z["user"], z["cand"]).numpy() - z["out"]).max() < 1e-4
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    """Our weight naming is the reference checkpoint naming."""
+    with open(os.path.join(golden_dir, "state_dict_keys.json")) as f:
+        keys = json.load(f)
+    for preset in ("tiny-bert", "bert-base-uncased"):
+        ours = sorted("text_encoder.plm_model." + n for n, _ in plm_param_shapes(PRESETS[preset]))
+        assert ours == keys[preset]
+    assert keys["user_encoder"] == sorted(
+        ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"])
+
+
+def test_to_dense_batch_semantics():
+    x = torch.arange(10, dtype=torch.float32).view(5, 2)
+    batch = torch.tensor([0, 0, 2, 2, 2])           # segment 1 is empty
+    dense, mask = O.to_dense_batch(x, batch)
+    assert dense.shape == (3, 3, 2) and mask.tolist() == [[True, True, False], [False] * 3, [True] * 3]
+    assert torch.equal(dense[0, :2], x[:2]) and torch.equal(dense[2], x[2:]) and dense[1].abs().sum() == 0
+
+
+def test_pipeline_regression(golden_dir):
+    z, _ = _load(golden_dir, "pipeline")
+    tables = [torch.from_numpy(t) for t in z["tables"]]
+    hi, ci = torch.from_numpy(z["hist_idx"]).long(), torch.from_numpy(z["cand_idx"]).long()
+    ho, co = z["hist_off"].tolist(), z["cand_off"].tolist()
+    bh, bc = O.offsets_to_batch(ho), O.offsets_to_batch(co)
+    vecs = [(t[hi], t[ci]) for t in tables]
+    late = O.cr_scores(vecs[0][0], bh, vecs[0][1], bc)
+    assert np.array_equal(O.ragged(late, bc).numpy(), z["late"])
+    # hand check of late fusion for impression 0: mean of history rows, dot with candidates
+    u0 = tables[0][hi[ho[0]:ho[1]]].mean(0)
+    ref0 = tables[0][ci[co[0]:co[1]]] @ u0
+    assert np.abs(ref0.numpy() - z["late"][co[0]:co[1]]).max() < 1e-5
+    ue = (z["ue_w"], z["ue_b"], z["ue_q"])
+    early = O.cr_scores(vecs[0][0], bh, vecs[0][1], bc, late_fusion=False, user_encoder=ue)
+    assert np.allclose(O.ragged(early, bc).numpy(), z["early"], atol=1e-6)
+    ens = O.ragged(O.ensemble_scores(vecs, bh, bc, (-0.3, 0.2)), bc)
+    assert np.allclose(ens.numpy(), z["ens_-0.3_0.2"], atol=1e-6)
+    # z-score hand check: CR-only ensemble row has mean 0 / unbiased std 1 per impression
+    e0 = z["ens_0_0"][co[1]:co[2]]
+    assert abs(e0.mean()) < 1e-5 and abs(e0.std(ddof=1) - 1) < 1e-5
+    n10, per10 = O.ndcg_at_k(ens, torch.from_numpy(z["labels"]), co, 10)
+    assert abs(n10 - float(z["ndcg10"])) < 1e-12
+    top = O.topk_indices(ens, co, 10)
+    for i, t in enumerate(top):
+        assert t == [v for v in z["top10"][i].tolist() if v >= 0]
+
+
+def test_ndcg_hand_example():
+    scores = torch.tensor([0.1, 0.9, 0.5, 0.3, 0.2, 0.8])
+    target = torch.tensor([0.0, 1.0, 0.0, 1.0, 0.0, 0.0])
+    off = [0, 3, 6]
+    val, per = O.ndcg_at_k(scores, target, off, 10)
+    # imp 0: positive ranked 1st -> 1.0 ; imp 1: order (0.8, 0.3, 0.2) -> positive at rank 2
+    assert abs(per[0] - 1.0) < 1e-12 and abs(per[1] - 1 / np.log2(3)) < 1e-12
+    assert abs(val - per.mean().item()) < 1e-12
+    val0, _ = O.ndcg_at_k(scores, torch.zeros(6), off, 10)
+    assert val0 == 0.0
