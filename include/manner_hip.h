@@ -1,0 +1,169 @@
+/*
+ * manner_hip.h — C ABI of the MI355X (gfx950) MANNeR news-encoding + candidate-scoring hot path.
+ *
+ * The reference has no FFI: its "plugin boundary" for this path is a set of torch.nn.Module
+ * classes imported by name.  Each entry point below states which reference
+ * interface it replaces (paths relative to the reference repository root).  The Python mirror of
+ * those classes (manner_amd/models/components/) binds these symbols through ctypes; see
+ * INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is CALLER-OWNED DEVICE memory unless marked "host"; nothing is retained past
+ *     the call except by an encoder handle, which owns private packed copies of the weights;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and is asynchronous with respect to the host; no entry point allocates, frees or
+ *     synchronises except *_create / *_destroy / manner_hip_encoder_status;
+ *   - return value: 0 = ok, non-zero = MANNER_HIP_E_*; manner_hip_last_error() returns a
+ *     thread-local message for the most recent failure.  No C++ exception crosses the ABI.
+ */
+#ifndef MANNER_HIP_H
+#define MANNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MANNER_HIP_ABI_VERSION 1
+
+enum {
+  MANNER_HIP_OK = 0,
+  MANNER_HIP_E_INVALID = 1,     /* bad argument (shape, alignment, unsupported architecture) */
+  MANNER_HIP_E_WORKSPACE = 2,   /* workspace too small */
+  MANNER_HIP_E_RUNTIME = 3,     /* HIP runtime error */
+  MANNER_HIP_E_INPUT = 4        /* device-side input validation failed (see encoder_status) */
+};
+
+enum { MANNER_HIP_ARCH_BERT = 0, MANNER_HIP_ARCH_ROBERTA = 1 };
+
+/* Arithmetic of the encoder GEMMs/attention.  F32: f32 operands on the f32 MFMA (exact f32 FMA
+ * chains; the 1e-4 parity mode).  BF16: bf16 operands, f32 accumulation, f32 LayerNorm/softmax. */
+enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1 };
+
+typedef void* manner_hip_stream_t;
+typedef struct manner_hip_encoder* manner_hip_encoder_t;
+
+typedef struct manner_hip_encoder_config {
+  int32_t arch;         /* MANNER_HIP_ARCH_* : position-id rule */
+  int32_t hidden;       /* H, multiple of 128 */
+  int32_t layers;
+  int32_t heads;        /* head_dim = H / heads must be 64 */
+  int32_t intermediate; /* I, multiple of 128 */
+  int32_t vocab;
+  int32_t max_pos;
+  int32_t type_vocab;
+  int32_t pad_id;       /* RoBERTa: positions start at pad_id + 1 */
+  float ln_eps;
+} manner_hip_encoder_config;
+
+/* Order of the fp32 device pointers in the `weights` table of manner_hip_encoder_create: the HF
+ * BertModel/RobertaModel state_dict tensors that sit under
+ * "news_encoder.text_encoder.plm_model." in a reference checkpoint, nn.Linear
+ * layout [out, in].  5 embedding tensors, then 16 per layer. */
+enum {
+  MANNER_HIP_W_WORD_EMB = 0, MANNER_HIP_W_POS_EMB, MANNER_HIP_W_TYPE_EMB,
+  MANNER_HIP_W_EMB_LN_G, MANNER_HIP_W_EMB_LN_B,
+  MANNER_HIP_W_EMB_COUNT
+};
+enum {
+  MANNER_HIP_WL_Q_W = 0, MANNER_HIP_WL_Q_B, MANNER_HIP_WL_K_W, MANNER_HIP_WL_K_B,
+  MANNER_HIP_WL_V_W, MANNER_HIP_WL_V_B, MANNER_HIP_WL_AO_W, MANNER_HIP_WL_AO_B,
+  MANNER_HIP_WL_ALN_G, MANNER_HIP_WL_ALN_B, MANNER_HIP_WL_FF1_W, MANNER_HIP_WL_FF1_B,
+  MANNER_HIP_WL_FF2_W, MANNER_HIP_WL_FF2_B, MANNER_HIP_WL_OLN_G, MANNER_HIP_WL_OLN_B,
+  MANNER_HIP_WL_COUNT
+};
+
+int manner_hip_abi_version(void);
+const char* manner_hip_last_error(void);
+
+/* ---------------------------------------------------------------- text encoder (K1-K7)
+ * Replaces MannerTextEncoder.__init__/forward — manner/models/components/news_encoder.py:11-37 —
+ * i.e. `AutoModel.from_pretrained(plm)(**tokenized).last_hidden_state[:, 0, :]`, eval mode. */
+
+/* Pack the PLM weights (fp32 device pointers, table order above, MANNER_HIP_W_EMB_COUNT +
+ * layers*MANNER_HIP_WL_COUNT entries) into the handle's private bf16 and/or fp32 GEMM layouts.
+ * `precisions` is a bit mask (1 << MANNER_HIP_PREC_*) of the modes the handle must serve.
+ * Synchronises `stream` before returning; the source tensors may be freed afterwards. */
+int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/,
+                              int32_t n_weights, uint32_t precisions, manner_hip_stream_t stream,
+                              manner_hip_encoder_t* out /*host*/);
+int manner_hip_encoder_destroy(manner_hip_encoder_t enc);
+
+/* Bytes of scratch manner_hip_encode_cls needs to process `max_tokens` packed tokens and
+ * `max_news` news per internal chunk. */
+size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens,
+                                          int32_t precision);
+
+/* CLS embeddings of `n_news` tokenised news.
+ *   ids, mask : int64 [n_news, padded_len] row-major, exactly the tensors of the reference's
+ *               BatchEncoding (manner/data/components/mind_rec_dataset.py:134-137); `mask` must be
+ *               a right-padded 0/1 prefix mask with >= 1 real token per news (validated on device,
+ *               see manner_hip_encoder_status);
+ *   host_lengths : optional host int32 [n_news] copy of the row sums of `mask`.  With it the
+ *               launch grids are exact; without it (NULL) grids cover n_news*padded_len tokens
+ *               and surplus workgroups exit early.  No host synchronisation either way;
+ *   out       : float32 [n_news, H].
+ * News are processed in internal chunks that fit the workspace; padding tokens cost no FLOPs
+ * (tokens are packed; SURVEY.md Q5 makes this equivalent to the padded reference computation). */
+int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask,
+                          const int32_t* host_lengths /*host, nullable*/, int64_t n_news, int64_t padded_len,
+                          int32_t precision, float* out, void* workspace, size_t workspace_bytes,
+                          manner_hip_stream_t stream);
+
+/* Blocking: synchronises `stream` and returns MANNER_HIP_E_INPUT if any encode_cls call on this
+ * handle since the last status call saw an invalid mask (non-prefix, empty or longer than
+ * MANNER_HIP_MAX_LEN); clears the flag. */
+int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stream);
+#define MANNER_HIP_MAX_LEN 128
+
+/* ---------------------------------------------------------------- pooler (K11)
+ * Replaces AdditiveAttention.forward — manner/models/components/attention.py:12-29 — and through
+ * it NAMLUserEncoder.forward — manner/models/components/user_encoder.py:17-21.
+ *   x [B,S,D] f32 contiguous; lin_w [Q,D]; lin_b [Q]; query [Q]; out [B,D] f32.
+ * No padding mask, as in the reference.  scratch: B*S floats. */
+int manner_hip_additive_pool(const float* x, const float* lin_w, const float* lin_b, const float* query,
+                             int64_t B, int64_t S, int32_t D, int32_t Q, float* out, float* scratch,
+                             manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- scorer (K12, K9+K10+K12)
+ * Replaces DotProduct.forward — manner/models/components/click_predictors.py:9-12:
+ * out[b,c] = <user[b,:], cand[b,:,c]>.  `cand` is addressed with element strides so that the
+ * reference call site's permuted view (manner/models/cr_module.py:127-129) is read in place. */
+int manner_hip_dot(const float* user, const float* cand, int64_t B, int64_t C, int32_t D,
+                   int64_t cand_stride_b, int64_t cand_stride_d, int64_t cand_stride_c,
+                   float* out /*[B,C]*/, manner_hip_stream_t stream);
+
+/* Fused late-fusion scorer over a news-embedding table: replaces the tail of CRModule.forward —
+ * manner/models/cr_module.py:108-131 with late_fusion=True — and of
+ * EnsembleModule._submodel_forward — manner/models/ensemble_module.py:116-135:
+ * user_i = sum(table[hist_idx[hist_off[i]:hist_off[i+1]]]) / h_i ;
+ * out[j] = <user_i, table[cand_idx[j]]> for j in [cand_off[i], cand_off[i+1]).
+ * table f32 [n_rows, D]; idx int32; off int64 [B+1]; out f32 [cand_off[B]] (ragged order). */
+int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D,
+                                 const int32_t* hist_idx, const int64_t* hist_off,
+                                 const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
+                                 float* out, manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- ensemble (K13+K14)
+ * Replaces the z-normalisation of EnsembleModule._submodel_forward —
+ * manner/models/ensemble_module.py:138-149 — and the fusion of EnsembleModule.forward — :95-109:
+ * out = z(scores[0]) + sum_{k>=1, w[k-1] != 0} w[k-1] * z(scores[k]), z per impression with the
+ * unbiased std (c_i == 1 gives NaN, as torch.std does).
+ * scores: K planes of f32 [total] at stride `plane_stride` elements; weights host f32 [K-1]. */
+int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K, const float* weights /*host*/,
+                           const int64_t* cand_off, int64_t B, float* out, manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- ranking / nDCG (K15)
+ * Replaces what RetrievalNormalizedDCG(top_k=k) computes per impression (constructed at
+ * manner/models/cr_module.py:83-84, fed at :267-273): stable descending rank of each candidate.
+ * topk_idx int32 [B,k]: position (within the impression) of the r-th ranked candidate, -1 padded.
+ * ndcg f32 [B]: DCG@k/IDCG@k, 0 for impressions without a positive label. Either may be NULL. */
+int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B,
+                         int32_t k, int32_t* topk_idx, float* ndcg, manner_hip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANNER_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libmanner_hip.so (the C ABI declared in include/manner_hip.h).
+
+There is no CPU fallback: if the library is missing this raises, and every wrapper in
+``manner_amd.hip`` refuses non-GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
+
+PREC_F32, PREC_BF16 = 0, 1
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+W_EMB_COUNT, WL_COUNT = 5, 16
+MAX_LEN = 128
+
+
+class EncoderConfigC(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+                ("intermediate", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32),
+                ("type_vocab", C.c_int32), ("pad_id", C.c_int32), ("ln_eps", C.c_float)]
+
+
+_P, _I64, _I32, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+SIGNATURES = {
+    "manner_hip_abi_version": (C.c_int, []),
+    "manner_hip_last_error": (C.c_char_p, []),
+    "manner_hip_encoder_create": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, C.c_uint32, _P,
+                                            C.POINTER(_P)]),
+    "manner_hip_encoder_destroy": (C.c_int, [_P]),
+    "manner_hip_encoder_workspace_bytes": (_SZ, [_P, _I64, _I64, _I32]),
+    "manner_hip_encode_cls": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P]),
+    "manner_hip_encoder_status": (C.c_int, [_P, _P]),
+    "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
+    "manner_hip_dot": (C.c_int, [_P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P]),
+    "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P]),
+    "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P]),
+    "manner_hip_rank_ndcg": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/manner_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(manner_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MANNeR HIP hot path has no CPU fallback. "
+                "Build it with `python -m manner_amd.build` (hipcc, gfx950).")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.manner_hip_abi_version() != 1:
+            raise RuntimeError("libmanner_hip.so ABI version mismatch; rebuild with `python -m manner_amd.build`")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"manner_hip error {rc}: {load().manner_hip_last_error().decode(errors='replace')}")

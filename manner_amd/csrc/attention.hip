@@ -1,0 +1,222 @@
+// K3: bidirectional multi-head self-attention over packed variable-length news
+// (HF BertSelfAttention / eager_attention_forward, transformers/models/bert/modeling_bert.py:111-136,
+// 188-203; additive padding mask of :704-708).  Tokens are packed, so the padding mask becomes
+// "keys of the same news only"; head_dim is 64 and a news has at most 128 tokens, so the whole
+// score row of a query fits in registers and softmax needs no online rescaling.
+//
+// bf16 path — one 64-lane wave per (news, head), no workgroup barriers:
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K rows as the A operand: a lane then owns ONE query
+//                 (column) and 16 keys per 32-key tile, so max / sum are in-lane reductions plus
+//                 one exchange with lane^32;
+//   O^T = V^T P^T the S^T accumulators, converted pairwise to bf16, ARE the B operand of the second
+//                 product (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
+//                 operand"), k-order permuted: element j of lane half h is key 16s+8(j>>2)+4h+(j&3);
+//                 V sits row-major in a wave-private LDS image and is read key-permuted and
+//                 transposed with ds_read_b64_tr_b16.  O^T keeps the query on the lane, so the
+//                 1/sum scaling is lane-local and stores are 8-byte runs along the ctx row.
+// f32 path — exact-f32 VALU kernel for the parity mode, one workgroup per (news, head).
+#include <math.h>
+
+#include "common.h"
+
+namespace manner {
+namespace {
+
+template <int NKT>
+__device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                               int tok0, int L, int H, int head, char* vl) {
+  const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
+  const size_t ld = 3 * (size_t)H;
+  const bf16_t* Qb = qkv + (size_t)tok0 * ld + head * 64;
+  const bf16_t* Kb = Qb + H;
+  const bf16_t* Vb = Qb + 2 * H;
+
+  // V -> LDS [32*NKT][64] bf16 row-major; rows >= L replicate row L-1 (finite, weighted by P = 0)
+#pragma unroll
+  for (int r0 = 0; r0 < 32 * NKT; r0 += 8) {
+    const int row = r0 + (lane >> 3);
+    const int sr = min(row, L - 1);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vb + (size_t)sr * ld + (lane & 7) * 8);
+    *reinterpret_cast<bf16x8*>(vl + row * 128 + (lane & 7) * 16) = v;
+  }
+  // K fragments (A operand): lane (rr, h) holds K[key = 32kt + rr][d = 16ks + 8h .. +7]
+  bf16x8 kf[NKT][4];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int key = min(32 * kt + rr, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      kf[kt][ks] = *reinterpret_cast<const bf16x8*>(Kb + (size_t)key * ld + (2 * ks + h) * 8);
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own V image is in LDS
+
+  // per-lane address of the transposed V reads: 16-lane group g, lane i = 4q + p of the group
+  // supplies row q, columns 4p..4p+3 of the group's 4x16 block
+  const int gi = lane & 15;
+  const int tr_base = ((gi >> 2) * 64 + 16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2 + (4 * h) * 128;
+
+#pragma unroll
+  for (int qb = 0; qb < NKT; ++qb) {
+    if (32 * qb >= L) break;
+    const int qrow = min(32 * qb + rr, L - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ld + (2 * ks + h) * 8);
+
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], s[kt], 0, 0, 0);
+    }
+    // scale (head_dim^-0.5 = 1/8), mask keys of other/padded positions, softmax over keys
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float v = key < L ? s[kt][e] * 0.125f : -INFINITY;
+        s[kt][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    bf16x8 pf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const bf16_t p = (bf16_t)__expf(s[kt][e] - mx);
+        pf[kt][e >> 3][e & 7] = p;
+        sum += (float)p;               // normalise by the sum of the ROUNDED weights
+      }
+    sum += __shfl_xor(sum, 32, 64);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char* a0 = vl + tr_base + (32 * kt + 16 * s2) * 128 + (32 * dt) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * 128));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], o[dt], 0, 0, 0);
+        }
+    }
+    const int q = 32 * qb + rr;
+    if (q < L) {
+      const float inv = 1.0f / sum;
+      bf16_t* dst = ctx + (size_t)(tok0 + q) * H + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * dt + 8 * g + 4 * h;
+          *reinterpret_cast<bf16x4*>(dst + d0) =
+              bf16x4{(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv),
+                     (bf16_t)(o[dt][4 * g + 2] * inv), (bf16_t)(o[dt][4 * g + 3] * inv)};
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                           const int32_t* __restrict__ cu, int64_t n_pairs,
+                                                           int heads, int H, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char vlds[];
+  const int wave = threadIdx.x >> 6;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+  if (pair >= n_pairs) return;
+  const int n = (int)(pair / heads), head = (int)(pair - (int64_t)n * heads);
+  const int tok0 = __builtin_amdgcn_readfirstlane(cu[n]);
+  const int L = __builtin_amdgcn_readfirstlane(cu[n + 1]) - tok0;
+  char* vl = vlds + wave * lds_per_wave;
+  if (L <= 32) attn_wave_bf16<1>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 64) attn_wave_bf16<2>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 96) attn_wave_bf16<3>(qkv, ctx, tok0, L, H, head, vl);
+  else attn_wave_bf16<4>(qkv, ctx, tok0, L, H, head, vl);
+}
+
+// exact-f32 attention: one workgroup (128 threads, one per query) per (news, head)
+__global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                       const int32_t* __restrict__ cu, int heads, int H) {
+  __shared__ __attribute__((aligned(16))) float Ks[MANNER_HIP_MAX_LEN * 64];
+  __shared__ __attribute__((aligned(16))) float Vs[MANNER_HIP_MAX_LEN * 64];
+  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  const int tok0 = cu[n], L = cu[n + 1] - tok0;
+  const size_t ld = 3 * (size_t)H;
+  const float* Qb = qkv + (size_t)tok0 * ld + head * 64;
+  for (int i = threadIdx.x; i < L * 16; i += 128) {
+    const int row = i >> 4, c = (i & 15) * 4;
+    *reinterpret_cast<f32x4*>(Ks + row * 64 + c) = *reinterpret_cast<const f32x4*>(Qb + (size_t)row * ld + H + c);
+    *reinterpret_cast<f32x4*>(Vs + row * 64 + c) = *reinterpret_cast<const f32x4*>(Qb + (size_t)row * ld + 2 * H + c);
+  }
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q >= L) return;
+  float qv[64];
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(Qb + (size_t)q * ld + c);
+    qv[c] = t[0]; qv[c + 1] = t[1]; qv[c + 2] = t[2]; qv[c + 3] = t[3];
+  }
+  auto score = [&](int key) {
+    const float* kr = Ks + key * 64;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a = fmaf(qv[c], kr[c], a);
+    return a * 0.125f;
+  };
+  float mx = -INFINITY;
+  for (int key = 0; key < L; ++key) mx = fmaxf(mx, score(key));
+  float sum = 0.f, o[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) o[c] = 0.f;
+  for (int key = 0; key < L; ++key) {
+    const float p = expf(score(key) - mx);
+    sum += p;
+    const float* vr = Vs + key * 64;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) o[c] = fmaf(p, vr[c], o[c]);
+  }
+  const float inv = 1.0f / sum;
+  float* dst = ctx + (size_t)(tok0 + q) * H + head * 64;
+#pragma unroll
+  for (int c = 0; c < 64; c += 4)
+    *reinterpret_cast<f32x4*>(dst + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+}
+
+}  // namespace
+
+int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, int64_t n_news, int heads, int H,
+                     int max_len, hipStream_t stream) {
+  if (H != heads * 64) return fail(MANNER_HIP_E_INVALID, "head_dim must be 64 (H=%d heads=%d)", H, heads);
+  if (max_len < 1 || max_len > MANNER_HIP_MAX_LEN)
+    return fail(MANNER_HIP_E_INVALID, "padded length %d exceeds the %d-token attention tile", max_len, MANNER_HIP_MAX_LEN);
+  const int64_t pairs = n_news * heads;
+  if (dt == DT_BF16) {
+    const int nkt = (max_len + 31) / 32;
+    const int lds_per_wave = nkt * 32 * 128;
+    hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
+                       static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
+  } else {
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)pairs), dim3(128), 0, stream, static_cast<const float*>(qkv),
+                       static_cast<float*>(ctx), cu, heads, H);
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+}  // namespace manner

@@ -1,0 +1,274 @@
+// Encoder handle: packed PLM weights + the per-chunk layer schedule behind
+// manner_hip_encode_cls (K1-K7: MannerTextEncoder.forward, reference
+// manner/models/components/news_encoder.py:29-37 over HF BertModel.forward,
+// transformers/models/bert/modeling_bert.py:623-686).
+//
+// Tokens of a chunk of news are PACKED (no padding rows): x[cu[n] + t] is token t of news n.
+// Per layer:  qkv = x Wqkv^T + b          (one GEMM over the fused [3H, H] weight)
+//             ctx = attention(qkv)        (per news, per head)
+//             pre = ctx Wo^T + b + x      (f32)         x = LN(pre)
+//             ffn = gelu(x W1^T + b)                    pre = ffn W2^T + b + x ; x = LN(pre)
+// Activations x/qkv/ctx/ffn are bf16 (MANNER_HIP_PREC_BF16) or f32 (MANNER_HIP_PREC_F32); the
+// pre-LayerNorm sums, LayerNorm statistics, softmax and all accumulation are f32 in both modes.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace manner {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+struct LayerWeights {
+  void* wqkv = nullptr;   // [3H, H]
+  void* wo = nullptr;     // [H, H]
+  void* w1 = nullptr;     // [I, H]
+  void* w2 = nullptr;     // [H, I]
+};
+struct LayerParams {      // f32, shared by both precisions
+  float *bqkv, *bo, *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
+};
+
+}  // namespace manner
+
+struct manner_hip_encoder {
+  manner_hip_encoder_config cfg;
+  uint32_t precisions = 0;
+  float *word = nullptr, *pos = nullptr, *type0 = nullptr, *embg = nullptr, *embb = nullptr;
+  std::vector<manner::LayerParams> params;
+  std::vector<manner::LayerWeights> w[2];   // [MANNER_HIP_PREC_*]
+  int32_t* status = nullptr;                // device flag word
+  std::vector<void*> allocs;
+};
+
+namespace manner {
+namespace {
+
+int dev_alloc(manner_hip_encoder* e, size_t bytes, void** out) {
+  MANNER_HIP_TRY(hipMalloc(out, bytes));
+  e->allocs.push_back(*out);
+  return MANNER_HIP_OK;
+}
+int dev_copy_f32(manner_hip_encoder* e, const float* src, size_t n, float** out, hipStream_t s) {
+  int rc = dev_alloc(e, n * sizeof(float), (void**)out);
+  if (rc) return rc;
+  MANNER_HIP_TRY(hipMemcpyAsync(*out, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return MANNER_HIP_OK;
+}
+// place rows of an f32 [rows, cols] matrix at dst (+row offset) in the precision's element type
+int pack_matrix(int prec, const float* src, size_t n, void* dst, size_t elem_off, hipStream_t s) {
+  if (prec == MANNER_HIP_PREC_BF16) return convert_f32_to_bf16(src, static_cast<bf16_t*>(dst) + elem_off, (int64_t)n, s);
+  MANNER_HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst) + elem_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return MANNER_HIP_OK;
+}
+
+struct Workspace {
+  int32_t *lens, *cu, *m_total;
+  float* pre;
+  void *x, *qkv, *ctx, *ffn;
+};
+
+size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
+  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (size_t)round_up((int64_t)bytes, 256); return base ? base + o : nullptr; };
+  char* p;
+  p = take((size_t)max_news * 4); if (ws) ws->lens = (int32_t*)p;
+  p = take((size_t)(max_news + 1) * 4); if (ws) ws->cu = (int32_t*)p;
+  p = take(256); if (ws) ws->m_total = (int32_t*)p;
+  p = take((size_t)m_cap * H * 4); if (ws) ws->pre = (float*)p;
+  p = take((size_t)m_cap * H * es); if (ws) ws->x = p;
+  p = take((size_t)m_cap * 3 * H * es); if (ws) ws->qkv = p;
+  p = take((size_t)m_cap * H * es); if (ws) ws->ctx = p;
+  p = take((size_t)m_cap * I * es); if (ws) ws->ffn = p;
+  return off;
+}
+
+int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t lp,
+                 int64_t m_bound, int prec, float* out, const Workspace& ws, hipStream_t s) {
+  const manner_hip_encoder_config& c = e->cfg;
+  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
+  const int H = c.hidden, I = c.intermediate;
+  int rc;
+  if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, e->status, s))) return rc;
+  const int pos_offset = c.arch == MANNER_HIP_ARCH_ROBERTA ? c.pad_id + 1 : 0;
+  if ((rc = embed_layernorm(dt, ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, e->embg, e->embb, H, c.ln_eps,
+                            pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
+    return rc;
+  for (int l = 0; l < c.layers; ++l) {
+    const LayerWeights& w = e->w[prec][l];
+    const LayerParams& p = e->params[l];
+    if ((rc = gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))) return rc;
+    if ((rc = attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))) return rc;
+    if ((rc = gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))) return rc;
+    if ((rc = layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))) return rc;
+    if ((rc = gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))) return rc;
+    if ((rc = gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))) return rc;
+    if ((rc = layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))) return rc;
+  }
+  return gather_cls(dt, ws.x, ws.cu, n_news, H, out, s);
+}
+
+}  // namespace
+}  // namespace manner
+
+using namespace manner;
+
+extern "C" {
+
+int manner_hip_abi_version(void) { return MANNER_HIP_ABI_VERSION; }
+const char* manner_hip_last_error(void) { return g_err; }
+
+int manner_hip_encoder_destroy(manner_hip_encoder_t enc) {
+  if (!enc) return MANNER_HIP_OK;
+  for (void* p : enc->allocs) (void)hipFree(p);
+  delete enc;
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                              uint32_t precisions, manner_hip_stream_t stream, manner_hip_encoder_t* out) {
+  if (!cfg || !weights || !out) return fail(MANNER_HIP_E_INVALID, "encoder_create: null argument");
+  const int H = cfg->hidden, I = cfg->intermediate, L = cfg->layers;
+  if (cfg->arch != MANNER_HIP_ARCH_BERT && cfg->arch != MANNER_HIP_ARCH_ROBERTA) return fail(MANNER_HIP_E_INVALID, "encoder_create: unknown arch %d", cfg->arch);
+  if (H <= 0 || H % 128 || H > 1024 || cfg->heads <= 0 || H != cfg->heads * 64) return fail(MANNER_HIP_E_INVALID, "encoder_create: hidden=%d heads=%d (need H %% 128 == 0, H <= 1024, head_dim 64)", H, cfg->heads);
+  if (I <= 0 || I % 128 || L <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: intermediate=%d layers=%d unsupported", I, L);
+  if (cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->type_vocab <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: bad table sizes");
+  if (n_weights != MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT) return fail(MANNER_HIP_E_INVALID, "encoder_create: expected %d weight pointers, got %d", MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT, n_weights);
+  if (!(precisions & 3u) || (precisions & ~3u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
+  for (int i = 0; i < n_weights; ++i)
+    if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "encoder_create: weight pointer %d is null", i);
+
+  hipStream_t s = (hipStream_t)stream;
+  manner_hip_encoder* e = new manner_hip_encoder();
+  e->cfg = *cfg;
+  e->precisions = precisions;
+  int rc = MANNER_HIP_OK;
+  auto guard = [&](int r) { if (r && !rc) rc = r; return r == 0; };
+  const size_t HH = (size_t)H * H, HI = (size_t)H * I;
+  do {
+    if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_WORD_EMB], (size_t)cfg->vocab * H, &e->word, s))) break;
+    if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_POS_EMB], (size_t)cfg->max_pos * H, &e->pos, s))) break;
+    if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_TYPE_EMB], (size_t)H, &e->type0, s))) break;   // row 0 only
+    if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_EMB_LN_G], H, &e->embg, s))) break;
+    if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_EMB_LN_B], H, &e->embb, s))) break;
+    if (!guard(dev_alloc(e, 256, (void**)&e->status))) break;
+    if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
+    e->params.resize(L);
+    for (int p = 0; p < 2; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
+    for (int l = 0; l < L && !rc; ++l) {
+      const float* const* wl = weights + MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT;
+      LayerParams& P = e->params[l];
+      if (!guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.bqkv))) break;
+      for (int j = 0; j < 3; ++j)
+        if (hipMemcpyAsync(P.bqkv + j * H, wl[MANNER_HIP_WL_Q_B + 2 * j], H * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(MANNER_HIP_E_RUNTIME, "bias copy failed");
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_AO_B], H, &P.bo, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_ALN_G], H, &P.ln1g, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_ALN_B], H, &P.ln1b, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_FF1_B], I, &P.b1, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_FF2_B], H, &P.b2, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_G], H, &P.ln2g, s));
+      guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_B], H, &P.ln2b, s));
+      for (int p = 0; p < 2 && !rc; ++p) {
+        if (!(precisions & (1u << p))) continue;
+        const size_t es = p == MANNER_HIP_PREC_BF16 ? 2 : 4;
+        LayerWeights& W = e->w[p][l];
+        if (!guard(dev_alloc(e, 3 * HH * es, &W.wqkv))) break;
+        if (!guard(dev_alloc(e, HH * es, &W.wo))) break;
+        if (!guard(dev_alloc(e, HI * es, &W.w1))) break;
+        if (!guard(dev_alloc(e, HI * es, &W.w2))) break;
+        for (int j = 0; j < 3; ++j) guard(pack_matrix(p, wl[MANNER_HIP_WL_Q_W + 2 * j], HH, W.wqkv, j * HH, s));
+        guard(pack_matrix(p, wl[MANNER_HIP_WL_AO_W], HH, W.wo, 0, s));
+        guard(pack_matrix(p, wl[MANNER_HIP_WL_FF1_W], HI, W.w1, 0, s));
+        guard(pack_matrix(p, wl[MANNER_HIP_WL_FF2_W], HI, W.w2, 0, s));
+      }
+    }
+    if (rc) break;
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "encoder_create: stream sync failed: %s", hipGetErrorString(hipGetLastError())); break; }
+  } while (0);
+  if (rc) { manner_hip_encoder_destroy(e); return rc; }
+  *out = e;
+  return MANNER_HIP_OK;
+}
+
+size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens, int32_t precision) {
+  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 1) return 0;
+  return carve(enc, max_news, round_up(max_tokens, 128), precision, nullptr, nullptr);
+}
+
+int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
+                          int64_t n_news, int64_t padded_len, int32_t precision, float* out, void* workspace,
+                          size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_cls: null handle");
+  if (n_news == 0) return MANNER_HIP_OK;
+  if (!ids || !mask || !out || !workspace || n_news < 0) return fail(MANNER_HIP_E_INVALID, "encode_cls: null pointer");
+  if (precision < 0 || precision > 1 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
+  if (padded_len < 1 || padded_len > MANNER_HIP_MAX_LEN) return fail(MANNER_HIP_E_INVALID, "encode_cls: padded_len %lld outside [1, %d]", (long long)padded_len, MANNER_HIP_MAX_LEN);
+  if ((uintptr_t)workspace % 256) return fail(MANNER_HIP_E_INVALID, "encode_cls: workspace must be 256-byte aligned");
+  const int H = enc->cfg.hidden;
+  // largest (news, tokens) chunk capacity the workspace admits: tokens scale the big buffers
+  const size_t es = precision == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es;
+  int64_t m_cap = (int64_t)(workspace_bytes / per_tok) / 128 * 128;
+  int64_t n_cap = 0;
+  while (m_cap >= 128) {
+    n_cap = m_cap;   // a news has >= 1 token, so a chunk never holds more news than tokens
+    if (n_cap > n_news) n_cap = n_news;
+    if (carve(enc, n_cap, m_cap, precision, nullptr, nullptr) <= workspace_bytes) break;
+    m_cap -= 128;
+  }
+  if (m_cap < 128 || m_cap < padded_len) return fail(MANNER_HIP_E_WORKSPACE, "encode_cls: workspace of %zu bytes cannot hold one 128-token tile", workspace_bytes);
+  Workspace ws;
+  carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace), &ws);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t n0 = 0;
+  while (n0 < n_news) {
+    int64_t cnt = 0, m_bound;
+    if (host_lengths) {
+      int64_t tok = 0;
+      while (n0 + cnt < n_news && cnt < n_cap) {
+        const int64_t len = host_lengths[n0 + cnt];
+        if (len < 1 || len > padded_len) return fail(MANNER_HIP_E_INVALID, "encode_cls: host_lengths[%lld]=%lld outside [1, padded_len]", (long long)(n0 + cnt), (long long)len);
+        if (tok + len > m_cap) break;
+        tok += len;
+        ++cnt;
+      }
+      m_bound = round_up(tok, 128);
+    } else {
+      cnt = m_cap / padded_len;
+      if (cnt > n_cap) cnt = n_cap;
+      if (cnt > n_news - n0) cnt = n_news - n0;
+      m_bound = round_up(cnt * padded_len, 128);
+    }
+    int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
+                          out + n0 * H, ws, s);
+    if (rc) return rc;
+    n0 += cnt;
+  }
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stream) {
+  if (!enc) return fail(MANNER_HIP_E_INVALID, "encoder_status: null handle");
+  int32_t flag = 0;
+  hipStream_t s = (hipStream_t)stream;
+  MANNER_HIP_TRY(hipMemcpyAsync(&flag, enc->status, sizeof(flag), hipMemcpyDeviceToHost, s));
+  MANNER_HIP_TRY(hipMemsetAsync(enc->status, 0, sizeof(flag), s));
+  MANNER_HIP_TRY(hipStreamSynchronize(s));
+  if (flag & 1) return fail(MANNER_HIP_E_INPUT, "attention_mask is not a right-padded 0/1 prefix mask with 1..%d real tokens per news", MANNER_HIP_MAX_LEN);
+  if (flag & 2) return fail(MANNER_HIP_E_INPUT, "input_ids or position index out of range of the embedding tables");
+  return MANNER_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// Y = epi(X W^T + b) on the gfx950 matrix cores — the PLM's Linear layers (K2, K4, K5, K6 of
+// SURVEY.md §2.2; HF BertSelfAttention/BertSelfOutput/BertIntermediate/BertOutput dense layers,
+// transformers/models/bert/modeling_bert.py:175-177, 289-293, 334-337, 347-351).
+//
+// Both operands are K-contiguous (activations [M,K], nn.Linear weight [N,K]), so one staging and
+// fragment-read routine serves both.  The kernel computes the TRANSPOSED tile D[n][m] =
+// sum_k W[n][k] X[m][k] (weights as the MFMA A operand): in the 32x32 accumulator layout a lane
+// then owns one token m and runs of 4 consecutive features n, so the epilogue (bias, erf-GeLU,
+// residual) is lane-local and stores are 8/16-byte vectors along the output row.
+//
+// Tile 128(m) x 128(n), 4 waves as 2(n) x 2(m), each 64x64 = 2x2 MFMA tiles of 32x32.
+// K advances 128 BYTES per stage for either dtype (64 bf16 or 32 f32): the LDS image is
+// [128 rows][128 B] per operand, filled by global_load_lds_dwordx4 (1 KiB = 8 rows per
+// wave-instruction, lane-linear destination) and read back as 16-byte chunks.  Chunk c of row r
+// is stored at chunk slot c ^ ((r >> 1) & 7): with 128-byte rows that makes every 16-lane group of
+// a ds_read_b128 (rows r..r+31 at one chunk index) hit 16 distinct 16-byte slots of the 256-byte
+// bank row.  The swizzle is applied on the per-lane global SOURCE address and again on the read
+// (cdna_hip_programming.md rule 21).
+//   bf16: one v_mfma_f32_32x32x16_bf16 per 16-byte chunk pair (lane half h holds k = 8h..8h+7).
+//   f32 : four v_mfma_f32_32x32x2_f32 per chunk (element e of lane half h is k = 4h+e of the
+//         chunk pair) — exact f32 FMA chains, the 1e-4 parity mode.
+#include "common.h"
+
+namespace manner {
+namespace {
+
+constexpr int BM = 128, BN = 128, ROW_BYTES = 128, TILE_BYTES = 128 * ROW_BYTES;  // 16 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;                                        // W + X
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // nn.functional.gelu default (transformers/activations.py ACT2FN["gelu"]): x/2 * (1 + erf(x/sqrt2))
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(const typename Frag<T>::type& a, const typename Frag<T>::type& b,
+                                          f32x16& acc);
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_t>(const bf16x8& a, const bf16x8& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(const f32x4& a, const f32x4& b, f32x16& acc) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+}
+
+template <typename TOut>
+__device__ __forceinline__ void store4(TOut* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float v[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+  bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+template <typename TIn, typename TOut, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
+    const TIn* __restrict__ X, const TIn* __restrict__ W, const float* __restrict__ bias,
+    const TIn* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles) {
+  constexpr int EPC = 16 / sizeof(TIn);          // elements per 16-byte chunk
+  constexpr int BK = ROW_BYTES / sizeof(TIn);    // elements of K per stage
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of tiles (bijective form for any grid size).  Tiles that share an activation
+  // row-panel are consecutive, so the panel is fetched into one XCD's L2 once.
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int M = *m_total;
+  if (mt * BM >= M) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rr = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wm = wave & 1;
+
+  // staging: wave w fills pieces 4w..4w+3 (8 rows each) of both operand tiles
+  const int srow = lane >> 3, sdst = lane & 7;
+  const TIn* wsrc[4];
+  const TIn* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + srow;
+    const int csrc = sdst ^ ((row >> 1) & 7);
+    wsrc[i] = W + (size_t)(nt * BN + row) * K + csrc * EPC;
+    xsrc[i] = X + (size_t)(mt * BM + row) * K + csrc * EPC;
+  }
+  auto stage = [&](int buf, int k0) {
+    char* base = lds + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wsrc[i] + k0), LDS_PTR(base + (4 * wave + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xsrc[i] + k0), LDS_PTR(base + TILE_BYTES + (4 * wave + i) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (rr >> 1) & 7;   // rows 32i + rr (+64 wn): (row >> 1) & 7 == (rr >> 1) & 7
+  const int woff = (wn * 64 + rr) * ROW_BYTES;
+  const int xoff = TILE_BYTES + (wm * 64 + rr) * ROW_BYTES;
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();   // emits vmcnt(0) for the pending LDS-DMA
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const char* base = lds + cur * STAGE_BYTES;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int coff = ((2 * kc + h) ^ swz) << 4;
+      typename Frag<TIn>::type a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const typename Frag<TIn>::type*>(base + woff + i * 32 * ROW_BYTES + coff);
+        bb[i] = *reinterpret_cast<const typename Frag<TIn>::type*>(base + xoff + i * 32 * ROW_BYTES + coff);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma_chunk<TIn>(a[i], bb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][reg] = D[n][m], n = 32i + (reg&3) + 8(reg>>2) + 4h, m = 32j + rr
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = mt * BM + wm * 64 + 32 * j + rr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = nt * BN + wn * 64 + 32 * i + 8 * g + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (EPI == EPI_BIAS_RES) {
+          float r[4];
+          load4<TIn>(R + (size_t)m * N + n0, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        store4<TOut>(Y + (size_t)m * N + n0, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename TIn, typename TOut>
+int launch(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
+           int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  const int n_tiles = N / BN;
+  const int64_t grid = (m_bound / BM) * n_tiles;
+  if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
+  dim3 g((unsigned)grid), b(256);
+  const TIn* x = static_cast<const TIn*>(X);
+  const TIn* w = static_cast<const TIn*>(W);
+  const TIn* r = static_cast<const TIn*>(R);
+  TOut* y = static_cast<TOut*>(Y);
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_tn_kernel<TIn, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_tn_kernel<TIn, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_RES:
+      hipLaunchKernelGGL((gemm_tn_kernel<TIn, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+}  // namespace
+
+int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,
+            const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
+            hipStream_t stream) {
+  const int esz = in == DT_BF16 ? 2 : 4;
+  if (N % BN || (K * esz) % ROW_BYTES || m_bound % BM)
+    return fail(MANNER_HIP_E_INVALID, "gemm shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  if (epi == EPI_BIAS_RES && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
+  if (in == DT_BF16 && out == DT_BF16) return launch<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  if (in == DT_BF16 && out == DT_F32) return launch<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  if (in == DT_F32 && out == DT_F32) return launch<float, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
+}
+
+}  // namespace manner

@@ -1,0 +1,237 @@
+// HBM-bound row kernels of the encoder: sequence lengths + packing offsets, embedding gather +
+// LayerNorm (K1), LayerNorm (tail of K4/K6), CLS gather (K7), f32 -> bf16 weight conversion.
+// One 64-lane wave per row, 16-byte accesses, two-pass mean/variance in registers, shuffle
+// reductions (no LDS).
+#include "common.h"
+
+namespace manner {
+namespace {
+
+constexpr int MAX_H = 1024;          // 4 x float4 per lane
+constexpr int VEC_PER_LANE = MAX_H / 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- lengths: one wave per news; validates that mask is a 0/1 prefix with 1 <= len <= MAX_LEN
+__global__ __launch_bounds__(256) void lengths_kernel(const int64_t* __restrict__ mask, int64_t n_news,
+                                                      int64_t lp, int32_t* __restrict__ lens,
+                                                      int32_t* __restrict__ status) {
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= n_news) return;
+  const int64_t* row = mask + n * lp;
+  int cnt = 0, bad = 0, last_one = -1;
+  for (int64_t j = lane; j < lp; j += 64) {
+    const int64_t v = row[j];
+    if (v != 0) { cnt++; last_one = (int)j; if (v != 1) bad = 1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    bad |= __shfl_xor(bad, o, 64);
+    last_one = max(last_one, __shfl_xor(last_one, o, 64));
+  }
+  if (last_one + 1 != cnt) bad = 1;                      // a hole: not a prefix mask
+  if (cnt < 1 || cnt > MANNER_HIP_MAX_LEN) bad = 1;
+  if (lane == 0) {
+    lens[n] = bad ? 1 : cnt;                             // keep downstream indexing in bounds
+    if (bad) atomicOr(status, 1);
+  }
+}
+
+// ---- exclusive scan of lens -> cu[0..n], m_total; single workgroup (n is at most a chunk of news)
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ lens, int64_t n,
+                                                    int32_t* __restrict__ cu, int32_t* __restrict__ m_total) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = t * per, hi = min(n, lo + per);
+  int s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += lens[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int64_t i = lo; i < hi; ++i) { cu[i] = run; run += lens[i]; }
+  if (t == 1023) { cu[n] = part[1023]; *m_total = part[1023]; }
+}
+
+template <typename TOut>
+__device__ __forceinline__ void store_vec(TOut* p, const f32x4& v);
+template <>
+__device__ __forceinline__ void store_vec<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <>
+__device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f32x4& v) {
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+// normalise the H values a wave holds in v[] (lane owns columns (i*64+lane)*4 .. +3) and store
+template <typename TOut>
+__device__ __forceinline__ void wave_layernorm_store(f32x4 v[VEC_PER_LANE], int H, float eps,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TOut* __restrict__ dst,
+                                                     int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i)
+    if ((i * 64 + lane) * 4 < H) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i)
+    if ((i * 64 + lane) * 4 < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      store_vec<TOut>(dst + c, o);
+    }
+  }
+}
+
+// ---- K1: x[cu[n]+t] = LN(word[ids[n,t]] + type[0] + pos[t + pos_offset])
+// (transformers/models/bert/modeling_bert.py:68-108; RoBERTa positions start at pad_id+1,
+// transformers/models/roberta/modeling_roberta.py:142-155, for right-padded inputs.)
+template <typename TOut>
+__global__ __launch_bounds__(256) void embed_ln_kernel(
+    const int64_t* __restrict__ ids, int64_t lp, const int32_t* __restrict__ cu,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int H, float eps, int pos_offset,
+    int vocab, int max_pos, TOut* __restrict__ x, int32_t* __restrict__ status) {
+  const int64_t n = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int start = cu[n], len = cu[n + 1] - start;
+  for (int t = wave; t < len; t += 4) {
+    int64_t id = ids[n * lp + t];
+    int p = t + pos_offset;
+    if (id < 0 || id >= vocab || p >= max_pos) {       // would be an IndexError in the reference
+      if (lane == 0) atomicOr(status, 2);
+      id = 0; p = 0;
+    }
+    const float* wr = word + (size_t)id * H;
+    const float* pr = pos + (size_t)p * H;
+    f32x4 v[VEC_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < VEC_PER_LANE; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wr + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(type0 + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(pr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (a[e] + b[e]) + d[e];   // HF order: (word + type) + pos
+      }
+    }
+    wave_layernorm_store<TOut>(v, H, eps, gamma, beta, x + (size_t)(start + t) * H, lane);
+  }
+}
+
+// ---- LayerNorm over rows of the f32 pre-activation buffer
+template <typename TOut>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ pre,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int H, float eps,
+                                                        TOut* __restrict__ x, const int* __restrict__ m_total) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= *m_total) return;
+  const float* src = pre + (size_t)row * H;
+  f32x4 v[VEC_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) v[i] = *reinterpret_cast<const f32x4*>(src + c);
+  }
+  wave_layernorm_store<TOut>(v, H, eps, gamma, beta, x + (size_t)row * H, lane);
+}
+
+// ---- K7: out[n] = x[cu[n]] (the [CLS] row), as f32
+template <typename TIn>
+__global__ __launch_bounds__(256) void gather_cls_kernel(const TIn* __restrict__ x, const int32_t* __restrict__ cu,
+                                                         int64_t n_news, int H, float* __restrict__ out) {
+  const int64_t n = blockIdx.x;
+  const TIn* src = x + (size_t)cu[n] * H;
+  for (int c = threadIdx.x; c < H; c += 256) out[n * H + c] = (float)src[c];
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)src[i];
+}
+
+}  // namespace
+
+int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens, int32_t* cu,
+                        int32_t* m_total, int32_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(lengths_kernel, dim3((unsigned)((n_news + 3) / 4)), dim3(256), 0, stream, mask, n_news,
+                     padded_len, lens, status);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, lens, n_news, cu, m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu,
+                    const float* word, const float* pos, const float* type0, const float* gamma,
+                    const float* beta, int H, float eps, int pos_offset, int vocab, int max_pos, void* x,
+                    int32_t* status, hipStream_t stream) {
+  if (H % 4 || H > MAX_H) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported (<= %d, %%4)", H, MAX_H);
+  dim3 g((unsigned)n_news), b(256);
+  if (out == DT_BF16)
+    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, g, b, 0, stream, ids, padded_len, cu, word, pos, type0, gamma, beta,
+                       H, eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(x), status);
+  else
+    hipLaunchKernelGGL(embed_ln_kernel<float>, g, b, 0, stream, ids, padded_len, cu, word, pos, type0, gamma, beta,
+                       H, eps, pos_offset, vocab, max_pos, static_cast<float*>(x), status);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int layernorm_rows(DType out, const float* pre, const float* gamma, const float* beta, int H, float eps, void* x,
+                   int64_t m_bound, const int* m_total, hipStream_t stream) {
+  if (H % 4 || H > MAX_H) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported", H);
+  dim3 g((unsigned)((m_bound + 3) / 4)), b(256);
+  if (out == DT_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<bf16_t*>(x), m_total);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<float*>(x), m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream) {
+  dim3 g((unsigned)n_news), b(256);
+  if (in == DT_BF16)
+    hipLaunchKernelGGL(gather_cls_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(x), cu, n_news, H, out);
+  else
+    hipLaunchKernelGGL(gather_cls_kernel<float>, g, b, 0, stream, static_cast<const float*>(x), cu, n_news, H, out);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream) {
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+}  // namespace manner

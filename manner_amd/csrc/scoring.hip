@@ -1,0 +1,297 @@
+// HBM-bound tail of the hot path: additive-attention pooler (K11), dot-product scorer (K12), fused
+// gather-mean-dot scorer over the news-embedding table (K9+K10+K12), per-impression z-score +
+// weighted fusion (K13+K14) and stable ranking / nDCG@k (K15).  All of it is f32, coalesced
+// 16-byte row reads with 64-lane shuffle reductions; no matrix cores (≈0.5 FLOP per byte).
+#include <math.h>
+
+#include "common.h"
+
+namespace manner {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// dot of a table row with a vector held in LDS; D % 4 == 0
+__device__ __forceinline__ float row_dot(const float* __restrict__ row, const float* vec, int D, int lane) {
+  float a = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + c);
+    const f32x4 u = *reinterpret_cast<const f32x4*>(vec + c);
+    a += (x[0] * u[0] + x[1] * u[1]) + (x[2] * u[2] + x[3] * u[3]);
+  }
+  return wave_sum(a);
+}
+
+// ---------------------------------------------------------------- K9 + K10 + K12 fused
+// one workgroup per impression: user = mean(table[hist]) (cr_module.py:116-123), then one wave per
+// candidate row (click_predictors.py:12).  `user` lives in LDS; table rows are read exactly once.
+__global__ __launch_bounds__(256) void score_late_fusion_kernel(
+    const float* __restrict__ table, int64_t n_rows, int D, const int32_t* __restrict__ hist_idx,
+    const int64_t* __restrict__ hist_off, const int32_t* __restrict__ cand_idx,
+    const int64_t* __restrict__ cand_off, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  const int64_t b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
+  for (int cb = 0; cb < D; cb += 256) {
+    const int c = cb + lane * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < D)
+      for (int64_t j = h0 + wave; j < h1; j += 4) {
+        int64_t r = hist_idx[j];
+        r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+        acc += *reinterpret_cast<const f32x4*>(table + r * D + c);
+      }
+    if (c < D) *reinterpret_cast<f32x4*>(sm + wave * D + c) = acc;
+  }
+  __syncthreads();
+  const float hn = (float)(h1 - h0);
+  float* user = sm + 4 * D;
+  for (int c = threadIdx.x; c < D; c += 256)
+    user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  __syncthreads();
+  const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
+  for (int64_t j = c0 + wave; j < c1; j += 4) {
+    int64_t r = cand_idx[j];
+    r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+    const float d = row_dot(table + r * D, user, D, lane);
+    if (lane == 0) out[j] = d;
+  }
+}
+
+// ---------------------------------------------------------------- K12 drop-in
+// rows contiguous along D (the permuted view the reference passes): one wave per candidate
+__global__ __launch_bounds__(256) void dot_rows_kernel(const float* __restrict__ user, const float* __restrict__ cand,
+                                                       int64_t B, int64_t C, int D, int64_t sb, int64_t sc,
+                                                       float* __restrict__ out, int vec_ok) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= B * C) return;
+  const int64_t b = p / C, c = p - b * C;
+  const float* u = user + b * D;
+  const float* x = cand + b * sb + c * sc;
+  float a = 0.f;
+  if (vec_ok) {
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + d);
+      const f32x4 uv = *reinterpret_cast<const f32x4*>(u + d);
+      a += (xv[0] * uv[0] + xv[1] * uv[1]) + (xv[2] * uv[2] + xv[3] * uv[3]);
+    }
+  } else {
+    for (int d = lane; d < D; d += 64) a += x[d] * u[d];
+  }
+  a = wave_sum(a);
+  if (lane == 0) out[p] = a;
+}
+// general strides (e.g. a materialised [B,D,C] tensor): one thread per candidate, coalesced over c
+__global__ __launch_bounds__(256) void dot_strided_kernel(const float* __restrict__ user, const float* __restrict__ cand,
+                                                          int64_t B, int64_t C, int D, int64_t sb, int64_t sd, int64_t sc,
+                                                          float* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= B * C) return;
+  const int64_t b = p / C, c = p - b * C;
+  const float* u = user + b * D;
+  const float* x = cand + b * sb + c * sc;
+  float a = 0.f;
+  for (int d = 0; d < D; ++d) a = fmaf(x[(int64_t)d * sd], u[d], a);
+  out[p] = a;
+}
+
+// ---------------------------------------------------------------- K11 additive attention
+// one workgroup per batch row b: logits[s] = sum_j tanh(<x[b,s],W[j]> + b[j]) q[j]; softmax over s
+// (NO padding mask — attention.py:21-27); out[b] = sum_s w_s x[b,s].
+__global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* __restrict__ query,
+                                                            int64_t S, int D, int Q, float* __restrict__ out,
+                                                            float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] row + [4] wave partials
+  const int64_t b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* xb = x + b * S * D;
+  float* lg = logits + b * S;
+  float* part = sm + D;
+  for (int64_t s = 0; s < S; ++s) {
+    for (int c = threadIdx.x * 4; c < D; c += 1024)
+      *reinterpret_cast<f32x4*>(sm + c) = *reinterpret_cast<const f32x4*>(xb + s * D + c);
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = wave; j < Q; j += 4) {
+      const float d = row_dot(W + (size_t)j * D, sm, D, lane);
+      acc += tanhf(d + bias[j]) * query[j];
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) lg[s] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+  }
+  // softmax over s (dim=1), every wave redundantly
+  float mx = -INFINITY;
+  for (int64_t s = lane; s < S; s += 64) mx = fmaxf(mx, lg[s]);
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int64_t s = lane; s < S; s += 64) den += expf(lg[s] - mx);
+  den = wave_sum(den);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+    for (int64_t s = 0; s < S; ++s) a = fmaf(expf(lg[s] - mx) / den, xb[s * D + c], a);
+    out[b * D + c] = a;
+  }
+}
+
+// ---------------------------------------------------------------- K13 + K14
+struct FuseWeights { float w[8]; };
+
+__global__ __launch_bounds__(256) void zscore_fuse_kernel(const float* __restrict__ scores, int64_t plane_stride, int K,
+                                                          FuseWeights fw, const int64_t* __restrict__ off, int64_t B,
+                                                          float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  const int64_t c0 = off[i], c1 = off[i + 1];
+  const float cn = (float)(c1 - c0);
+  for (int k = 0; k < K; ++k) {
+    const float wk = k == 0 ? 1.0f : fw.w[k - 1];
+    if (k > 0 && wk == 0.0f) continue;                 // ensemble_module.py:100,105: module skipped
+    const float* s = scores + (int64_t)k * plane_stride;
+    float a = 0.f;
+    for (int64_t j = c0 + lane; j < c1; j += 64) a += s[j];
+    const float mean = wave_sum(a) / cn;               // sum(scores, dim=1) / cand_size  (:147)
+    float q = 0.f;
+    for (int64_t j = c0 + lane; j < c1; j += 64) { const float d = s[j] - mean; q += d * d; }
+    const float sd = sqrtf(wave_sum(q) / (cn - 1.0f)); // torch.std: unbiased; c == 1 -> NaN  (:143)
+    for (int64_t j = c0 + lane; j < c1; j += 64) {
+      const float z = (s[j] - mean) / sd;
+      out[j] = k == 0 ? z : out[j] + wk * z;           // scores += w * z  (:102,:107)
+    }
+  }
+}
+
+// ---------------------------------------------------------------- K15 ranking + nDCG@k
+__device__ __forceinline__ bool ranks_before(float a, int ia, float b, int ib) {
+  // descending, stable; NaN sorts first like torch.argsort(descending=True)
+  const bool na = a != a, nb = b != b;
+  if (na || nb) return na && (!nb || ia < ib);
+  return a > b || (a == b && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                                        const int64_t* __restrict__ off, int64_t B, int k,
+                                                        int32_t* __restrict__ topk, float* __restrict__ ndcg) {
+  constexpr int CAP = 512;
+  __shared__ float ssm[4][CAP];
+  __shared__ float lsm[4][CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= B) return;
+  const int64_t c0 = off[i];
+  const int c = (int)(off[i + 1] - c0);
+  const float* s = scores + c0;
+  const float* l = labels ? labels + c0 : nullptr;
+  if (c <= CAP) {                                      // wave-private staging, no workgroup barrier
+    for (int j = lane; j < c; j += 64) { ssm[wave][j] = s[j]; if (l) lsm[wave][j] = l[j]; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    s = ssm[wave];
+    if (l) l = lsm[wave];
+  }
+  if (topk)
+    for (int r = lane; r < k; r += 64) if (r >= c) topk[i * k + r] = -1;
+  float dcg = 0.f, idcg = 0.f, pos = 0.f;
+  for (int a = lane; a < c; a += 64) {
+    const float sa = s[a];
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += ranks_before(s[j], j, sa, a) ? 1 : 0;
+    if (rank < k && topk) topk[i * k + rank] = a;
+    if (l) {
+      const float la = l[a];
+      if (rank < k) dcg += la / log2f((float)rank + 2.0f);
+      int lrank = 0;
+      for (int j = 0; j < c; ++j) lrank += ranks_before(l[j], j, la, a) ? 1 : 0;
+      if (lrank < k) idcg += la / log2f((float)lrank + 2.0f);
+      pos += la;
+    }
+  }
+  if (ndcg && l) {
+    dcg = wave_sum(dcg); idcg = wave_sum(idcg); pos = wave_sum(pos);
+    if (lane == 0) ndcg[i] = pos == 0.f ? 0.f : dcg / idcg;   // empty_target_action="neg" -> 0
+  }
+}
+
+}  // namespace
+}  // namespace manner
+
+using namespace manner;
+
+extern "C" {
+
+int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D, const int32_t* hist_idx,
+                                 const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
+                                 float* out, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!table || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: null pointer");
+  if (D <= 0 || D % 4 || D > 4096 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: D=%d must be a multiple of 4, <= 4096", D);
+  hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                     table, n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_dot(const float* user, const float* cand, int64_t B, int64_t C, int32_t D, int64_t sb, int64_t sd,
+                   int64_t sc, float* out, manner_hip_stream_t stream) {
+  if (B * C == 0) return MANNER_HIP_OK;
+  if (!user || !cand || !out || D <= 0) return fail(MANNER_HIP_E_INVALID, "dot: bad argument");
+  if (sd == 1) {
+    const int vec_ok = (D % 4 == 0) && (sb % 4 == 0) && (sc % 4 == 0) && ((uintptr_t)cand % 16 == 0) && ((uintptr_t)user % 16 == 0);
+    hipLaunchKernelGGL(dot_rows_kernel, dim3((unsigned)((B * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, user, cand, B, C,
+                       D, sb, sc, out, vec_ok);
+  } else {
+    hipLaunchKernelGGL(dot_strided_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, user, cand,
+                       B, C, D, sb, sd, sc, out);
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_additive_pool(const float* x, const float* lin_w, const float* lin_b, const float* query, int64_t B,
+                             int64_t S, int32_t D, int32_t Q, float* out, float* scratch, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!x || !lin_w || !lin_b || !query || !out || !scratch) return fail(MANNER_HIP_E_INVALID, "additive_pool: null pointer");
+  if (S <= 0 || D <= 0 || D % 4 || D > 8192 || Q <= 0) return fail(MANNER_HIP_E_INVALID, "additive_pool: S=%lld D=%d Q=%d unsupported", (long long)S, D, Q);
+  hipLaunchKernelGGL(additive_pool_kernel, dim3((unsigned)B), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, lin_w,
+                     lin_b, query, S, D, Q, out, scratch);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K, const float* weights, const int64_t* cand_off,
+                           int64_t B, float* out, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!scores || !cand_off || !out || K < 1 || K > 9 || (K > 1 && !weights)) return fail(MANNER_HIP_E_INVALID, "zscore_fuse: bad argument (1 <= K <= 9)");
+  FuseWeights fw;
+  for (int k = 0; k < 8; ++k) fw.w[k] = k < K - 1 ? weights[k] : 0.f;
+  hipLaunchKernelGGL(zscore_fuse_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, plane_stride, K,
+                     fw, cand_off, B, out);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t k,
+                         int32_t* topk_idx, float* ndcg, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!scores || !cand_off || k < 1 || (ndcg && !labels)) return fail(MANNER_HIP_E_INVALID, "rank_ndcg: bad argument");
+  hipLaunchKernelGGL(rank_ndcg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, labels, cand_off,
+                     B, k, topk_idx, ndcg);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+}  // extern "C"

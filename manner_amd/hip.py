@@ -1,0 +1,220 @@
+"""Torch-tensor front end of the C ABI: pointer/stream plumbing only.
+
+PyTorch-ROCm provides device memory and the current HIP stream; all arithmetic happens in
+libmanner_hip.so.  Every function raises on non-GPU tensors — there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EncoderConfig
+from .weights import plm_param_shapes
+
+Tensor = torch.Tensor
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: Tensor, dtype: torch.dtype, name: str) -> Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor — the MANNeR HIP hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def weight_table_order(cfg: EncoderConfig) -> Sequence[str]:
+    """HF parameter names in the order of the ``weights`` table of manner_hip_encoder_create."""
+    names = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+             "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+    per_layer = ["attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+                 "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
+                 "attention.output.dense.weight", "attention.output.dense.bias",
+                 "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+                 "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
+                 "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
+    for l in range(cfg.layers):
+        names += [f"encoder.layer.{l}.{n}" for n in per_layer]
+    return names
+
+
+class HipEncoder:
+    """Owns a manner_hip_encoder handle (packed PLM weights) and a growable workspace."""
+
+    def __init__(self, cfg: EncoderConfig, weights: Dict[str, Tensor], precisions: Sequence[str] = ("bf16", "fp32"),
+                 device: Optional[torch.device] = None):
+        lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEncoder needs a GPU device — there is no CPU fallback")
+        shapes = dict(plm_param_shapes(cfg))
+        names = weight_table_order(cfg)
+        keep = []
+        with torch.cuda.device(self.device):
+            for n in names:
+                w = weights[n]
+                if isinstance(w, np.ndarray):
+                    w = torch.from_numpy(w)
+                w = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                if tuple(w.shape) != tuple(shapes[n]):
+                    raise ValueError(f"{n}: shape {tuple(w.shape)} != {shapes[n]}")
+                keep.append(w)
+            table = (C.c_void_p * len(keep))(*[w.data_ptr() for w in keep])
+            cc = _lib.EncoderConfigC(cfg.arch, cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate, cfg.vocab,
+                                     cfg.max_pos, cfg.type_vocab, cfg.pad_id, cfg.ln_eps)
+            mask = 0
+            for p in precisions:
+                mask |= 1 << _lib.PRECISIONS[p]
+            handle = C.c_void_p()
+            _lib.check(lib.manner_hip_encoder_create(C.byref(cc), table, len(keep), mask, _stream(), C.byref(handle)))
+        self._handle = handle
+        self._ws: Optional[Tensor] = None
+        del keep                      # the handle owns private packed copies
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().manner_hip_encoder_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _workspace(self, n_news: int, tokens: int, prec: int) -> Tensor:
+        need = int(_lib.load().manner_hip_encoder_workspace_bytes(self._handle, n_news, tokens, prec))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_cls(self, ids: Tensor, mask: Tensor, precision: str = "bf16",
+                   host_lengths: Optional[np.ndarray] = None, max_chunk_tokens: int = 65536,
+                   out: Optional[Tensor] = None) -> Tensor:
+        """[N, Lp] int64 ids/mask -> [N, H] float32 CLS embeddings."""
+        ids, mask = _dev(ids, torch.int64, "input_ids"), _dev(mask, torch.int64, "attention_mask")
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError(f"input_ids {tuple(ids.shape)} / attention_mask {tuple(mask.shape)} must be equal 2-D")
+        ids, mask = ids.contiguous(), mask.contiguous()
+        n, lp = ids.shape
+        prec = _lib.PRECISIONS[precision]
+        if out is None:
+            out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=ids.device)
+        else:
+            _dev(out, torch.float32, "out")
+            assert out.is_contiguous() and tuple(out.shape) == (n, self.cfg.hidden)
+        if n == 0:
+            return out
+        hl = None
+        if host_lengths is not None:
+            hl = np.ascontiguousarray(host_lengths, dtype=np.int32)
+            assert hl.shape == (n,)
+            tokens = min(int(hl.sum()), max_chunk_tokens)
+        else:
+            tokens = min(n * lp, max_chunk_tokens)
+        tokens = max(tokens, lp, 128)
+        with torch.cuda.device(ids.device):
+            ws = self._workspace(min(n, tokens), tokens, prec)
+            _lib.check(_lib.load().manner_hip_encode_cls(
+                self._handle, _ptr(ids), _ptr(mask), C.c_void_p(hl.ctypes.data if hl is not None else 0), n, lp, prec,
+                _ptr(out), _ptr(ws), ws.numel(), _stream()))
+        return out
+
+    def status(self) -> None:
+        """Blocking check of the device-side input validation flag (raises on bad masks/ids)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().manner_hip_encoder_status(self._handle, _stream()))
+
+
+def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:
+    x = _dev(x, torch.float32, "input_vector").contiguous()
+    b, s, d = x.shape
+    lin_w = _dev(lin_w, torch.float32, "linear.weight").contiguous()
+    lin_b = _dev(lin_b, torch.float32, "linear.bias").contiguous()
+    query = _dev(query, torch.float32, "query").contiguous()
+    q = lin_w.shape[0]
+    assert lin_w.shape == (q, d) and lin_b.shape == (q,) and query.shape == (q,)
+    out = torch.empty((b, d), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((b, max(s, 1)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().manner_hip_additive_pool(_ptr(x), _ptr(lin_w), _ptr(lin_b), _ptr(query), b, s, d, q,
+                                                        _ptr(out), _ptr(scratch), _stream()))
+    return out
+
+
+def dot(user: Tensor, cand: Tensor) -> Tensor:
+    """DotProduct contract: user [B,1,D], cand [B,D,C] (any strides, e.g. a permuted [B,C,D]) -> [B,C]."""
+    user, cand = _dev(user, torch.float32, "clicked_news_vector"), _dev(cand, torch.float32, "candidate_news_vector")
+    b, one, d = user.shape
+    assert one == 1 and cand.shape[0] == b and cand.shape[1] == d
+    c = cand.shape[2]
+    u = user.reshape(b, d).contiguous()
+    if c == 0:
+        return torch.empty((b, 0), dtype=torch.float32, device=user.device)
+    if min(cand.stride()) < 0 or (cand.stride(1) != 1 and cand.stride(2) != 1):
+        cand = cand.contiguous()
+    out = torch.empty((b, c), dtype=torch.float32, device=user.device)
+    with torch.cuda.device(user.device):
+        _lib.check(_lib.load().manner_hip_dot(_ptr(u), _ptr(cand), b, c, d, cand.stride(0), cand.stride(1),
+                                              cand.stride(2), _ptr(out), _stream()))
+    return out
+
+
+def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
+                      total_cand: Optional[int] = None) -> Tensor:
+    """Ragged scores [sum c_i] of impressions given as CSR index lists into ``table`` [n, D]."""
+    table = _dev(table, torch.float32, "table").contiguous()
+    hist_idx, cand_idx = _dev(hist_idx, torch.int32, "hist_idx"), _dev(cand_idx, torch.int32, "cand_idx")
+    hist_off, cand_off = _dev(hist_off, torch.int64, "hist_off"), _dev(cand_off, torch.int64, "cand_off")
+    nb = hist_off.numel() - 1
+    assert cand_off.numel() == nb + 1
+    total = int(cand_idx.numel()) if total_cand is None else total_cand
+    out = torch.empty((total,), dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _lib.check(_lib.load().manner_hip_score_late_fusion(
+            _ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx.contiguous()), _ptr(hist_off.contiguous()),
+            _ptr(cand_idx.contiguous()), _ptr(cand_off.contiguous()), nb, _ptr(out), _stream()))
+    return out
+
+
+def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor) -> Tensor:
+    """planes [K, total] (module 0 = CR); weights of modules 1..K-1 -> fused ragged scores [total]."""
+    planes = _dev(planes, torch.float32, "scores").contiguous()
+    cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
+    k, total = planes.shape
+    assert len(weights) == k - 1
+    w = (C.c_float * max(1, k - 1))(*[float(v) for v in weights])
+    out = torch.empty((total,), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        _lib.check(_lib.load().manner_hip_zscore_fuse(_ptr(planes), total, k, w, _ptr(cand_off), cand_off.numel() - 1,
+                                                      _ptr(out), _stream()))
+    return out
+
+
+def rank_ndcg(scores: Tensor, labels: Optional[Tensor], cand_off: Tensor, k: int = 10) -> Tuple[Tensor, Optional[Tensor]]:
+    """Per impression: top-k candidate positions int32 [B,k] (-1 padded) and nDCG@k float32 [B]."""
+    scores = _dev(scores, torch.float32, "scores").contiguous()
+    cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
+    nb = cand_off.numel() - 1
+    topk = torch.empty((nb, k), dtype=torch.int32, device=scores.device)
+    ndcg = None
+    if labels is not None:
+        labels = _dev(labels, torch.float32, "labels").contiguous()
+        ndcg = torch.empty((nb,), dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().manner_hip_rank_ndcg(_ptr(scores), _ptr(labels), _ptr(cand_off), nb, k, _ptr(topk),
+                                                    _ptr(ndcg), _stream()))
+    return topk, ndcg

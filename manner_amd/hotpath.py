@@ -1,0 +1,126 @@
+"""Device-side composition of the hot path above the C ABI.
+
+* ``cr_forward`` / ``ensemble_forward`` restate ``CRModule.forward`` (reference
+  manner/models/cr_module.py:105-131) and ``EnsembleModule.forward`` / ``_submodel_forward``
+  (reference manner/models/ensemble_module.py:95-151) on the fused HIP kernels, returning the same
+  dense ``[B, Cmax]`` score matrix (padded slots 0) — mode R of SURVEY.md §8d: every history and
+  candidate occurrence is encoded.
+* ``encode_table`` / ``score_impressions`` are the table architecture (mode T): each unique news is
+  encoded once per module into ``[N_news, D]``, impressions are scored by index.  Valid for
+  ``use_entities=False`` only.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+
+Tensor = torch.Tensor
+
+
+def segment_offsets(batch: Tensor, num_segments: int) -> Tensor:
+    """Sorted segment ids (reference ``_make_batch_assignees``, mind_rec_dataset.py:171-174) -> CSR
+    offsets int64 [B+1], on device, no host sync."""
+    counts = torch.bincount(batch, minlength=num_segments)
+    off = torch.zeros(num_segments + 1, dtype=torch.int64, device=batch.device)
+    torch.cumsum(counts, 0, out=off[1:])
+    return off
+
+
+def ragged_to_dense(values: Tensor, off: Tensor, width: Optional[int] = None) -> Tensor:
+    """K9 for a ragged score vector: [sum c_i] -> zero-filled [B, Cmax] (``to_dense_batch`` layout)."""
+    nb = off.numel() - 1
+    counts = off[1:] - off[:-1]
+    if width is None:
+        width = int(counts.max()) if nb else 0           # the same sync to_dense_batch performs
+    seg = torch.repeat_interleave(torch.arange(nb, device=values.device), counts, output_size=values.numel())
+    pos = torch.arange(values.numel(), device=values.device) - off[:-1][seg]
+    dense = torch.zeros((nb, width), dtype=values.dtype, device=values.device)
+    dense[seg, pos] = values
+    return dense
+
+
+def _late_fusion_ragged(hist_vec: Tensor, cand_vec: Tensor, hist_off: Tensor, cand_off: Tensor) -> Tensor:
+    table = torch.cat([hist_vec, cand_vec], dim=0)
+    nh, nc = hist_vec.shape[0], cand_vec.shape[0]
+    hidx = torch.arange(nh, dtype=torch.int32, device=table.device)
+    cidx = torch.arange(nh, nh + nc, dtype=torch.int32, device=table.device)
+    return hip.score_late_fusion(table, hidx, hist_off, cidx, cand_off, total_cand=nc)
+
+
+def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder=None, click_predictor=None,
+               dense: bool = True) -> Tensor:
+    """CRModule.forward: scores [B, Cmax] (or the ragged [sum c_i] vector with ``dense=False``)."""
+    nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
+    hist_vec = news_encoder(batch["x_hist"])
+    cand_vec = news_encoder(batch["x_cand"])
+    hist_off = segment_offsets(batch["batch_hist"], nb)
+    cand_off = segment_offsets(batch["batch_cand"], nb)
+    if late_fusion:
+        ragged = _late_fusion_ragged(hist_vec, cand_vec, hist_off, cand_off)
+        return ragged_to_dense(ragged, cand_off) if dense else ragged
+    # early fusion: the unmasked additive pooler sees the ZERO-PADDED history
+    counts = hist_off[1:] - hist_off[:-1]
+    hmax = int(counts.max())
+    seg = torch.repeat_interleave(torch.arange(nb, device=hist_vec.device), counts, output_size=hist_vec.shape[0])
+    pos = torch.arange(hist_vec.shape[0], device=hist_vec.device) - hist_off[:-1][seg]
+    hist_dense = torch.zeros((nb, hmax, hist_vec.shape[1]), dtype=hist_vec.dtype, device=hist_vec.device)
+    hist_dense[seg, pos] = hist_vec
+    user = user_encoder(hist_dense)
+    ccounts = cand_off[1:] - cand_off[:-1]
+    cmax = int(ccounts.max())
+    cseg = torch.repeat_interleave(torch.arange(nb, device=cand_vec.device), ccounts, output_size=cand_vec.shape[0])
+    cpos = torch.arange(cand_vec.shape[0], device=cand_vec.device) - cand_off[:-1][cseg]
+    cand_dense = torch.zeros((nb, cmax, cand_vec.shape[1]), dtype=cand_vec.dtype, device=cand_vec.device)
+    cand_dense[cseg, cpos] = cand_vec
+    scores = (click_predictor or hip.dot)(user.unsqueeze(1), cand_dense.permute(0, 2, 1))
+    return scores if dense else scores[torch.arange(cmax, device=scores.device)[None, :] < ccounts[:, None]]
+
+
+def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[float], dense: bool = True) -> Tensor:
+    """EnsembleModule.forward: CR scores + weighted A-module scores, each z-normalised per impression.
+    ``news_encoders[0]`` is the CR-Module's encoder; a zero weight skips that module's encoder entirely
+    (ensemble_module.py:100,105)."""
+    nb = batch["users"].numel()
+    hist_off = segment_offsets(batch["batch_hist"], nb)
+    cand_off = segment_offsets(batch["batch_cand"], nb)
+    planes, used = [], []
+    for k, enc in enumerate(news_encoders):
+        if k > 0 and weights[k - 1] == 0:
+            continue
+        planes.append(_late_fusion_ragged(enc(batch["x_hist"]), enc(batch["x_cand"]), hist_off, cand_off))
+        if k > 0:
+            used.append(weights[k - 1])
+    fused = hip.zscore_fuse(torch.stack(planes), used, cand_off)
+    return ragged_to_dense(fused, cand_off) if dense else fused
+
+
+# ------------------------------------------------------------------------------------- table mode
+
+def encode_table(encoder: hip.HipEncoder, ids: Tensor, mask: Tensor, precision: str = "bf16",
+                 host_lengths: Optional[np.ndarray] = None, max_chunk_tokens: int = 65536,
+                 out: Optional[Tensor] = None) -> Tensor:
+    """Encode a (shard of the) news pool once: [N, Lp] tokens -> [N, D] float32 table rows."""
+    return encoder.encode_cls(ids, mask, precision=precision, host_lengths=host_lengths,
+                              max_chunk_tokens=max_chunk_tokens, out=out)
+
+
+def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights: Sequence[float] = (),
+                      labels: Optional[Tensor] = None, k: int = 10) -> Dict[str, Tensor]:
+    """Score impressions against per-module tables, fuse, rank.  ``imp``: hist_idx/cand_idx int32,
+    hist_off/cand_off int64 (device).  With a single table and no weights the scores are the raw
+    late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion."""
+    planes = []
+    for j, t in enumerate(tables):
+        if j > 0 and weights[j - 1] == 0:
+            continue
+        planes.append(hip.score_late_fusion(t, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"]))
+    if len(tables) == 1 and len(weights) == 0:
+        scores = planes[0]
+    else:
+        scores = hip.zscore_fuse(torch.stack(planes), [w for w in weights if w != 0], imp["cand_off"])
+    topk, ndcg = hip.rank_ndcg(scores, labels, imp["cand_off"], k)
+    return {"scores": scores, "topk": topk, "ndcg": ndcg}

@@ -1,0 +1,180 @@
+"""MannerTextEncoder / MannerEntityEncoder / MannerNewsEncoder — mirror of reference
+manner/models/components/news_encoder.py:11-129.
+
+Same constructor arguments, forward signature and state_dict keys (``text_encoder.plm_model.*`` are
+the HF BertModel / RobertaModel names), so reference checkpoints load with
+``load_state_dict``.  ``forward`` (eval mode, GPU tensors) runs K1-K7 through libmanner_hip.so;
+there is no CPU or autograd path.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from manner_amd import hip
+from manner_amd.config import EncoderConfig, resolve
+from manner_amd.models.components.attention import AdditiveAttention
+from manner_amd.weights import plm_param_shapes
+
+
+def _set_nested_parameter(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class HipPLM(nn.Module):
+    """Parameter tree with HF BertModel/RobertaModel names; the arithmetic lives in the HIP library."""
+
+    def __init__(self, cfg: EncoderConfig) -> None:
+        super().__init__()
+        self.cfg = cfg
+        for name, shape in plm_param_shapes(cfg, with_pooler=True):
+            t = torch.empty(shape, dtype=torch.float32)
+            if name.endswith("LayerNorm.weight"):
+                t.fill_(1.0)
+            elif name.endswith(".bias"):
+                t.zero_()
+            else:
+                t.normal_(0.0, 0.02)            # HF initializer_range
+            _set_nested_parameter(self, name, nn.Parameter(t))
+
+    @property
+    def base_model(self) -> "HipPLM":           # reference freezes via plm_model.base_model (news_encoder.py:24)
+        return self
+
+    @classmethod
+    def from_pretrained(cls, plm_model: str) -> "HipPLM":
+        """Local HF directory (config.json + model.safetensors / pytorch_model.bin) or an architecture
+        preset name.  There is no hub access: a preset name yields random HF-style init and expects a
+        checkpoint to be loaded afterwards (as EnsembleModule does, ensemble_module.py:33-46)."""
+        model = cls(resolve(plm_model))
+        if os.path.isdir(plm_model):
+            sd = None
+            st, pt = os.path.join(plm_model, "model.safetensors"), os.path.join(plm_model, "pytorch_model.bin")
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+                sd = load_file(st)
+            elif os.path.exists(pt):
+                sd = torch.load(pt, map_location="cpu", weights_only=True)
+            if sd is None:
+                raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {plm_model}")
+            own = model.state_dict()
+            fixed = {}
+            for k, v in sd.items():
+                for pre in ("bert.", "roberta.", ""):
+                    if k.startswith(pre) and k[len(pre):] in own:
+                        fixed[k[len(pre):]] = v
+                        break
+            missing = [k for k in own if k not in fixed and not k.startswith("pooler.")]
+            if missing:
+                raise KeyError(f"{plm_model}: checkpoint lacks {missing[:4]}... ({len(missing)} tensors)")
+            model.load_state_dict(fixed, strict=False)
+        else:
+            warnings.warn(f"PLM {plm_model!r}: no hub access — random init of the {plm_model} architecture; "
+                          "load a checkpoint before use")
+        return model
+
+
+class MannerTextEncoder(nn.Module):
+    """reference news_encoder.py:11-37."""
+
+    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate) or "fp32" (f32 MFMA parity mode)
+    precision: str = os.environ.get("MANNER_HIP_PRECISION", "bf16")
+
+    def __init__(self, plm_model: str, frozen_layers: List[int], dropout_probability: float) -> None:
+        super().__init__()
+        self.plm_model = HipPLM.from_pretrained(plm_model)
+        self.dropout = nn.Dropout(p=dropout_probability)
+        # freeze PLM layers (same name test as the reference, news_encoder.py:24-27)
+        for name, param in self.plm_model.base_model.named_parameters():
+            for layer in frozen_layers:
+                if "layer." + str(layer) + "." in name:
+                    param.requires_grad = False
+        self._hip: Optional[hip.HipEncoder] = None
+        self._hip_key = None
+
+    def __getstate__(self):                      # the HIP handle is rebuilt lazily after copy/unpickle
+        d = self.__dict__.copy()
+        d["_hip"], d["_hip_key"] = None, None
+        return d
+
+    def _encoder(self, device: torch.device) -> hip.HipEncoder:
+        params = dict(self.plm_model.named_parameters())
+        key = (str(device), tuple((p.data_ptr(), p._version) for p in params.values()))
+        if self._hip is None or self._hip_key != key:
+            if self._hip is not None:
+                self._hip.close()
+            self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
+                                       precisions=("bf16", "fp32"), device=device)
+            self._hip_key = key
+        return self._hip
+
+    def forward(self, tokenized_text) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("manner_amd MannerTextEncoder is inference-only: dropout/backward of the reference's "
+                               "training mode are out of scope (SURVEY.md Q6); call .eval()")
+        ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
+        if not ids.is_cuda:
+            raise RuntimeError("MannerTextEncoder.forward needs GPU tensors — the HIP hot path has no CPU fallback")
+        if "token_type_ids" in tokenized_text and tokenized_text["token_type_ids"] is not None:
+            if bool(torch.count_nonzero(tokenized_text["token_type_ids"])):
+                raise ValueError("non-zero token_type_ids: the reference collate never passes them "
+                                 "(mind_rec_dataset.py:134-137) and the HIP encoder assumes segment 0")
+        # CLS slice of the last hidden state; dropout is the identity in eval()
+        return self._encoder(ids.device).encode_cls(ids, mask, precision=self.precision)
+
+
+class MannerEntityEncoder(nn.Module):
+    """reference news_encoder.py:40-72 — parameters only (checkpoint compatibility).
+
+    The reference feeds a batch-first tensor to a batch_first=False nn.MultiheadAttention, so entity
+    attention mixes the news of a batch; the HIP path does not reproduce that yet and
+    refuses instead of returning different numbers."""
+
+    def __init__(self, pretrained_embedding: nn.Embedding, embedding_dim: int, num_attention_heads: int,
+                 query_vector_dim: int, dropout_probability: float) -> None:
+        super().__init__()
+        self.pretrained_embedding = pretrained_embedding
+        self.multihead_attention = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=num_attention_heads)
+        self.additive_attention = AdditiveAttention(input_dim=embedding_dim, query_dim=query_vector_dim)
+        self.dropout = nn.Dropout(p=dropout_probability)
+
+    def forward(self, entity_sequence: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            "use_entities=True: the reference's entity encoder couples the news of a batch (SURVEY.md Q1); "
+            "the HIP hot path covers use_entities=False (the *_title_* configs) and refuses this one")
+
+
+class MannerNewsEncoder(nn.Module):
+    """reference news_encoder.py:75-129."""
+
+    def __init__(self, plm_model: str, frozen_layers: List[int], dropout_probability: float, use_entities: bool,
+                 entity_embeddings: torch.Tensor, entity_embedding_dim: int, num_attention_heads: int,
+                 query_vector_dim: int, text_embedding_dim: int) -> None:
+        super().__init__()
+        self.text_encoder = MannerTextEncoder(plm_model=plm_model, frozen_layers=frozen_layers,
+                                              dropout_probability=dropout_probability)
+        self.use_entities = use_entities
+        if self.use_entities:
+            pretrained_entity_embedding = nn.Embedding.from_pretrained(
+                embeddings=torch.FloatTensor(entity_embeddings), freeze=False, padding_idx=0)
+            self.entity_encoder = MannerEntityEncoder(
+                pretrained_embedding=pretrained_entity_embedding, embedding_dim=entity_embedding_dim,
+                num_attention_heads=num_attention_heads, query_vector_dim=query_vector_dim,
+                dropout_probability=dropout_probability)
+            self.linear = nn.Linear(in_features=text_embedding_dim + entity_embedding_dim,
+                                    out_features=text_embedding_dim)
+
+    def forward(self, news: Dict[str, Any]) -> torch.Tensor:
+        if self.use_entities:
+            return self.entity_encoder(news["entities"])      # raises: see MannerEntityEncoder
+        return self.text_encoder(news["text"])

@@ -1,0 +1,256 @@
+"""Parity of the HIP hot path (through the C ABI) against the reference-generated golden vectors
+and the CPU oracle.  Run on the MI355X box: ``pytest -m gpu``."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import manner_oracle as O  # noqa: E402  (tests/conftest.py puts oracle/ on sys.path)
+from manner_amd import hip, hotpath  # noqa: E402
+from manner_amd.config import PRESETS  # noqa: E402
+from manner_amd.synth import segment_ids, synth_impressions, synth_news_tokens  # noqa: E402
+from manner_amd.weights import make_additive_attention_weights, make_plm_weights  # noqa: E402
+
+DEV = "cuda:0"
+FP32_TOL = 1e-4       # north_star: outputs within 1e-4 of the reference fp32 CPU path
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def _cuda(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+_ENC = {}
+
+
+def _encoder(preset, seed, std):
+    key = (preset, seed, std)
+    if key not in _ENC:
+        cfg = PRESETS[preset]
+        _ENC[key] = (hip.HipEncoder(cfg, make_plm_weights(cfg, seed=seed, std=std), device=DEV), cfg)
+    return _ENC[key]
+
+
+GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_bert_base", "enc_bert_base_spread"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_ENC)
+def test_encoder_fp32_matches_reference(golden_dir, name):
+    z, meta = _load(golden_dir, name)
+    enc, _ = _encoder(meta["preset"], meta["seed"], meta["std"])
+    ids, mask = _cuda(z["ids"]), _cuda(z["mask"])
+    out = enc.encode_cls(ids, mask, precision="fp32", host_lengths=z["mask"].sum(1)).cpu().numpy()
+    enc.status()
+    err = np.abs(out - z["out"]).max()
+    print(f"{name}: fp32 max-abs err vs reference {err:.3e}")
+    assert err < FP32_TOL
+    # device-side lengths (no host_lengths) give the same bits
+    out2 = enc.encode_cls(ids, mask, precision="fp32").cpu().numpy()
+    assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("name", GOLDEN_ENC)
+def test_encoder_bf16_close_to_reference(golden_dir, name):
+    z, meta = _load(golden_dir, name)
+    enc, _ = _encoder(meta["preset"], meta["seed"], meta["std"])
+    out = enc.encode_cls(_cuda(z["ids"]), _cuda(z["mask"]), precision="bf16").cpu().numpy()
+    ref = z["out"]
+    err = np.abs(out - ref).max()
+    cos = (out * ref).sum(1) / np.linalg.norm(out, axis=1) / np.linalg.norm(ref, axis=1)
+    print(f"{name}: bf16 max-abs err {err:.3e}, min cosine {cos.min():.6f}")
+    # bf16 operands (8 mantissa bits) through 12 layers: tolerance stated, not the 1e-4 fp32 claim
+    assert err < 0.1 and cos.min() > 0.999
+
+
+def test_encoder_matches_oracle_ragged_chunks():
+    """Seeded inputs vs the oracle: many chunks, ragged lengths incl. 2 and 128 tokens."""
+    enc, cfg = _encoder("tiny-bert", 7, 0.05)
+    w = make_plm_weights(cfg, seed=7, std=0.05)
+    lens = np.array([2, 128, 3, 127, 33, 64, 65, 96, 97, 31, 32, 1 + 1, 50, 17, 100, 5] * 4)
+    ids, mask = synth_news_tokens(len(lens), cfg, seed=7, lengths=lens)
+    ref = O.encode_cls(ids, mask, w, cfg).numpy()
+    for chunk in (128, 256, 1024, 65536):
+        out = enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32", host_lengths=lens, max_chunk_tokens=chunk)
+        assert np.abs(out.cpu().numpy() - ref).max() < FP32_TOL, chunk
+    outb = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", max_chunk_tokens=256).cpu().numpy()
+    assert np.abs(outb - ref).max() < 0.1
+    enc.status()
+
+
+def test_encoder_padding_and_order_invariance_full_size():
+    """Size-independent properties at the bert-base shape: (Q5) the CLS row does not depend on the
+    padded width, nor on which other news share the launch / their order."""
+    enc, cfg = _encoder("bert-base-uncased", 42, 0.02)
+    n = 1500
+    ids, mask = synth_news_tokens(n, cfg, seed=11, profile="title_abstract")
+    a = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=mask.sum(1))
+    ids_p = np.pad(ids, ((0, 0), (0, 128 - ids.shape[1])), constant_values=cfg.pad_id)
+    mask_p = np.pad(mask, ((0, 0), (0, 128 - mask.shape[1])))
+    b = enc.encode_cls(_cuda(ids_p), _cuda(mask_p), precision="bf16")
+    assert torch.equal(a, b)
+    perm = np.random.Generator(np.random.PCG64(5)).permutation(n)
+    c = enc.encode_cls(_cuda(ids[perm]), _cuda(mask[perm]), precision="bf16", max_chunk_tokens=16384)
+    assert torch.equal(a[torch.from_numpy(perm).to(DEV)], c)
+    assert torch.isfinite(a).all()
+    enc.status()
+
+
+def test_encoder_rejects_bad_mask():
+    enc, cfg = _encoder("tiny-bert", 7, 0.05)
+    ids, mask = synth_news_tokens(4, cfg, seed=1, lengths=np.array([5, 6, 7, 8]))
+    mask[2, 2] = 0                                   # a hole: not a prefix mask
+    enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32")
+    with pytest.raises(RuntimeError, match="prefix mask"):
+        enc.status()
+    enc.status()                                     # flag cleared
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc.encode_cls(torch.from_numpy(ids), torch.from_numpy(mask))
+
+
+def test_additive_pool_matches_reference(golden_dir):
+    z, meta = _load(golden_dir, "additive_attention")
+    aw = make_additive_attention_weights(meta["input_dim"], meta["query_dim"], seed=meta["seed"])
+    p = [_cuda(aw["additive_attention." + k]) for k in ("linear.weight", "linear.bias", "query")]
+    out = hip.additive_pool(_cuda(z["x"]), *p).cpu().numpy()
+    assert np.abs(out - z["out"]).max() < 1e-5
+    out1 = hip.additive_pool(_cuda(z["x1"]), *p).cpu().numpy()
+    assert np.abs(out1 - z["out1"]).max() < 1e-6
+
+
+def test_dot_matches_reference(golden_dir):
+    z, _ = _load(golden_dir, "dot_product")
+    user, cand = _cuda(z["user"]), _cuda(z["cand"])
+    assert np.abs(hip.dot(user, cand).cpu().numpy() - z["out"]).max() < 1e-4          # materialised [B,D,C]
+    view = cand.permute(0, 2, 1).contiguous().permute(0, 2, 1)                            # the call-site view
+    assert np.abs(hip.dot(user, view).cpu().numpy() - z["out"]).max() < 1e-4
+    odd = cand[:, :, 1:6]                                                                  # unaligned strides
+    assert np.abs(hip.dot(user, odd).cpu().numpy() - z["out"][:, 1:6]).max() < 1e-4
+
+
+def test_pipeline_kernels_match_golden(golden_dir):
+    z, _ = _load(golden_dir, "pipeline")
+    tables = [_cuda(t) for t in z["tables"]]
+    imp = {"hist_idx": _cuda(z["hist_idx"]), "hist_off": _cuda(z["hist_off"]),
+           "cand_idx": _cuda(z["cand_idx"]), "cand_off": _cuda(z["cand_off"])}
+    late = hip.score_late_fusion(tables[0], imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    assert np.abs(late.cpu().numpy() - z["late"]).max() < 1e-5
+    dense = hotpath.ragged_to_dense(late, imp["cand_off"]).cpu().numpy()
+    assert dense.shape == z["late_dense"].shape and np.abs(dense - z["late_dense"]).max() < 1e-5
+    assert (dense[z["late_dense"] == 0] == 0).all()                                       # padded slots exactly 0
+    labels = _cuda(z["labels"])
+    for wts in ((0.0, 0.0), (-0.3, 0.0), (-0.3, 0.2)):
+        res = hotpath.score_impressions(tables, imp, wts, labels=labels, k=10)
+        ref = z["ens_%g_%g" % wts]
+        assert np.abs(res["scores"].cpu().numpy() - ref).max() < 1e-4, wts
+    assert np.array_equal(res["topk"].cpu().numpy(), z["top10"])                          # ranking bit-exact
+    assert np.abs(res["ndcg"].cpu().numpy() - z["per10"]).max() < 1e-6
+    assert abs(float(res["ndcg"].double().mean()) - float(z["ndcg10"])) < 1e-6
+    _, n5 = hip.rank_ndcg(res["scores"], labels, imp["cand_off"], 5)
+    assert np.abs(n5.cpu().numpy() - z["per5"]).max() < 1e-6
+
+
+def test_zscore_single_candidate_is_nan_and_rank_edge_cases():
+    off = torch.tensor([0, 1, 4, 4, 9], dtype=torch.int64, device=DEV)     # c = 1, 3, 0 (empty), 5
+    s = torch.tensor([1.0, 3.0, 3.0, 2.0, 0.5, 0.5, 0.7, 0.5, 0.1], device=DEV)
+    z = hip.zscore_fuse(s[None, :], [], off).cpu()
+    assert torch.isnan(z[0]) and torch.isfinite(z[1:]).all()                # torch.std of one element is NaN (Q3)
+    lab = torch.tensor([1.0, 0, 1, 0, 0, 0, 0, 1, 0], device=DEV)
+    topk, nd = hip.rank_ndcg(s, lab, off, 3)
+    assert topk.cpu().tolist() == [[0, -1, -1], [0, 1, 2], [-1, -1, -1], [2, 0, 1]]       # ties keep lower index
+    ref, per = O.ndcg_at_k(s.cpu(), lab.cpu(), off.cpu().tolist(), 3)
+    assert np.abs(nd.cpu().numpy() - per.numpy()).max() < 1e-6
+
+
+def test_module_surface_matches_reference(golden_dir):
+    """The nn.Module mirror: reference checkpoint keys load, forward equals the reference output."""
+    import warnings
+    from manner_amd.models.components.click_predictors import DotProduct
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder
+    from manner_amd.models.components.user_encoder import NAMLUserEncoder
+    z, meta = _load(golden_dir, "enc_tiny_bert")
+    cfg = PRESETS[meta["preset"]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder(plm_model="tiny-bert", frozen_layers=[0], dropout_probability=0.2, use_entities=False,
+                                entity_embeddings=None, entity_embedding_dim=100, num_attention_heads=10,
+                                query_vector_dim=200, text_embedding_dim=cfg.hidden)
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    enc.load_state_dict({"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    enc = enc.to(DEV).eval()
+    enc.text_encoder.precision = "fp32"
+    news = {"text": {"input_ids": _cuda(z["ids"]), "attention_mask": _cuda(z["mask"])}}
+    with torch.no_grad():
+        out = enc(news).cpu().numpy()
+    assert np.abs(out - z["out"]).max() < FP32_TOL
+    enc.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        enc(news)
+    za, ma = _load(golden_dir, "additive_attention")
+    ue = NAMLUserEncoder(news_embedding_dim=ma["input_dim"], query_vector_dim=ma["query_dim"])
+    ue.load_state_dict({k: torch.from_numpy(v) for k, v in
+                        make_additive_attention_weights(ma["input_dim"], ma["query_dim"], seed=ma["seed"]).items()})
+    ue = ue.to(DEV).eval()
+    assert np.abs(ue(_cuda(za["x"])).cpu().numpy() - za["out"]).max() < 1e-5
+    zd, _ = _load(golden_dir, "dot_product")
+    assert np.abs(DotProduct()(_cuda(zd["user"]), _cuda(zd["cand"])).cpu().numpy() - zd["out"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("late_fusion", [True, False])
+def test_cr_forward_matches_oracle(late_fusion):
+    """CRModule.forward restated on the HIP path vs the oracle's restatement, tiny encoder, B = 6."""
+    enc, cfg = _encoder("tiny-bert", 7, 0.05)
+    w = make_plm_weights(cfg, seed=7, std=0.05)
+    imp = synth_impressions(6, 40, seed=3, max_hist=9, max_cand=12)
+    pool_ids, pool_mask = synth_news_tokens(40, cfg, seed=3, max_len=30)
+
+    def sub(idx):
+        m = pool_mask[idx]
+        lp = int(m.sum(1).max())
+        return pool_ids[idx][:, :lp], m[:, :lp]
+
+    (hi, hm), (ci, cm) = sub(imp["hist_idx"]), sub(imp["cand_idx"])
+    bh, bc = segment_ids(imp["hist_off"]), segment_ids(imp["cand_off"])
+    aw = make_additive_attention_weights(cfg.hidden, 20, seed=3)
+    uep = [aw["additive_attention." + k] for k in ("linear.weight", "linear.bias", "query")]
+    ref = O.cr_scores(O.encode_cls(hi, hm, w, cfg), torch.from_numpy(bh), O.encode_cls(ci, cm, w, cfg),
+                      torch.from_numpy(bc), late_fusion=late_fusion,
+                      user_encoder=tuple(torch.from_numpy(p) for p in uep)).numpy()
+    batch = {"x_hist": {"input_ids": _cuda(hi), "attention_mask": _cuda(hm)},
+             "x_cand": {"input_ids": _cuda(ci), "attention_mask": _cuda(cm)},
+             "batch_hist": _cuda(bh), "batch_cand": _cuda(bc), "users": torch.zeros(6, dtype=torch.int64, device=DEV)}
+    news_encoder = lambda x: enc.encode_cls(x["input_ids"], x["attention_mask"], precision="fp32")  # noqa: E731
+    ue = lambda x: hip.additive_pool(x, *[_cuda(p) for p in uep])  # noqa: E731
+    out = hotpath.cr_forward(news_encoder, batch, late_fusion=late_fusion, user_encoder=ue).cpu().numpy()
+    assert out.shape == ref.shape and np.abs(out - ref).max() < FP32_TOL
+
+
+def test_scorer_linearity_full_size():
+    """Property at MIND-small table shape: scores are linear in the table (late fusion), so
+    score(a*T) == a^2 * score(T) and the top-10 ranking is scale-invariant."""
+    n_news, d = 65238, 768
+    g = torch.Generator(device="cpu").manual_seed(0)
+    table = torch.randn((n_news, d), generator=g).to(DEV)
+    imp_np = synth_impressions(4096, n_news, seed=9)
+    imp = {k: _cuda(v) for k, v in imp_np.items() if k != "labels"}
+    s1 = hip.score_late_fusion(table, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    s2 = hip.score_late_fusion(table * 2.0, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    assert torch.equal(s2, s1 * 4.0)                                        # powers of two are exact in f32
+    t1, _ = hip.rank_ndcg(s1, None, imp["cand_off"], 10)
+    t2, _ = hip.rank_ndcg(s2, None, imp["cand_off"], 10)
+    assert torch.equal(t1, t2)
+    # spot-check 64 impressions against the oracle restatement
+    tc = table.cpu()
+    ho, co = imp_np["hist_off"], imp_np["cand_off"]
+    for i in range(0, 4096, 64):
+        u = tc[imp_np["hist_idx"][ho[i]:ho[i + 1]].astype(np.int64)].sum(0) / float(ho[i + 1] - ho[i])
+        ref = tc[imp_np["cand_idx"][co[i]:co[i + 1]].astype(np.int64)] @ u
+        assert (s1[co[i]:co[i + 1]].cpu() - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
