@@ -59,6 +59,12 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the MANNeR HIP hot path has no CPU fallback. "
                 "Build it with `python -m manner_amd.build` (hipcc, gfx950).")
+        # PyTorch-ROCm bundles its own HIP runtime (same soname); let it initialise the device before
+        # this library's code objects register with that runtime (the reverse order leaves the
+        # library's first hipMalloc failing with hipErrorNoDevice).
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
