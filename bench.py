@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline bench: candidate news encoded+scored per second (BASELINE.json metric), configs[1]:
+CR-Module, MIND-small shape, bert-base-uncased architecture, bf16, HIP NewsEncoder + scorer.
+
+One STEP = one pass of the hot path over one batch of synthetic impressions in reference-faithful
+mode R: EVERY history and candidate occurrence of the batch is encoded by the PLM
+(as reference cr_module.py:107,113 does — nothing is cached or deduplicated), then late-fusion
+mean + dot product per candidate, stable top-10 ranking and nDCG@10.  Token tensors, index lists
+and labels of every step are resident in HBM before the timed region; each step uses different
+impressions.  value = candidates scored by all ranks / max-over-ranks wall time of the K steps.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: impressions are independent, so ranks take disjoint impression batches (weak scaling,
+no data-path collective in mode R; barrier + MAX over ranks for the clock).  The table
+architecture with the RCCL all-gather of the news-embedding table is measured by --table.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from manner_amd import hip, hotpath  # noqa: E402
+from manner_amd.config import PRESETS  # noqa: E402
+from manner_amd.synth import MIND_SMALL, shard_range, synth_impressions, synth_news_tokens  # noqa: E402
+from manner_amd.weights import make_plm_weights  # noqa: E402
+
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+F32_PEAK_TFLOPS = 157.3        # f32-input MFMA
+HBM_PEAK_GBS = 8000.0
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--impressions", type=int, default=256, help="impressions per step per GPU")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--profile", default="title_abstract", choices=["title", "title_abstract"],
+                   help="token-length profile of the news pool (SURVEY.md §8d)")
+    p.add_argument("--model", default="bert-base-uncased")
+    p.add_argument("--std", type=float, default=0.02, help="std of the seeded PLM weight matrices")
+    p.add_argument("--chunk-tokens", type=int, default=65536)
+    p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline sample")
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-kernel-profile", action="store_true")
+    return p.parse_args()
+
+
+class StepBatch:
+    """Device-resident inputs of one step: one MINDRecBatch-like batch of impressions."""
+
+    def __init__(self, imp, lo, hi, pool_ids, pool_mask, pool_len, dev):
+        ho, co = imp["hist_off"], imp["cand_off"]
+        h0, h1, c0, c1 = int(ho[lo]), int(ho[hi]), int(co[lo]), int(co[hi])
+        occ = np.concatenate([imp["hist_idx"][h0:h1], imp["cand_idx"][c0:c1]]).astype(np.int64)
+        self.n_hist, self.n_cand = h1 - h0, c1 - c0
+        self.lens = pool_len[occ].astype(np.int32)
+        lp = int(self.lens.max())                                  # tokenizer padding=True: batch max
+        occ_d = torch.from_numpy(occ).to(dev)
+        self.ids = pool_ids[occ_d][:, :lp].contiguous()            # x_hist ++ x_cand token tensors
+        self.mask = pool_mask[occ_d][:, :lp].contiguous()
+        self.hist_off = torch.from_numpy(ho[lo:hi + 1] - h0).to(dev)
+        self.cand_off = torch.from_numpy(co[lo:hi + 1] - c0).to(dev)
+        self.hist_idx = torch.arange(self.n_hist, dtype=torch.int32, device=dev)
+        self.cand_idx = torch.arange(self.n_hist, self.n_hist + self.n_cand, dtype=torch.int32, device=dev)
+        self.labels = torch.from_numpy(imp["labels"][c0:c1]).to(dev)
+        self.tokens = int(self.lens.sum())
+        self.flops = None
+
+
+def run_step(enc, b, precision, chunk_tokens, table_buf):
+    table = enc.encode_cls(b.ids, b.mask, precision=precision, host_lengths=b.lens, max_chunk_tokens=chunk_tokens,
+                           out=table_buf[: b.ids.shape[0]])
+    scores = hip.score_late_fusion(table, b.hist_idx, b.hist_off, b.cand_idx, b.cand_off, total_cand=b.n_cand)
+    topk, ndcg = hip.rank_ndcg(scores, b.labels, b.cand_off, 10)
+    return scores, topk, ndcg
+
+
+def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev):
+    """Oracle (CPU port of the reference path) on a bounded sample + parity of the HIP path on it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import manner_oracle as O
+    pool_ids, pool_mask, pool_len = pool
+    nb = args.cpu_impressions
+    ho, co = imp["hist_off"][: nb + 1], imp["cand_off"][: nb + 1]
+    hi, ci = imp["hist_idx"][: ho[-1]], imp["cand_idx"][: co[-1]]
+    # the GPU box grants a CPU share of 16 cores per GPU; os.cpu_count() reports the whole host
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    ref = O.reference_faithful_scores(pool_ids, pool_mask, hi.astype(np.int64), ho.tolist(), ci.astype(np.int64),
+                                      co.tolist(), weights, cfg, chunk=64)
+    cpu_s = time.perf_counter() - t0
+    labels = torch.from_numpy(imp["labels"][: co[-1]])
+    ref_ndcg, _ = O.ndcg_at_k(ref, labels, co.tolist(), 10)
+    ref_top = O.topk_indices(ref, co.tolist(), 10)
+    b = StepBatch(imp, 0, nb, torch.from_numpy(pool_ids).to(dev), torch.from_numpy(pool_mask).to(dev), pool_len, dev)
+    buf = torch.empty((b.ids.shape[0], cfg.hidden), dtype=torch.float32, device=dev)
+    par = {}
+    for prec in ("fp32", "bf16"):
+        scores, topk, ndcg = run_step(enc, b, prec, args.chunk_tokens, buf)
+        top = [[v for v in row if v >= 0] for row in topk.cpu().tolist()]
+        agree = float(np.mean([t == r for t, r in zip(top, ref_top)]))
+        par[prec] = {"score_max_abs_err": float((scores.cpu() - ref).abs().max()),
+                     "top10_identical_frac": agree,
+                     "ndcg10_delta": float(abs(ndcg.double().mean().item() - ref_ndcg))}
+    par["score_abs_scale"] = float(ref.abs().max())
+    cpu = {"value": float(co[-1] / cpu_s), "unit": "candidates/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/manner_oracle.py mode R on the first {nb} impressions "
+                     f"({int(ho[-1] + co[-1])} news encodes, {cpu_s:.1f} s, torch {torch.__version__} CPU fp32)"}
+    return cpu, par
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (see docstring)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = PRESETS[args.model]
+    log("generating seeded weights")
+    weights = make_plm_weights(cfg, seed=42, std=args.std)
+    log("packing weights into the HIP encoder")
+    enc = hip.HipEncoder(cfg, weights, precisions=("bf16", "fp32"), device=dev)
+    n_news = MIND_SMALL["n_news"]
+    log("synthesising news pool + impressions")
+    pool_ids_np, pool_mask_np = synth_news_tokens(n_news, cfg, seed=42, max_len=96, profile=args.profile)
+    pool_len = pool_mask_np.sum(1)
+    pool_ids, pool_mask = torch.from_numpy(pool_ids_np).to(dev), torch.from_numpy(pool_mask_np).to(dev)
+    n_steps = args.warmup + args.steps
+    # disjoint impressions per rank: one global list, contiguous block per rank
+    imp_all = synth_impressions(world * n_steps * args.impressions, n_news, seed=42)
+    lo_r, _ = shard_range(world * n_steps * args.impressions, rank, world)
+    batches = [StepBatch(imp_all, lo_r + s * args.impressions, lo_r + (s + 1) * args.impressions, pool_ids, pool_mask,
+                         pool_len, dev) for s in range(n_steps)]
+    max_news = max(b.ids.shape[0] for b in batches)
+    table_buf = torch.empty((max_news, cfg.hidden), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    log(f"{n_steps} step batches resident ({batches[0].ids.shape[0]} news, {batches[0].tokens} tokens in step 0); warm-up")
+    for b in batches[: args.warmup]:
+        run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for b in batches[args.warmup:]:
+        last = run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+    enc.status()
+
+    timed = batches[args.warmup:]
+    cands = float(sum(b.n_cand for b in timed))
+    news = float(sum(b.n_hist + b.n_cand for b in timed))
+    tokens = float(sum(b.tokens for b in timed))
+    enc_flops = float(sum(cfg.flops_per_news(int(l)) for b in timed for l in b.lens))
+    stats = torch.tensor([elapsed, cands, news, tokens, enc_flops], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
+        stats[0] = mx[0]
+    elapsed_max, cands_all, news_all, tokens_all, flops_all = stats.tolist()
+
+    result = None
+    if rank == 0:
+        peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else F32_PEAK_TFLOPS
+        result = {
+            "metric": "candidate news encoded+scored/sec", "value": cands_all / elapsed_max, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[1]: CR-Module late fusion, MIND-small shape (65238-news pool), "
+                                   f"{args.model} architecture, mode R (every history+candidate occurrence encoded)",
+                       "impressions_per_step_per_gpu": args.impressions, "length_profile": args.profile,
+                       "seeded_weights_std": args.std, "parallelism": f"dp{world} (impressions sharded, no collective)"},
+            "news_encoded_per_s": news_all / elapsed_max, "tokens_per_s": tokens_all / elapsed_max,
+            "encoder_mfma_frac": flops_all / elapsed_max / 1e12 / (peak * world),
+            "encoder_tflops": flops_all / elapsed_max / 1e12,
+            "ndcg10_last_step": float(last[2].double().mean().item()),
+        }
+
+    # per-kernel roofline: same steps again with every launch bracketed by HIP events on the launch stream
+    if rank == 0 and not args.no_kernel_profile:
+        log("per-kernel HIP-event pass")
+        enc.profile(True)
+        for b in timed:
+            run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+        prof = enc.profile_read()
+        enc.profile(False)
+        tok_local = float(sum(b.tokens for b in timed))
+        h, i = cfg.hidden, cfg.intermediate
+        shape = {"gemm_qkv": (3 * h, h), "gemm_out": (h, h), "gemm_ffn1": (i, h), "gemm_ffn2": (h, i)}
+        kern = {}
+        for cls, (ms, cnt) in prof.items():
+            if cnt == 0:
+                continue
+            ent = {"ms_total": ms, "launches": cnt, "avg_us": 1e3 * ms / cnt}
+            if cls in shape:
+                n_, k_ = shape[cls]
+                fl = 2.0 * n_ * k_ * tok_local * cfg.layers / cnt          # algorithmic FLOPs per launch
+                ent["flops_per_launch"] = fl
+                ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
+            kern[cls] = ent
+        dom = max((c for c in kern if c in shape), key=lambda c: kern[c]["ms_total"])
+        result["kernels"] = kern
+        result["roofline"] = {
+            "kernel": dom + " (gemm_tn_kernel)", "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+            "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": None,
+            "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops_per_launch"]}
+    barrier()
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        log("CPU baseline (oracle) + parity on the bounded sample")
+        cpu, par = cpu_baseline_and_parity(args, cfg, weights, enc, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev)
+        result["cpu_baseline"] = cpu
+        result["parity"] = par
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

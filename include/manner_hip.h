@@ -118,6 +118,20 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
 int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stream);
 #define MANNER_HIP_MAX_LEN 128
 
+/* Optional per-kernel timing (the reference delegates profiling to Lightning's `profiler: simple`,
+ * configs/trainer/default.yaml:21; this is the build's equivalent for the roofline report).
+ * While enabled, every launch inside encode_cls is bracketed by hipEvents on the launch stream.
+ * profile_read synchronises `stream`, adds the elapsed times into ms[MANNER_HIP_PROF_COUNT] and the
+ * launch counts into launches[...] (host arrays, accumulated since the last read) and resets. */
+enum {
+  MANNER_HIP_PROF_LENGTHS = 0, MANNER_HIP_PROF_EMBED, MANNER_HIP_PROF_GEMM_QKV, MANNER_HIP_PROF_ATTENTION,
+  MANNER_HIP_PROF_GEMM_OUT, MANNER_HIP_PROF_LAYERNORM, MANNER_HIP_PROF_GEMM_FFN1, MANNER_HIP_PROF_GEMM_FFN2,
+  MANNER_HIP_PROF_GATHER, MANNER_HIP_PROF_COUNT
+};
+int manner_hip_encoder_profile(manner_hip_encoder_t enc, int32_t enable);
+int manner_hip_encoder_profile_read(manner_hip_encoder_t enc, manner_hip_stream_t stream, double* ms /*host*/,
+                                    int64_t* launches /*host*/);
+
 /* ---------------------------------------------------------------- pooler (K11)
  * Replaces AdditiveAttention.forward — manner/models/components/attention.py:12-29 — and through
  * it NAMLUserEncoder.forward — manner/models/components/user_encoder.py:17-21.

@@ -17,6 +17,8 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
 W_EMB_COUNT, WL_COUNT = 5, 16
 MAX_LEN = 128
+PROF_CLASSES = ["lengths", "embed_ln", "gemm_qkv", "attention", "gemm_out", "layernorm", "gemm_ffn1", "gemm_ffn2",
+                "gather_cls"]
 
 
 class EncoderConfigC(C.Structure):
@@ -35,6 +37,8 @@ SIGNATURES = {
     "manner_hip_encoder_workspace_bytes": (_SZ, [_P, _I64, _I64, _I32]),
     "manner_hip_encode_cls": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P]),
     "manner_hip_encoder_status": (C.c_int, [_P, _P]),
+    "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
+    "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_dot": (C.c_int, [_P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P]),
     "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P]),

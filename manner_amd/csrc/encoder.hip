@@ -49,6 +49,11 @@ struct manner_hip_encoder {
   std::vector<manner::LayerWeights> w[2];   // [MANNER_HIP_PREC_*]
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
+  // opt-in per-launch timing (manner_hip_encoder_profile)
+  bool profiling = false;
+  struct Span { hipEvent_t a, b; int cls; };
+  std::vector<Span> spans;                  // recorded, not yet read
+  std::vector<hipEvent_t> free_events;
 };
 
 namespace manner {
@@ -71,6 +76,27 @@ int pack_matrix(int prec, const float* src, size_t n, void* dst, size_t elem_off
   MANNER_HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst) + elem_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return MANNER_HIP_OK;
 }
+
+// brackets one launch with events when profiling is on
+struct ProfScope {
+  manner_hip_encoder* e; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int cls;
+  static hipEvent_t get(manner_hip_encoder* e) {
+    hipEvent_t ev = nullptr;
+    if (!e->free_events.empty()) { ev = e->free_events.back(); e->free_events.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    return ev;
+  }
+  ProfScope(manner_hip_encoder* enc, hipStream_t st, int c) : e(enc), s(st), cls(c) {
+    if (!e->profiling) return;
+    a = get(e); b = get(e);
+    if (a && b) (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!a || !b) return;
+    (void)hipEventRecord(b, s);
+    e->spans.push_back({a, b, cls});
+  }
+};
 
 struct Workspace {
   int32_t *lens, *cu, *m_total;
@@ -101,22 +127,30 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
   const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
   const int H = c.hidden, I = c.intermediate;
   int rc;
-  if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, e->status, s))) return rc;
+  {
+    ProfScope ps(e, s, MANNER_HIP_PROF_LENGTHS);
+    if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, e->status, s))) return rc;
+  }
   const int pos_offset = c.arch == MANNER_HIP_ARCH_ROBERTA ? c.pad_id + 1 : 0;
-  if ((rc = embed_layernorm(dt, ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, e->embg, e->embb, H, c.ln_eps,
-                            pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
-    return rc;
+  {
+    ProfScope ps(e, s, MANNER_HIP_PROF_EMBED);
+    if ((rc = embed_layernorm(dt, ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, e->embg, e->embb, H, c.ln_eps,
+                              pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
+      return rc;
+  }
   for (int l = 0; l < c.layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
-    if ((rc = gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))) return rc;
-    if ((rc = attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))) return rc;
-    if ((rc = gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))) return rc;
-    if ((rc = layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))) return rc;
-    if ((rc = gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))) return rc;
-    if ((rc = gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))) return rc;
-    if ((rc = layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))) return rc;
+#define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
+    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
   }
+  ProfScope ps(e, s, MANNER_HIP_PROF_GATHER);
   return gather_cls(dt, ws.x, ws.cu, n_news, H, out, s);
 }
 
@@ -130,8 +164,29 @@ extern "C" {
 int manner_hip_abi_version(void) { return MANNER_HIP_ABI_VERSION; }
 const char* manner_hip_last_error(void) { return g_err; }
 
+int manner_hip_encoder_profile(manner_hip_encoder_t enc, int32_t enable) {
+  if (!enc) return fail(MANNER_HIP_E_INVALID, "encoder_profile: null handle");
+  enc->profiling = enable != 0;
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_encoder_profile_read(manner_hip_encoder_t enc, manner_hip_stream_t stream, double* ms, int64_t* launches) {
+  if (!enc || !ms || !launches) return fail(MANNER_HIP_E_INVALID, "encoder_profile_read: null argument");
+  MANNER_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  for (auto& sp : enc->spans) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms[sp.cls] += t; launches[sp.cls] += 1; }
+    enc->free_events.push_back(sp.a);
+    enc->free_events.push_back(sp.b);
+  }
+  enc->spans.clear();
+  return MANNER_HIP_OK;
+}
+
 int manner_hip_encoder_destroy(manner_hip_encoder_t enc) {
   if (!enc) return MANNER_HIP_OK;
+  for (auto& sp : enc->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (hipEvent_t ev : enc->free_events) (void)hipEventDestroy(ev);
   for (void* p : enc->allocs) (void)hipFree(p);
   delete enc;
   return MANNER_HIP_OK;

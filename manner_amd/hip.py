@@ -133,6 +133,18 @@ class HipEncoder:
                 _ptr(out), _ptr(ws), ws.numel(), _stream()))
         return out
 
+    def profile(self, enable: bool) -> None:
+        """Bracket every launch of encode_cls with HIP events on the launch stream (opt-in)."""
+        _lib.check(_lib.load().manner_hip_encoder_profile(self._handle, int(enable)))
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        """{kernel class: (total ms, launches)} accumulated since the last read; synchronises."""
+        n = len(_lib.PROF_CLASSES)
+        ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().manner_hip_encoder_profile_read(self._handle, _stream(), ms, cnt))
+        return {c: (ms[i], cnt[i]) for i, c in enumerate(_lib.PROF_CLASSES)}
+
     def status(self) -> None:
         """Blocking check of the device-side input validation flag (raises on bad masks/ids)."""
         with torch.cuda.device(self.device):
