@@ -12,6 +12,7 @@
 // pre-LayerNorm sums, LayerNorm statistics, softmax and all accumulation are f32 in both modes.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -49,6 +50,12 @@ struct manner_hip_encoder {
   std::vector<manner::LayerWeights> w[2];   // [MANNER_HIP_PREC_*]
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
+  // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
+  // HBM-bound phases of one chunk (epilogues, LayerNorm, attention) overlap the MFMA-bound phases
+  // of the other; MANNER_HIP_STREAMS=1 disables
+  int n_streams = 2;
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   // opt-in per-launch timing (manner_hip_encoder_profile)
   bool profiling = false;
   struct Span { hipEvent_t a, b; int cls; };
@@ -187,6 +194,9 @@ int manner_hip_encoder_destroy(manner_hip_encoder_t enc) {
   if (!enc) return MANNER_HIP_OK;
   for (auto& sp : enc->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t ev : enc->free_events) (void)hipEventDestroy(ev);
+  if (enc->side) (void)hipStreamDestroy(enc->side);
+  if (enc->fork_ev) (void)hipEventDestroy(enc->fork_ev);
+  if (enc->join_ev) (void)hipEventDestroy(enc->join_ev);
   for (void* p : enc->allocs) (void)hipFree(p);
   delete enc;
   return MANNER_HIP_OK;
@@ -220,6 +230,15 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_EMB_LN_B], H, &e->embb, s))) break;
     if (!guard(dev_alloc(e, 256, (void**)&e->status))) break;
     if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
+    if (const char* ev = getenv("MANNER_HIP_STREAMS")) e->n_streams = atoi(ev) >= 2 ? 2 : 1;
+    if (e->n_streams == 2) {
+      if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming) != hipSuccess) {
+        rc = fail(MANNER_HIP_E_RUNTIME, "encoder_create: side stream/event creation failed");
+        break;
+      }
+    }
     e->params.resize(L);
     for (int p = 0; p < 2; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
     for (int l = 0; l < L && !rc; ++l) {
@@ -259,7 +278,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
 
 size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens, int32_t precision) {
   if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 1) return 0;
-  return carve(enc, max_news, round_up(max_tokens, 128), precision, nullptr, nullptr);
+  return enc->n_streams * carve(enc, max_news, round_up(max_tokens, 256), precision, nullptr, nullptr);
 }
 
 int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
@@ -272,22 +291,27 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
   if (padded_len < 1 || padded_len > MANNER_HIP_MAX_LEN) return fail(MANNER_HIP_E_INVALID, "encode_cls: padded_len %lld outside [1, %d]", (long long)padded_len, MANNER_HIP_MAX_LEN);
   if ((uintptr_t)workspace % 256) return fail(MANNER_HIP_E_INVALID, "encode_cls: workspace must be 256-byte aligned");
   const int H = enc->cfg.hidden;
-  // largest (news, tokens) chunk capacity the workspace admits: tokens scale the big buffers
+  // largest (news, tokens) chunk capacity the workspace admits: tokens scale the big buffers.
+  // With two streams the workspace is split into two independent halves.
+  const int ns = enc->profiling ? 1 : enc->n_streams;   // per-kernel timing wants un-overlapped launches
+  const size_t ws_each = (workspace_bytes / ns) / 256 * 256;
   const size_t es = precision == MANNER_HIP_PREC_BF16 ? 2 : 4;
   const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es;
-  int64_t m_cap = (int64_t)(workspace_bytes / per_tok) / 128 * 128;
+  int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;
   int64_t n_cap = 0;
-  while (m_cap >= 128) {
+  while (m_cap >= 256) {
     n_cap = m_cap;   // a news has >= 1 token, so a chunk never holds more news than tokens
     if (n_cap > n_news) n_cap = n_news;
-    if (carve(enc, n_cap, m_cap, precision, nullptr, nullptr) <= workspace_bytes) break;
-    m_cap -= 128;
+    if (carve(enc, n_cap, m_cap, precision, nullptr, nullptr) <= ws_each) break;
+    m_cap -= 256;
   }
-  if (m_cap < 128 || m_cap < padded_len) return fail(MANNER_HIP_E_WORKSPACE, "encode_cls: workspace of %zu bytes cannot hold one 128-token tile", workspace_bytes);
-  Workspace ws;
-  carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace), &ws);
-  hipStream_t s = (hipStream_t)stream;
+  if (m_cap < 256 || m_cap < padded_len) return fail(MANNER_HIP_E_WORKSPACE, "encode_cls: workspace of %zu bytes cannot hold one 256-token tile per stream", workspace_bytes);
+  Workspace ws[2];
+  for (int i = 0; i < ns; ++i) carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace) + i * ws_each, &ws[i]);
+  hipStream_t s0 = (hipStream_t)stream;
+  bool forked = false;
   int64_t n0 = 0;
+  int chunk = 0;
   while (n0 < n_news) {
     int64_t cnt = 0, m_bound;
     if (host_lengths) {
@@ -299,17 +323,32 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
         tok += len;
         ++cnt;
       }
-      m_bound = round_up(tok, 128);
+      m_bound = round_up(tok, 256);
     } else {
       cnt = m_cap / padded_len;
       if (cnt > n_cap) cnt = n_cap;
       if (cnt > n_news - n0) cnt = n_news - n0;
-      m_bound = round_up(cnt * padded_len, 128);
+      m_bound = round_up(cnt * padded_len, 256);
+    }
+    const int lane = ns == 2 ? (chunk & 1) : 0;
+    hipStream_t s = s0;
+    if (lane == 1) {
+      if (!forked) {                                   // side stream starts after the caller's prior work
+        MANNER_HIP_TRY(hipEventRecord(enc->fork_ev, s0));
+        MANNER_HIP_TRY(hipStreamWaitEvent(enc->side, enc->fork_ev, 0));
+        forked = true;
+      }
+      s = enc->side;
     }
     int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
-                          out + n0 * H, ws, s);
+                          out + n0 * H, ws[lane], s);
     if (rc) return rc;
     n0 += cnt;
+    ++chunk;
+  }
+  if (forked) {                                        // join: the caller's stream waits for the side stream
+    MANNER_HIP_TRY(hipEventRecord(enc->join_ev, enc->side));
+    MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev, 0));
   }
   return MANNER_HIP_OK;
 }

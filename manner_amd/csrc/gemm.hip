@@ -19,6 +19,10 @@
 //   bf16: one v_mfma_f32_32x32x16_bf16 per 16-byte chunk pair (lane half h holds k = 8h..8h+7).
 //   f32 : four v_mfma_f32_32x32x2_f32 per chunk (element e of lane half h is k = 4h+e of the
 //         chunk pair) — exact f32 FMA chains, the 1e-4 parity mode.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace manner {
@@ -31,6 +35,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
   // nn.functional.gelu default (transformers/activations.py ACT2FN["gelu"]): x/2 * (1 + erf(x/sqrt2))
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): used where the result is rounded to bf16
+// (relative step 2^-9), i.e. the bf16 encoder's FFN; the f32 parity mode keeps erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+template <typename TIn> __device__ __forceinline__ float gelu_for(float x);
+template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return gelu_erf_fast(x); }
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = gelu_for<TIn>(v[e]);
         }
         if (EPI == EPI_BIAS_RES) {
           float r[4];
@@ -208,6 +228,212 @@ int launch(Epilogue epi, const void* X, const void* W, const float* bias, const 
   return MANNER_HIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel: 256(m) x 256(n) tile, 8 waves as 2(m) x 4(n), wave tile 128(m) x 64(n) = 4 x 2 MFMA
+// tiles (128 accumulator VGPRs), BK = 128 bytes, two 64 KiB LDS stages.  Per K-step a wave issues
+// 8 LDS-DMA pieces, 24 ds_read_b128 and 32 MFMAs (the 128x128 kernel above: 8 / 16 / 16), and the
+// K-chunk loop is software-pipelined in registers: the fragments of chunk kc+1 and two DMA pieces
+// of the NEXT K-step are issued before the 8 MFMAs of chunk kc, so the matrix pipe of a SIMD (two
+// waves) is not left idle while its waves issue LDS reads and DMA.
+//   iteration kt:  s_waitcnt vmcnt(0)   my pieces of tile kt (issued during iteration kt-1) landed
+//                  s_barrier            everyone's pieces landed; everyone finished reading buf^1
+//                  for kc: read frags(kc+1); issue 2 pieces of tile kt+1 -> buf^1; 8 MFMAs(kc)
+constexpr int G_BM = 256, G_BN = 256;
+constexpr int G_OP_BYTES = 256 * ROW_BYTES, G_STAGE_BYTES = 2 * G_OP_BYTES;   // 32 KiB per operand
+
+// ABL (lab only, tools/gemm_lab.hip): 0 production; 1 no epilogue stores; 2 no DMA inside the loop;
+// 3 no fragment reads inside the loop.  Timing-only builds: outputs are wrong for ABL != 0.
+template <typename TIn, typename TOut, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
+    const TIn* __restrict__ X, const TIn* __restrict__ W, const float* __restrict__ bias,
+    const TIn* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles) {
+  constexpr int EPC = 16 / sizeof(TIn);
+  constexpr int BK = ROW_BYTES / sizeof(TIn);
+  typedef typename Frag<TIn>::type frag_t;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
+
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int M = *m_total;
+  if (mt * G_BM >= M) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rr = lane & 31, h = lane >> 5;
+  const int wn = wave & 3, wm = wave >> 2;
+
+  // staging: 64 pieces (1 KiB = 8 rows) per stage; waves 0-3 bring the weight tile, 4-7 the
+  // activation tile, 8 consecutive pieces (64 rows) each
+  const bool is_w = wave < 4;
+  const int prow0 = 64 * (wave & 3);                                  // first row of this wave's pieces
+  const TIn* gbase = is_w ? W + (size_t)(nt * G_BN + prow0) * K : X + (size_t)(mt * G_BM + prow0) * K;
+  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
+  // piece i covers rows prow0 + 8i + (lane>>3); (row>>1)&7 = (4i + (lane>>4)) & 7
+  const int lrow = lane >> 3;
+  int voff[2];                                                         // even / odd pieces
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
+  auto issue2 = [&](int buf, int k0, int pair) {                       // pieces 2*pair, 2*pair+1
+    char* base = lds + buf * G_STAGE_BYTES + ldst0;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int i = 2 * pair + par;
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gbase + (size_t)(8 * i) * K + k0 + voff[par]),
+                                       LDS_PTR(base + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (rr >> 1) & 7;
+  const int woff = (wn * 64 + rr) * ROW_BYTES;
+  const int xoff = G_OP_BYTES + (wm * 128 + rr) * ROW_BYTES;
+  auto read_frags = [&](const char* base, int kc, frag_t (&wf)[2], frag_t (&xf)[4]) {
+    const int coff = ((2 * kc + h) ^ swz) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const frag_t*>(base + woff + i * 32 * ROW_BYTES + coff);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const frag_t*>(base + xoff + j * 32 * ROW_BYTES + coff);
+  };
+  auto mma8 = [&](const frag_t (&wf)[2], const frag_t (&xf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma_chunk<TIn>(wf[i], xf[j], acc[i][j]);
+  };
+
+  // one K-step on buffer `cur`; NEXT: also issue the DMA of the following K-step into cur^1
+  auto kstep = [&](int cur, int k1, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* base = lds + cur * G_STAGE_BYTES;
+    frag_t wa[2], xa[4], wb[2], xb[4];
+    if (ABL != 3 || k1 == BK) read_frags(base, 0, wa, xa);
+    if (ABL != 3 || k1 == BK) read_frags(base, 1, wb, xb);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wa, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 3) read_frags(base, 2, wa, xa);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wb, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 3) read_frags(base, 3, wb, xb);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wa, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wb, xb);
+  };
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) issue2(0, 0, pair);
+  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, std::true_type{});
+  kstep((nk - 1) & 1, 0, std::false_type{});
+
+  // ---- epilogue.  acc[i][j][reg] = D[n][m], n = 32i + (reg&3) + 8(reg>>2) + 4h, m = 32j + rr.
+  // Direct stores from this layout are 8-byte pieces at a row stride (store-issue bound: they cost
+  // 38 % of the K=768 GEMMs).  Instead each wave passes its 32(m) x 64(n) slabs through a private
+  // LDS slab (XOR-swizzled 16-byte chunks) and writes whole 128/256-byte output rows with 16-byte
+  // accesses; the residual is added on the row-contiguous side, so its loads are coalesced too.
+  __builtin_amdgcn_s_barrier();                      // all waves finished reading the K-loop stages
+  constexpr int OUT_ROW = 64 * sizeof(TOut);         // 128 B (bf16) / 256 B (f32) per token row
+  constexpr int CHUNKS = OUT_ROW / 16;               // 8 / 16 chunks of 16 bytes
+  constexpr int OPC = 16 / sizeof(TOut);             // outputs per chunk: 8 / 4
+  char* slab = lds + wave * (32 * OUT_ROW);
+  const int nbase = nt * G_BN + wn * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = 32 * i + 8 * g + 4 * h;        // local n of the lane's 4 values
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + nbase + nl);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_for<TIn>(v[e]);
+        }
+        const int c = nl / OPC;                       // logical chunk; bf16: + 8-byte half h
+        const int off = rr * OUT_ROW + ((c ^ (rr & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * h : 0);
+        store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ROWS_PER_INST = 64 / CHUNKS;        // 8 / 4 token rows per wave-instruction
+    constexpr int NQ = 32 / ROWS_PER_INST;
+    const int row0 = lane / CHUNKS, sl = lane % CHUNKS;
+    float res[EPI == EPI_BIAS_RES ? NQ : 1][4];
+    if (EPI == EPI_BIAS_RES && ABL != 1) {            // all residual loads of the slab in flight at once
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
+        load4<TIn>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC, res[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = q * ROWS_PER_INST + row0;
+      const int c = sl ^ (row & (CHUNKS - 1));
+      const int m = mt * G_BM + wm * 128 + 32 * j + row;
+      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+      if (EPI == EPI_BIAS_RES) {                      // TOut == float here: 4 outputs per chunk
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] += res[q][e];
+      }
+      if (m < M)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename TIn, typename TOut>
+int launch_big(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
+               int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  const int n_tiles = N / G_BN;
+  const int64_t grid = (m_bound / G_BM) * n_tiles;
+  if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
+  dim3 g((unsigned)grid), b(512);
+  const TIn* x = static_cast<const TIn*>(X);
+  const TIn* w = static_cast<const TIn*>(W);
+  const TIn* r = static_cast<const TIn*>(R);
+  TOut* y = static_cast<TOut*>(Y);
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_tn_big_kernel<TIn, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_tn_big_kernel<TIn, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_RES:
+      hipLaunchKernelGGL((gemm_tn_big_kernel<TIn, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
 }  // namespace
 
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,
@@ -217,6 +443,12 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   if (N % BN || (K * esz) % ROW_BYTES || m_bound % BM)
     return fail(MANNER_HIP_E_INVALID, "gemm shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if (epi == EPI_BIAS_RES && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
+  static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
+  if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
+    if (in == DT_BF16 && out == DT_BF16) return launch_big<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+    if (in == DT_BF16 && out == DT_F32) return launch_big<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+    if (in == DT_F32 && out == DT_F32) return launch_big<float, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  }
   if (in == DT_BF16 && out == DT_BF16) return launch<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
   if (in == DT_BF16 && out == DT_F32) return launch<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
   if (in == DT_F32 && out == DT_F32) return launch<float, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);

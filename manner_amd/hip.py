@@ -125,7 +125,7 @@ class HipEncoder:
             tokens = min(int(hl.sum()), max_chunk_tokens)
         else:
             tokens = min(n * lp, max_chunk_tokens)
-        tokens = max(tokens, lp, 128)
+        tokens = max(tokens, lp, 256)
         with torch.cuda.device(ids.device):
             ws = self._workspace(min(n, tokens), tokens, prec)
             _lib.check(_lib.load().manner_hip_encode_cls(

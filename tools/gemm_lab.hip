@@ -1,0 +1,72 @@
+// Development lab: times the encoder GEMM kernels standalone on random data (not shipped, not
+// part of libmanner_hip.so).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imanner_amd/csrc
+//   tools/gemm_lab.hip -o gpurun_out/gemm_lab && gpurun_out/gemm_lab
+#include <stdio.h>
+#include <vector>
+#include <random>
+#include "../manner_amd/csrc/gemm.hip"
+namespace manner { int fail(int code, const char* fmt, ...) { fprintf(stderr, "fail %d: %s\n", code, fmt); return code; } }
+using namespace manner;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <typename F>
+static double time_ms(F f, int iters) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); f();
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 65536;
+  struct Shape { const char* name; int N, K; Epilogue epi; bool f32out; };
+  Shape shapes[] = {{"qkv", 2304, 768, EPI_BIAS, false}, {"out", 768, 768, EPI_BIAS_RES, true},
+                    {"ffn1", 3072, 768, EPI_BIAS_GELU, false}, {"ffn2", 768, 3072, EPI_BIAS_RES, true}};
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  const size_t maxe = (size_t)M * 3072;
+  std::vector<bf16_t> h(maxe);
+  for (size_t i = 0; i < maxe; ++i) h[i] = (bf16_t)nd(rng);
+  bf16_t *X, *W, *R; float* bias; void* Y; int* mtot;
+  CK(hipMalloc(&X, maxe * 2)); CK(hipMalloc(&W, (size_t)3072 * 3072 * 2)); CK(hipMalloc(&R, maxe * 2));
+  CK(hipMalloc(&Y, maxe * 4)); CK(hipMalloc(&bias, 3072 * 4)); CK(hipMalloc(&mtot, 4));
+  CK(hipMemcpy(X, h.data(), maxe * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(R, h.data(), maxe * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, h.data(), (size_t)3072 * 3072 * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, 3072 * 4));
+  CK(hipMemcpy(mtot, &M, 4, hipMemcpyHostToDevice));
+  for (auto& s : shapes) {
+    const int n_tiles = s.N / G_BN;
+    dim3 g((M / G_BM) * n_tiles), b(512);
+    const double fl = 2.0 * M * s.N * s.K;
+    auto run = [&](int abl) {
+#define LAUNCH(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_big_kernel<bf16_t, TO, EPI, ABL>), g, b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
+#define BY_ABL(TO, EPI) switch (abl) { case 0: LAUNCH(TO, EPI, 0); break; case 1: LAUNCH(TO, EPI, 1); break; case 2: LAUNCH(TO, EPI, 2); break; case 3: LAUNCH(TO, EPI, 3); break; }
+      if (s.epi == EPI_BIAS) { BY_ABL(bf16_t, EPI_BIAS) }
+      else if (s.epi == EPI_BIAS_GELU) { BY_ABL(bf16_t, EPI_BIAS_GELU) }
+      else { BY_ABL(float, EPI_BIAS_RES) }
+    };
+    printf("%-5s M=%d N=%d K=%d:", s.name, M, s.N, s.K);
+    for (int abl = 0; abl < 4; ++abl) {
+      double ms = time_ms([&] { run(abl); }, 20);
+      printf("  abl%d %.1f us %.0f TF", abl, ms * 1e3, fl / ms / 1e9);
+    }
+    // v1 128x128
+    {
+      dim3 g1((M / 128) * (s.N / 128)), b1(256);
+      double ms = time_ms([&] {
+        if (s.epi == EPI_BIAS) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t, EPI_BIAS>), g1, b1, 0, 0, X, W, bias, R, (bf16_t*)Y, s.N, s.K, mtot, s.N / 128);
+        else if (s.epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t, EPI_BIAS_GELU>), g1, b1, 0, 0, X, W, bias, R, (bf16_t*)Y, s.N, s.K, mtot, s.N / 128);
+        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float, EPI_BIAS_RES>), g1, b1, 0, 0, X, W, bias, R, (float*)Y, s.N, s.K, mtot, s.N / 128);
+      }, 20);
+      printf("  | v1 %.1f us %.0f TF", ms * 1e3, fl / ms / 1e9);
+    }
+    printf("\n");
+  }
+  CK(hipDeviceSynchronize());
+  return 0;
+}
