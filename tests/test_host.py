@@ -1,0 +1,187 @@
+"""CPU-side checks: the C-ABI library exports what the header declares, the module mirror keeps the
+reference's surface, host logic (sharding, synthetic generators) is deterministic, and the
+multi-rank plumbing works under gloo with world_size 2.  No GPU compute here."""
+import ctypes
+import inspect
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from manner_amd import _lib
+from manner_amd.config import PRESETS
+from manner_amd.synth import segment_ids, shard_range, synth_impressions, synth_lengths, synth_news_tokens
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 14 and set(syms) == set(_lib.SIGNATURES)
+    for s in syms:
+        assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
+    assert lib.manner_hip_abi_version() == 1
+    assert lib.manner_hip_encoder_workspace_bytes(None, 1, 1, 0) == 0          # null handle: no crash
+
+
+def test_library_argument_errors_without_gpu():
+    lib = _lib.load()
+    assert lib.manner_hip_dot(None, None, 2, 2, 4, 8, 1, 4, None, None) == 1    # MANNER_HIP_E_INVALID
+    assert b"dot" in lib.manner_hip_last_error()
+    assert lib.manner_hip_encode_cls(None, None, None, None, 1, 8, 0, None, None, 0, None) == 1
+    assert lib.manner_hip_zscore_fuse(None, 0, 1, None, None, 0, None, None) == 0   # B == 0: nothing to do
+
+
+def test_module_surface_matches_reference_signatures(golden_dir):
+    """Constructor arguments / forward parameters as in reference news_encoder.py:76-87,115,
+    user_encoder.py:10,17, click_predictors.py:6,9-11, attention.py:7,12."""
+    from manner_amd.models.components.attention import AdditiveAttention
+    from manner_amd.models.components.click_predictors import DotProduct
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder, MannerTextEncoder
+    from manner_amd.models.components.user_encoder import NAMLUserEncoder
+
+    def params(f):
+        return list(inspect.signature(f).parameters)[1:]
+
+    assert params(MannerNewsEncoder.__init__) == [
+        "plm_model", "frozen_layers", "dropout_probability", "use_entities", "entity_embeddings",
+        "entity_embedding_dim", "num_attention_heads", "query_vector_dim", "text_embedding_dim"]
+    assert params(MannerNewsEncoder.forward) == ["news"]
+    assert params(MannerTextEncoder.__init__) == ["plm_model", "frozen_layers", "dropout_probability"]
+    assert params(NAMLUserEncoder.__init__) == ["news_embedding_dim", "query_vector_dim"]
+    assert params(NAMLUserEncoder.forward) == ["clicked_news_vector"]
+    assert params(DotProduct.forward) == ["clicked_news_vector", "candidate_news_vector"]
+    assert params(AdditiveAttention.__init__) == ["input_dim", "query_dim"]
+    with open(os.path.join(golden_dir, "state_dict_keys.json")) as f:
+        ref_keys = json.load(f)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder("tiny-bert", [0, 1], 0.2, False, None, 100, 10, 200, 128)
+        ent = MannerNewsEncoder("tiny-bert", [0], 0.2, True, np.zeros((7, 100), np.float32), 100, 10, 200, 128)
+    assert sorted(enc.state_dict()) == ref_keys["tiny-bert"]
+    frozen = [n for n, p in enc.named_parameters() if not p.requires_grad]
+    assert frozen and all("layer.0." in n or "layer.1." in n for n in frozen)          # news_encoder.py:24-27
+    extra = sorted(set(ent.state_dict()) - set(enc.state_dict()))
+    assert extra == sorted(["entity_encoder.pretrained_embedding.weight", "entity_encoder.multihead_attention.in_proj_weight",
+                            "entity_encoder.multihead_attention.in_proj_bias", "entity_encoder.multihead_attention.out_proj.weight",
+                            "entity_encoder.multihead_attention.out_proj.bias", "entity_encoder.additive_attention.query",
+                            "entity_encoder.additive_attention.linear.weight", "entity_encoder.additive_attention.linear.bias",
+                            "linear.weight", "linear.bias"])
+    assert tuple(ent.linear.weight.shape) == (128, 228)
+    assert sorted(NAMLUserEncoder(768, 200).state_dict()) == ref_keys["user_encoder"]
+    # no CPU fallback, no training path
+    enc.eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        enc({"text": {"input_ids": torch.zeros(1, 4, dtype=torch.long), "attention_mask": torch.ones(1, 4, dtype=torch.long)}})
+    with pytest.raises(RuntimeError, match="GPU"):
+        DotProduct()(torch.zeros(1, 1, 4), torch.zeros(1, 4, 2))
+    with pytest.raises(NotImplementedError):
+        ent.eval()({"entities": torch.zeros(1, 2, dtype=torch.long)})
+
+
+def test_local_hf_directory_loading(tmp_path):
+    from safetensors.torch import save_file
+    from manner_amd.models.components.news_encoder import HipPLM
+    from manner_amd.weights import make_plm_weights
+    cfg = PRESETS["tiny-roberta"]
+    w = make_plm_weights(cfg, seed=3)
+    (tmp_path / "config.json").write_text(json.dumps({
+        "model_type": "roberta", "hidden_size": cfg.hidden, "num_hidden_layers": cfg.layers,
+        "num_attention_heads": cfg.heads, "intermediate_size": cfg.intermediate, "vocab_size": cfg.vocab,
+        "max_position_embeddings": cfg.max_pos, "type_vocab_size": cfg.type_vocab, "layer_norm_eps": cfg.ln_eps,
+        "pad_token_id": cfg.pad_id, "hidden_act": "gelu"}))
+    save_file({"roberta." + k: torch.from_numpy(v) for k, v in w.items()}, str(tmp_path / "model.safetensors"))
+    m = HipPLM.from_pretrained(str(tmp_path))
+    assert m.cfg == cfg
+    sd = m.state_dict()
+    assert all(np.array_equal(sd[k].numpy(), v) for k, v in w.items())
+
+
+def test_synthetic_inputs_are_deterministic_and_well_formed():
+    cfg = PRESETS["bert-base-uncased"]
+    ids, mask = synth_news_tokens(500, cfg, seed=42, profile="title_abstract")
+    ids2, _ = synth_news_tokens(500, cfg, seed=42, profile="title_abstract")
+    assert np.array_equal(ids, ids2) and ids.dtype == np.int64
+    lens = mask.sum(1)
+    assert lens.min() >= 5 and lens.max() <= 96 and (ids[:, 0] == 101).all()
+    assert (ids[np.arange(500), lens - 1] == 102).all() and (ids[mask == 0] == cfg.pad_id).all()
+    assert (np.diff(mask, axis=1) <= 0).all()                                  # right-padded prefix masks
+    ta = synth_lengths(5000, 1, profile="title_abstract")        # SURVEY.md §8d formula: a third saturate at 96
+    assert 0.25 < (ta == 96).mean() < 0.5 and 65 < ta.mean() < 85 and 12 < synth_lengths(5000, 1).mean() < 20
+    imp = synth_impressions(2000, 65238, seed=42)
+    h, c = np.diff(imp["hist_off"]), np.diff(imp["cand_off"])
+    assert h.min() >= 1 and h.max() <= 50 and c.min() >= 2 and c.max() <= 300
+    assert imp["cand_idx"].max() < 65238 and imp["hist_idx"].dtype == np.int32
+    pos = np.add.reduceat(imp["labels"], imp["cand_off"][:-1])
+    assert (pos >= 1).all()
+    assert np.array_equal(segment_ids(np.array([0, 2, 2, 5])), [0, 0, 2, 2, 2])
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 73152):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import manner_oracle as O
+        from manner_amd import distributed as D
+        from manner_amd.weights import make_plm_weights
+        cfg = PRESETS["tiny-bert"]
+        w = make_plm_weights(cfg, seed=5, std=0.05)
+        ids, mask = synth_news_tokens(37, cfg, seed=5, max_len=24)
+        shards = D.balanced_news_shards(mask.sum(1), world, cfg.flops_per_news)
+        lo, hi = shards[rank]
+        local = O.encode_cls(ids[lo:hi], mask[lo:hi], w, cfg)               # stand-in for the HIP encoder on CPU
+        table = D.all_gather_table(local, shards)
+        full = O.encode_cls(ids, mask, w, cfg)
+        assert table.shape == full.shape and torch.allclose(table, full, atol=1e-5)
+        imp = synth_impressions(11, 37, seed=5, max_hist=6, max_cand=9)
+        a, b = D.impression_shard(11)
+        ho, co = imp["hist_off"], imp["cand_off"]
+        bh = O.offsets_to_batch((ho[a:b + 1] - ho[a]).tolist())
+        bc = O.offsets_to_batch((co[a:b + 1] - co[a]).tolist())
+        sc = O.ragged(O.cr_scores(table[imp["hist_idx"][ho[a]:ho[b]].astype(np.int64)], bh,
+                                  table[imp["cand_idx"][co[a]:co[b]].astype(np.int64)], bc), bc)
+        nd, per = O.ndcg_at_k(sc, torch.from_numpy(imp["labels"][co[a]:co[b]]), (co[a:b + 1] - co[a]).tolist(), 10)
+        sums = D.allreduce_metric_sums(torch.tensor([per.sum().item(), float(b - a)], dtype=torch.float64))
+        torch.save({"sums": sums, "range": (a, b), "scores": sc}, os.path.join(tmp, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_table_allgather_and_impression_sharding_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["range"][0] == 0 and r0["range"][1] == r1["range"][0] and r1["range"][1] == 11
+    assert torch.equal(r0["sums"], r1["sums"]) and r0["sums"][1] == 11
+    # the two ranks' shards reproduce the single-process result
+    import manner_oracle as O
+    from manner_amd.weights import make_plm_weights
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=5, std=0.05)
+    ids, mask = synth_news_tokens(37, cfg, seed=5, max_len=24)
+    imp = synth_impressions(11, 37, seed=5, max_hist=6, max_cand=9)
+    ref = O.reference_faithful_scores(ids, mask, imp["hist_idx"].astype(np.int64), imp["hist_off"].tolist(),
+                                      imp["cand_idx"].astype(np.int64), imp["cand_off"].tolist(), w, cfg)
+    both = torch.cat([r0["scores"], r1["scores"]])
+    assert torch.allclose(both, ref, atol=1e-4)
+    nd, per = O.ndcg_at_k(ref, torch.from_numpy(imp["labels"]), imp["cand_off"].tolist(), 10)
+    assert abs(r0["sums"][0].item() / 11 - nd) < 1e-6
