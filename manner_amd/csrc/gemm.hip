@@ -408,6 +408,385 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256x256 kernel (MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3
+// (group A) and their SIMD partners 4-7 (group B) run the same K-step half a step apart.  A K-step
+// of a wave is a LOAD segment (all 24 ds_read_b128 of the step into registers, plus DMA issue) and a
+// COMPUTE segment (32 MFMAs on registers only), each ended by s_barrier; while one wave of a SIMD
+// computes, its partner loads, so the matrix pipe always has a feeder and LDS/DMA issue is hidden.
+//   segment:        2k              2k+1            2k+2             2k+3
+//   group A:     LOAD(k)+DMA(k+1)  COMPUTE(k)     LOAD(k+1)+DMA(k+2) COMPUTE(k+1)
+//   group B:     COMPUTE(k-1)+DMA(k+1)  LOAD(k)   COMPUTE(k)+DMA(k+2)  LOAD(k+1)
+// Stage k%2 is read in segments 2k (A) and 2k+1 (B); both groups issue their half of DMA(j) in
+// segment 2j-2 (the stage was last read in 2j-4, 2j-3) and wait vmcnt(0) before the barrier that
+// ends segment 2j-1, so the data is visible from segment 2j on.
+template <typename TIn, typename TOut, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(
+    const TIn* __restrict__ X, const TIn* __restrict__ W, const float* __restrict__ bias,
+    const TIn* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles) {
+  constexpr int EPC = 16 / sizeof(TIn);
+  constexpr int BK = ROW_BYTES / sizeof(TIn);
+  typedef typename Frag<TIn>::type frag_t;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
+
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int M = *m_total;
+  if (mt * G_BM >= M) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rr = lane & 31, h = lane >> 5;
+  const int wn = wave & 3, wm = wave >> 2;          // wm is also the ping-pong group
+
+  const bool is_w = wave < 4;                        // group A brings the weight tile, B the activations
+  const int prow0 = 64 * (wave & 3);
+  const TIn* gbase = is_w ? W + (size_t)(nt * G_BN + prow0) * K : X + (size_t)(mt * G_BM + prow0) * K;
+  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
+  const int lrow = lane >> 3;
+  int voff[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
+  auto issue_all = [&](int buf, int k0) {
+    char* base = lds + buf * G_STAGE_BYTES + ldst0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gbase + (size_t)(8 * i) * K + k0 + voff[i & 1]),
+                                       LDS_PTR(base + i * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (rr >> 1) & 7;
+  const int woff = (wn * 64 + rr) * ROW_BYTES;
+  const int xoff = G_OP_BYTES + (wm * 128 + rr) * ROW_BYTES;
+  frag_t wf[4][2], xf[4][4];
+  auto load_seg = [&](int buf) {
+    const char* base = lds + buf * G_STAGE_BYTES;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int coff = ((2 * kc + h) ^ swz) << 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[kc][i] = *reinterpret_cast<const frag_t*>(base + woff + i * 32 * ROW_BYTES + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[kc][j] = *reinterpret_cast<const frag_t*>(base + xoff + j * 32 * ROW_BYTES + coff);
+    }
+  };
+  auto compute_seg = [&]() {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mma_chunk<TIn>(wf[kc][i], xf[kc][j], acc[i][j]);
+  };
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+  const int nk = K / BK;
+  issue_all(0, 0);
+  if (nk > 1) {
+    issue_all(1, BK);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    PP_WAIT_VM0();
+  }
+  PP_BARRIER();                                        // every wave's DMA(0) is in LDS
+  if (wm == 0) {                                       // ---- group A
+    for (int k = 0; k < nk; ++k) {
+      load_seg(k & 1);
+      if (k >= 1 && k + 1 < nk) issue_all((k + 1) & 1, (k + 1) * BK);
+      PP_BARRIER();                                    // end of segment 2k
+      compute_seg();
+      PP_WAIT_VM0();                                   // own DMA(k+1) landed
+      PP_BARRIER();                                    // end of segment 2k+1
+    }
+  } else {                                             // ---- group B (half a K-step behind)
+    PP_BARRIER();                                      // end of segment 0
+    for (int k = 0; k < nk; ++k) {
+      load_seg(k & 1);
+      PP_WAIT_VM0();                                   // own DMA(k+1) landed (issued in segment 2k)
+      PP_BARRIER();                                    // end of segment 2k+1
+      if (k + 2 < nk) issue_all(k & 1, (k + 2) * BK);
+      compute_seg();
+      if (k + 1 < nk) PP_BARRIER();                    // end of segment 2k+2
+    }
+  }
+#undef PP_BARRIER
+#undef PP_WAIT_VM0
+
+  // ---- epilogue (as in gemm_tn_big_kernel): slabs through wave-private LDS, whole-row 16-byte stores.
+  // After the last common barrier nobody reads the K-loop stages and no DMA is outstanding.
+  constexpr int OUT_ROW = 64 * sizeof(TOut);
+  constexpr int CHUNKS = OUT_ROW / 16;
+  constexpr int OPC = 16 / sizeof(TOut);
+  char* slab = lds + wave * (32 * OUT_ROW);
+  const int nbase = nt * G_BN + wn * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = 32 * i + 8 * g + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + nbase + nl);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_for<TIn>(v[e]);
+        }
+        const int c = nl / OPC;
+        const int off = rr * OUT_ROW + ((c ^ (rr & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * h : 0);
+        store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ROWS_PER_INST = 64 / CHUNKS;
+    constexpr int NQ = 32 / ROWS_PER_INST;
+    const int row0 = lane / CHUNKS, sl = lane % CHUNKS;
+    float res[EPI == EPI_BIAS_RES ? NQ : 1][4];
+    if (EPI == EPI_BIAS_RES && ABL != 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
+        load4<TIn>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC, res[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = q * ROWS_PER_INST + row0;
+      const int c = sl ^ (row & (CHUNKS - 1));
+      const int m = mt * G_BM + wm * 128 + 32 * j + row;
+      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+      if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] += res[q][e];
+      }
+      if (m < M)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 production kernel: the 256x256 / 8-wave / 2-stage structure of gemm_tn_big_kernel on
+// v_mfma_f32_16x16x32_bf16.  Measured on MI355X with random operands, a register-only MFMA loop
+// sustains 2.04 PFLOP/s with the 16x16x32 shape against 1.68-1.77 with 32x32x16 (the chip holds a
+// higher clock on it — cdna_hip_programming.md rule 28), so the same tile is built on the smaller
+// shape.  Wave tile 128(m) x 64(n) = 8 x 4 MFMA tiles, acc[a][b] = D[n = 16a + 4(l>>4) + reg]
+// [m = 16b + (l&15)]: a lane still owns one token and runs of 4 consecutive features.
+// A K-step (64 bf16) is two k32 steps x two m-halves = 4 chunks of 16 MFMAs; the weight fragments
+// of a k32 step (4) and the activation fragments of a chunk (4) are double-buffered in registers and
+// read one chunk ahead, with two DMA pieces of the next K-step issued per chunk.
+template <typename TOut, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    const bf16_t* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles) {
+  typedef bf16_t TIn;
+  constexpr int EPC = 8, BK = 64;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
+
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int M = *m_total;
+  if (mt * G_BM >= M) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wn = wave & 3, wm = wave >> 2;
+
+  const bool is_w = wave < 4;
+  const int prow0 = 64 * (wave & 3);
+  const TIn* gbase = is_w ? W + (size_t)(nt * G_BN + prow0) * K : X + (size_t)(mt * G_BM + prow0) * K;
+  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
+  const int lrow = lane >> 3;
+  int voff[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
+  auto issue2 = [&](int buf, int k0, int pair) {
+    char* base = lds + buf * G_STAGE_BYTES + ldst0;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int i = 2 * pair + par;
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gbase + (size_t)(8 * i) * K + k0 + voff[par]),
+                                       LDS_PTR(base + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment of k32 step s, 16-row block: lane reads row 16*blk + l15, 16-byte chunk 4s + lq
+  const int swz = (l15 >> 1) & 7;
+  const int woff = (wn * 64 + l15) * ROW_BYTES;
+  const int xoff = G_OP_BYTES + (wm * 128 + l15) * ROW_BYTES;
+  auto read_w = [&](const char* base, int s2, bf16x8 (&wf)[4]) {
+    const int coff = ((4 * s2 + lq) ^ swz) << 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(base + woff + a * 16 * ROW_BYTES + coff);
+  };
+  auto read_x = [&](const char* base, int s2, int half, bf16x8 (&xf)[4]) {
+    const int coff = ((4 * s2 + lq) ^ swz) << 4;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+      xf[bb] = *reinterpret_cast<const bf16x8*>(base + xoff + (4 * half + bb) * 16 * ROW_BYTES + coff);
+  };
+  auto mma16 = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4], int half) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        acc[a][4 * half + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[bb], acc[a][4 * half + bb], 0, 0, 0);
+  };
+
+  auto kstep = [&](int cur, int k1, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* base = lds + cur * G_STAGE_BYTES;
+    bf16x8 w0[4], w1[4], xa[4], xb[4];
+    read_w(base, 0, w0);
+    read_x(base, 0, 0, xa);
+    // chunk (s=0, half 0)
+    read_x(base, 0, 1, xb);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(w0, xa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // chunk (0, 1)
+    read_w(base, 1, w1);
+    read_x(base, 1, 0, xa);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(w0, xb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // chunk (1, 0)
+    read_x(base, 1, 1, xb);
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(w1, xa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // chunk (1, 1)
+    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(w1, xb, 1);
+  };
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) issue2(0, 0, pair);
+  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, std::true_type{});
+  kstep((nk - 1) & 1, 0, std::false_type{});
+
+  // ---- epilogue: 32-token x 64-feature slabs through a wave-private swizzled LDS slab, whole-row
+  // 16-byte stores / residual loads (see gemm_tn_big_kernel).
+  __builtin_amdgcn_s_barrier();
+  constexpr int OUT_ROW = 64 * sizeof(TOut);
+  constexpr int CHUNKS = OUT_ROW / 16;
+  constexpr int OPC = 16 / sizeof(TOut);
+  char* slab = lds + wave * (32 * OUT_ROW);
+  const int nbase = nt * G_BN + wn * 64;
+  f32x4 bv[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const int row = 16 * b2 + l15;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int nl = 16 * a + 4 * lq;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][2 * j + b2][e] + bv[a][e];
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+        }
+        const int c = nl / OPC;
+        const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
+        store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ROWS_PER_INST = 64 / CHUNKS;
+    constexpr int NQ = 32 / ROWS_PER_INST;
+    const int row0 = lane / CHUNKS, sl = lane % CHUNKS;
+    float res[EPI == EPI_BIAS_RES ? NQ : 1][4];
+    if (EPI == EPI_BIAS_RES && ABL != 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
+        load4<TIn>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC, res[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = q * ROWS_PER_INST + row0;
+      const int c = sl ^ (row & (CHUNKS - 1));
+      const int m = mt * G_BM + wm * 128 + 32 * j + row;
+      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+      if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] += res[q][e];
+      }
+      if (m < M)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename TOut>
+int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
+               int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  const int n_tiles = N / G_BN;
+  const int64_t grid = (m_bound / G_BM) * n_tiles;
+  if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
+  dim3 g((unsigned)grid), b(512);
+  const bf16_t* x = static_cast<const bf16_t*>(X);
+  const bf16_t* w = static_cast<const bf16_t*>(W);
+  const bf16_t* r = static_cast<const bf16_t*>(R);
+  TOut* y = static_cast<TOut*>(Y);
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+    case EPI_BIAS_RES:
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      break;
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
 template <typename TIn, typename TOut>
 int launch_big(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
@@ -445,6 +824,11 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   if (epi == EPI_BIAS_RES && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
+    static const bool use_x32 = getenv("MANNER_HIP_GEMM_X32") != nullptr;   // A/B: bf16 on the 32x32x16 shape
+    if (in == DT_BF16 && !use_x32) {
+      if (out == DT_BF16) return launch_x16<bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+      return launch_x16<float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+    }
     if (in == DT_BF16 && out == DT_BF16) return launch_big<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
     if (in == DT_BF16 && out == DT_F32) return launch_big<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
     if (in == DT_F32 && out == DT_F32) return launch_big<float, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);

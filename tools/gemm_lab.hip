@@ -21,6 +21,47 @@ static double time_ms(F f, int iters) {
   return ms / iters;
 }
 
+// pure-MFMA ceiling: 8 waves per CU, register operands, 8 independent accumulators per wave
+__global__ __launch_bounds__(512, 1) void mfma_peak_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + i) * 8);
+    b[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + 4 + i) * 8);
+  }
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(t + kc) & 3], b[(t >> 1) & 3], acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  dst[blockIdx.x * 512 + threadIdx.x] = s + lane;
+}
+
+__global__ __launch_bounds__(512, 1) void mfma_peak16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + i) * 8);
+    b[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + 4 + i) * 8);
+  }
+  f32x4 acc[32];
+  for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int t = 0; t < 32; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(t + kc) & 3], b[(t >> 3) & 3], acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) s += acc[i][e];
+  dst[blockIdx.x * 512 + threadIdx.x] = s + lane;
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 65536;
   struct Shape { const char* name; int N, K; Epilogue epi; bool f32out; };
@@ -39,6 +80,23 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(W, h.data(), (size_t)3072 * 3072 * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 3072 * 4));
   CK(hipMemcpy(mtot, &M, 4, hipMemcpyHostToDevice));
+  {
+    const int iters = 2000;
+    for (int blocks : {256, 512}) {
+      double ms = time_ms([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, 0, X, (float*)Y, iters); }, 10);
+      const double fl = (double)blocks * 8 * iters * 32 * (2.0 * 32 * 32 * 16);
+      printf("mfma_peak blocks=%d: %.1f us  %.0f TF  (=> %.2f GHz if issue-bound)\n", blocks, ms * 1e3, fl / ms / 1e9,
+             fl / ms / 1e9 / 2500.0 * 2.4);
+    }
+  }
+  {
+    const int iters = 2000;
+    for (int blocks : {256, 512}) {
+      double ms = time_ms([&] { hipLaunchKernelGGL(mfma_peak16_kernel, dim3(blocks), dim3(512), 0, 0, X, (float*)Y, iters); }, 10);
+      const double fl = (double)blocks * 8 * iters * 64 * (2.0 * 16 * 16 * 32);
+      printf("mfma_peak 16x16x32 blocks=%d: %.1f us  %.0f TF\n", blocks, ms * 1e3, fl / ms / 1e9);
+    }
+  }
   for (auto& s : shapes) {
     const int n_tiles = s.N / G_BN;
     dim3 g((M / G_BM) * n_tiles), b(512);
@@ -54,6 +112,34 @@ int main(int argc, char** argv) {
     for (int abl = 0; abl < 4; ++abl) {
       double ms = time_ms([&] { run(abl); }, 20);
       printf("  abl%d %.1f us %.0f TF", abl, ms * 1e3, fl / ms / 1e9);
+    }
+    {
+      auto runx = [&](int abl) {
+#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), g, b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
+#define BY_ABLX(TO, EPI) switch (abl) { case 0: LAUNCHX(TO, EPI, 0); break; case 1: LAUNCHX(TO, EPI, 1); break; case 2: LAUNCHX(TO, EPI, 2); break; }
+        if (s.epi == EPI_BIAS) { BY_ABLX(bf16_t, EPI_BIAS) }
+        else if (s.epi == EPI_BIAS_GELU) { BY_ABLX(bf16_t, EPI_BIAS_GELU) }
+        else { BY_ABLX(float, EPI_BIAS_RES) }
+      };
+      for (int abl = 0; abl < 3; ++abl) {
+        double ms = time_ms([&] { runx(abl); }, 20);
+        printf("  | x16_%d %.1f us %.0f TF", abl, ms * 1e3, fl / ms / 1e9);
+      }
+      // x16 vs big: same products, different summation order inside a K-step -> compare numerically
+      const size_t n_out = (size_t)M * s.N;
+      const size_t bytes = n_out * (s.f32out ? 4 : 2);
+      std::vector<char> y1(bytes), y2(bytes);
+      CK(hipMemset(Y, 0, bytes)); run(0); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(y1.data(), Y, bytes, hipMemcpyDeviceToHost));
+      CK(hipMemset(Y, 0, bytes)); runx(0); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(y2.data(), Y, bytes, hipMemcpyDeviceToHost));
+      double maxd = 0, maxv = 0;
+      for (size_t i = 0; i < n_out; i += 7) {
+        float a_ = s.f32out ? ((float*)y1.data())[i] : (float)((bf16_t*)y1.data())[i];
+        float b_ = s.f32out ? ((float*)y2.data())[i] : (float)((bf16_t*)y2.data())[i];
+        maxd = fmax(maxd, fabs((double)a_ - b_)); maxv = fmax(maxv, fabs((double)a_));
+      }
+      printf("  | x16 vs big: max|d| %.3g of %.3g", maxd, maxv);
     }
     // v1 128x128
     {
