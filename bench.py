@@ -190,13 +190,17 @@ def main():
     news = float(sum(b.n_hist + b.n_cand for b in timed))
     tokens = float(sum(b.tokens for b in timed))
     enc_flops = float(sum(cfg.flops_per_news(int(l)) for b in timed for l in b.lens))
-    stats = torch.tensor([elapsed, cands, news, tokens, enc_flops], dtype=torch.float64, device=dev)
+    h_, i_ = cfg.hidden, cfg.intermediate
+    per_layer = lambda l: 8 * l * h_ * h_ + 4 * l * h_ * i_ + 4 * l * l * h_      # noqa: E731
+    exec_flops = float(sum((cfg.layers - 1) * per_layer(int(l)) + 4 * int(l) * h_ * h_ + 4 * int(l) * h_
+                           + 4 * h_ * h_ + 4 * h_ * i_ for b in timed for l in b.lens))
+    stats = torch.tensor([elapsed, cands, news, tokens, enc_flops, exec_flops], dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone()
         torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
         stats[0] = mx[0]
-    elapsed_max, cands_all, news_all, tokens_all, flops_all = stats.tolist()
+    elapsed_max, cands_all, news_all, tokens_all, flops_all, exec_all = stats.tolist()
 
     result = None
     if rank == 0:
@@ -211,8 +215,12 @@ def main():
                        "impressions_per_step_per_gpu": args.impressions, "length_profile": args.profile,
                        "seeded_weights_std": args.std, "parallelism": f"dp{world} (impressions sharded, no collective)"},
             "news_encoded_per_s": news_all / elapsed_max, "tokens_per_s": tokens_all / elapsed_max,
-            "encoder_mfma_frac": flops_all / elapsed_max / 1e12 / (peak * world),
-            "encoder_tflops": flops_all / elapsed_max / 1e12,
+            # algorithmic = SURVEY.md §8d F(L) for every news (what the reference computes); executed
+            # excludes the last layer's non-[CLS] rows, which the HIP path prunes (not credited as
+            # utilisation): last layer costs 4LH^2 (K,V) instead of 8LH^2 + 4LHI + 4L^2 H
+            "encoder_tflops_algorithmic": flops_all / elapsed_max / 1e12,
+            "encoder_tflops": exec_all / elapsed_max / 1e12,
+            "encoder_mfma_frac": exec_all / elapsed_max / 1e12 / (peak * world),
             "ndcg10_last_step": float(last[2].double().mean().item()),
         }
 
@@ -227,6 +235,11 @@ def main():
         tok_local = float(sum(b.tokens for b in timed))
         h, i = cfg.hidden, cfg.intermediate
         shape = {"gemm_qkv": (3 * h, h), "gemm_out": (h, h), "gemm_ffn1": (i, h), "gemm_ffn2": (h, i)}
+        nl = cfg.layers
+        # launches per class per chunk: QKV runs in every layer (the last one as the K|V-only GEMM,
+        # N = 2H); out-proj / FFN on all tokens only in the first layers-1 layers
+        nk_total = {"gemm_qkv": (3 * h * (nl - 1) + 2 * h) * h, "gemm_out": h * h * (nl - 1),
+                    "gemm_ffn1": i * h * (nl - 1), "gemm_ffn2": h * i * (nl - 1)}
         kern = {}
         for cls, (ms, cnt) in prof.items():
             if cnt == 0:
@@ -234,7 +247,7 @@ def main():
             ent = {"ms_total": ms, "launches": cnt, "avg_us": 1e3 * ms / cnt}
             if cls in shape:
                 n_, k_ = shape[cls]
-                fl = 2.0 * n_ * k_ * tok_local * cfg.layers / cnt          # algorithmic FLOPs per launch
+                fl = 2.0 * nk_total[cls] * tok_local / cnt                 # algorithmic FLOPs per launch (average)
                 ent["flops_per_launch"] = fl
                 ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
             kern[cls] = ent

@@ -126,7 +126,8 @@ int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stre
 enum {
   MANNER_HIP_PROF_LENGTHS = 0, MANNER_HIP_PROF_EMBED, MANNER_HIP_PROF_GEMM_QKV, MANNER_HIP_PROF_ATTENTION,
   MANNER_HIP_PROF_GEMM_OUT, MANNER_HIP_PROF_LAYERNORM, MANNER_HIP_PROF_GEMM_FFN1, MANNER_HIP_PROF_GEMM_FFN2,
-  MANNER_HIP_PROF_GATHER, MANNER_HIP_PROF_COUNT
+  MANNER_HIP_PROF_GATHER, MANNER_HIP_PROF_CLS_TAIL /* last layer's [CLS]-row-only launches */,
+  MANNER_HIP_PROF_COUNT
 };
 int manner_hip_encoder_profile(manner_hip_encoder_t enc, int32_t enable);
 int manner_hip_encoder_profile_read(manner_hip_encoder_t enc, manner_hip_stream_t stream, double* ms /*host*/,

@@ -18,7 +18,7 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
 W_EMB_COUNT, WL_COUNT = 5, 16
 MAX_LEN = 128
 PROF_CLASSES = ["lengths", "embed_ln", "gemm_qkv", "attention", "gemm_out", "layernorm", "gemm_ffn1", "gemm_ffn2",
-                "gather_cls"]
+                "gather_cls", "cls_tail"]
 
 
 class EncoderConfigC(C.Structure):

@@ -198,7 +198,112 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
     *reinterpret_cast<f32x4*>(dst + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
 }
 
+// ---- last layer: one query ([CLS]) per news.  One wave per (news, head); lane (g = lane>>3,
+// c = lane&7) walks key rows g, g+8, ... and owns the 8 head dims 8c..8c+7 of each, so every load
+// instruction fetches 8 whole 128-byte K (or V) rows.  f32 arithmetic in both precisions.
+template <typename T> struct Row8;
+template <> struct Row8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float v[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float v[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+template <> struct Row8<float> {
+  static __device__ __forceinline__ void load(const float* p, float v[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float v[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ qcls, const T* __restrict__ kv,
+                                                       T* __restrict__ ctx, const int32_t* __restrict__ cu,
+                                                       int64_t n_pairs, int heads, int H) {
+  const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x & 63, g = lane >> 3, c = lane & 7;
+  const int n = (int)(pair / heads), head = (int)(pair - (int64_t)n * heads);
+  const int tok0 = cu[n], L = cu[n + 1] - tok0;
+  const size_t ld = 2 * (size_t)H;
+  const T* Kb = kv + (size_t)tok0 * ld + head * 64 + 8 * c;
+  const T* Vb = Kb + H;
+  float q[8];
+  Row8<T>::load(qcls + (size_t)n * H + head * 64 + 8 * c, q);
+  constexpr int MAXR = MANNER_HIP_MAX_LEN / 8;       // 16 key rows per lane group
+  float sc[MAXR];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int key = 8 * r + g;
+    float s = -INFINITY;
+    if (8 * r < L) {                                  // wave-uniform
+      float kr[8];
+      Row8<T>::load(Kb + (size_t)min(key, L - 1) * ld, kr);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d = fmaf(q[e], kr[e], d);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      s = key < L ? d * 0.125f : -INFINITY;
+    }
+    sc[r] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    if (8 * r < L) {
+      const int key = 8 * r + g;
+      const float p = expf(sc[r] - mx);               // 0 for masked keys
+      sum += p;
+      float vr[8];
+      Row8<T>::load(Vb + (size_t)min(key, L - 1) * ld, vr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vr[e], o[e]);
+    }
+  }
+  // every lane of a row group carries the same p: sum over groups only (xor 8, 16, 32)
+  sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o[e] += __shfl_xor(o[e], 8, 64); o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64);
+  }
+  if (g == 0) {
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= inv;
+    Row8<T>::store(ctx + (size_t)n * H + head * 64 + 8 * c, o);
+  }
+}
+
 }  // namespace
+
+int attention_cls(DType dt, const void* qcls, const void* kv, void* ctx_cls, const int32_t* cu, int64_t n_news, int heads,
+                  int H, hipStream_t stream) {
+  if (H != heads * 64) return fail(MANNER_HIP_E_INVALID, "head_dim must be 64 (H=%d heads=%d)", H, heads);
+  const int64_t pairs = n_news * heads;
+  dim3 g((unsigned)((pairs + 3) / 4)), b(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(attn_cls_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(qcls), static_cast<const bf16_t*>(kv),
+                       static_cast<bf16_t*>(ctx_cls), cu, pairs, heads, H);
+  else
+    hipLaunchKernelGGL(attn_cls_kernel<float>, g, b, 0, stream, static_cast<const float*>(qcls), static_cast<const float*>(kv),
+                       static_cast<float*>(ctx_cls), cu, pairs, heads, H);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
 
 int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, int64_t n_news, int heads, int H,
                      int max_len, hipStream_t stream) {

@@ -51,7 +51,7 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens,
-                        int32_t* cu /*[n_news+1]*/, int32_t* m_total, int32_t* status, hipStream_t stream);
+                        int32_t* cu /*[n_news+1]*/, int32_t* m_total /*[2]: tokens, news*/, int32_t* status, hipStream_t stream);
 int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu,
                     const float* word, const float* pos, const float* type0, const float* gamma,
                     const float* beta, int H, float eps, int pos_offset, int vocab, int max_pos,
@@ -59,11 +59,17 @@ int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padde
 int layernorm_rows(DType out, const float* pre, const float* gamma, const float* beta, int H, float eps,
                    void* x, int64_t m_bound, const int* m_total, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
+int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);
 int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 // ctx[tok, head*64 + d] = softmax_k(q.k/8) v over the tokens of the same news; qkv [m, 3H] = [Q|K|V].
 int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, int64_t n_news, int heads,
                      int H, int max_len, hipStream_t stream);
+
+// last layer: only the [CLS] query of every news attends.  qcls [n_news, H]; kv [m, 2H] = [K|V];
+// ctx_cls [n_news, H].
+int attention_cls(DType dt, const void* qcls, const void* kv, void* ctx_cls, const int32_t* cu, int64_t n_news,
+                  int heads, int H, hipStream_t stream);
 
 }  // namespace manner

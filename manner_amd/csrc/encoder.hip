@@ -106,9 +106,10 @@ struct ProfScope {
 };
 
 struct Workspace {
-  int32_t *lens, *cu, *m_total;
+  int32_t *lens, *cu, *m_total;      // m_total[0] = packed tokens, m_total[1] = news of the chunk
   float* pre;
   void *x, *qkv, *ctx, *ffn;
+  void *xcls, *qcls;                 // compact [CLS] rows of the last layer
 };
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
@@ -125,6 +126,9 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   p = take((size_t)m_cap * 3 * H * es); if (ws) ws->qkv = p;
   p = take((size_t)m_cap * H * es); if (ws) ws->ctx = p;
   p = take((size_t)m_cap * I * es); if (ws) ws->ffn = p;
+  const size_t n_pad = (size_t)round_up(max_news, 256);
+  p = take(n_pad * H * es); if (ws) ws->xcls = p;
+  p = take(n_pad * H * es); if (ws) ws->qcls = p;
   return off;
 }
 
@@ -145,10 +149,11 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
                               pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
       return rc;
   }
-  for (int l = 0; l < c.layers; ++l) {
+#define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
+  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  for (int l = 0; l + 1 < c.layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
-#define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
     PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))
@@ -157,8 +162,27 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
   }
-  ProfScope ps(e, s, MANNER_HIP_PROF_GATHER);
-  return gather_cls(dt, ws.x, ws.cu, n_news, H, out, s);
+  // Last layer: the reference keeps only last_hidden_state[:, 0, :] (news_encoder.py:30-34), so K and V
+  // are needed for every token but Q, the output projection, both LayerNorms and the FFN only for the
+  // [CLS] row of each news.  Those run on compact [n_news, *] buffers; the final LayerNorm writes the
+  // f32 result straight into `out`.
+  {
+    const LayerWeights& w = e->w[prec][c.layers - 1];
+    const LayerParams& p = e->params[c.layers - 1];
+    const int64_t n_bound = round_up(n_news, 256);
+    const int32_t* n_total = ws.m_total + 1;
+    const char* wkv = static_cast<const char*>(w.wqkv) + (size_t)H * H * es;
+    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_rows(dt, ws.x, ws.cu, n_news, H, ws.xcls, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, out, n_bound, n_total, s))
+  }
+  return MANNER_HIP_OK;
 }
 
 }  // namespace

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
   }
   int run = part[t] - s;
   for (int64_t i = lo; i < hi; ++i) { cu[i] = run; run += lens[i]; }
-  if (t == 1023) { cu[n] = part[1023]; *m_total = part[1023]; }
+  if (t == 1023) { cu[n] = part[1023]; m_total[0] = part[1023]; m_total[1] = (int32_t)n; }
 }
 
 template <typename TOut>
@@ -172,6 +172,16 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const TIn* __restrict__
   for (int c = threadIdx.x; c < H; c += 256) out[n * H + c] = (float)src[c];
 }
 
+// compact copy of the [CLS] rows, same dtype: dst[n] = x[cu[n]]
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ cu,
+                                                          int H, T* __restrict__ dst) {
+  const int64_t n = blockIdx.x;
+  const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)cu[n] * H);
+  f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)n * H);
+  for (int c = threadIdx.x; c < H * (int)sizeof(T) / 16; c += 256) d[c] = src[c];
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)src[i];
@@ -223,6 +233,16 @@ int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H
     hipLaunchKernelGGL(gather_cls_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(x), cu, n_news, H, out);
   else
     hipLaunchKernelGGL(gather_cls_kernel<float>, g, b, 0, stream, static_cast<const float*>(x), cu, n_news, H, out);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream) {
+  dim3 g((unsigned)n_news), b(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(x), cu, H, static_cast<bf16_t*>(dst));
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<float>, g, b, 0, stream, static_cast<const float*>(x), cu, H, static_cast<float*>(dst));
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
