@@ -660,48 +660,59 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         acc[a][4 * half + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[bb], acc[a][4 * half + bb], 0, 0, 0);
   };
 
-  auto kstep = [&](int cur, int k1, auto next_tag) {
-    constexpr bool NEXT = decltype(next_tag)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  // K-step k on stage `cur`, rotated so that the only barrier sits between chunks 2 and 3:
+  //   entry : fragments of chunk 0 in (w0, xa); pieces 0-3 of DMA(k+1) already issued into cur^1
+  //   c0    : read chunk 1; issue pieces 4-7 of DMA(k+1);            16 MFMAs
+  //   c1,c2 : read chunks 2, 3;                                      16 MFMAs each
+  //   sync  : lgkmcnt(0) (every read of `cur` has completed), vmcnt(0) (own DMA(k+1) landed), s_barrier
+  //   c3    : read chunk 0 of K-step k+1 from cur^1; issue pieces 0-3 of DMA(k+2) into `cur`; 16 MFMAs
+  // The LDS-read latency and the barrier skew that used to open every K-step (a third of the wave
+  // time in SQ_WAIT_ANY) now sit in the shadow of chunk 2 / chunk 3 MFMAs.
+  bf16x8 w0[4], w1[4], xa[4], xb[4];
+  auto kstep = [&](int cur, int k1, int k2, auto has1_tag, auto has2_tag) {
+    constexpr bool HAS1 = decltype(has1_tag)::value, HAS2 = decltype(has2_tag)::value;
     const char* base = lds + cur * G_STAGE_BYTES;
-    bf16x8 w0[4], w1[4], xa[4], xb[4];
-    read_w(base, 0, w0);
-    read_x(base, 0, 0, xa);
-    // chunk (s=0, half 0)
+    const char* nxt = lds + (cur ^ 1) * G_STAGE_BYTES;
     read_x(base, 0, 1, xb);
-    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 0);
+    if (HAS1 && ABL != 2) { issue2(cur ^ 1, k1, 2); issue2(cur ^ 1, k1, 3); }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // chunk (0, 1)
     read_w(base, 1, w1);
     read_x(base, 1, 0, xa);
-    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 1);
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    // chunk (1, 0)
     read_x(base, 1, 1, xb);
-    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 2);
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // chunk (1, 1)
-    if (NEXT && ABL != 2) issue2(cur ^ 1, k1, 3);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS1) { read_w(nxt, 0, w0); read_x(nxt, 0, 0, xa); }
+    if (HAS2 && ABL != 2) { issue2(cur, k2, 0); issue2(cur, k2, 1); }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xb, 1);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   const int nk = K / BK;
 #pragma unroll
   for (int pair = 0; pair < 4; ++pair) issue2(0, 0, pair);
-  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, std::true_type{});
-  kstep((nk - 1) & 1, 0, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_w(lds, 0, w0);
+  read_x(lds, 0, 0, xa);
+  if (nk > 1) { issue2(1, BK, 0); issue2(1, BK, 1); }
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, (kt + 2) * BK, std::true_type{}, std::true_type{});
+  if (nk > 1) { kstep(kt & 1, (kt + 1) * BK, 0, std::true_type{}, std::false_type{}); ++kt; }
+  kstep(kt & 1, 0, 0, std::false_type{}, std::false_type{});
 
   // ---- epilogue: 32-token x 64-feature slabs through a wave-private swizzled LDS slab, whole-row
   // 16-byte stores / residual loads (see gemm_tn_big_kernel).
-  __builtin_amdgcn_s_barrier();
+  // (after the last K-step's barrier nobody reads the stages and no DMA is outstanding)
   constexpr int OUT_ROW = 64 * sizeof(TOut);
   constexpr int CHUNKS = OUT_ROW / 16;
   constexpr int OPC = 16 / sizeof(TOut);
