@@ -584,14 +584,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // bf16 production kernel: the 256x256 / 8-wave / 2-stage structure of gemm_tn_big_kernel on
-// v_mfma_f32_16x16x32_bf16.  Measured on MI355X with random operands, a register-only MFMA loop
-// sustains 2.04 PFLOP/s with the 16x16x32 shape against 1.68-1.77 with 32x32x16 (the chip holds a
-// higher clock on it — cdna_hip_programming.md rule 28), so the same tile is built on the smaller
-// shape.  Wave tile 128(m) x 64(n) = 8 x 4 MFMA tiles, acc[a][b] = D[n = 16a + 4(l>>4) + reg]
-// [m = 16b + (l&15)]: a lane still owns one token and runs of 4 consecutive features.
-// A K-step (64 bf16) is two k32 steps x two m-halves = 4 chunks of 16 MFMAs; the weight fragments
-// of a k32 step (4) and the activation fragments of a chunk (4) are double-buffered in registers and
-// read one chunk ahead, with two DMA pieces of the next K-step issued per chunk.
+// v_mfma_f32_16x16x32_bf16, PERSISTENT over tiles.
+//  * MFMA shape: on MI355X with random operands a register-only MFMA loop sustains 2.04 PFLOP/s with
+//    16x16x32 against 1.68-1.77 with 32x32x16 (the chip holds a higher clock on it —
+//    cdna_hip_programming.md rule 28).  Wave tile 128(m) x 64(n) = 8 x 4 MFMA tiles,
+//    acc[a][b] = D[n = 16a + 4(l>>4) + reg][m = 16b + (l&15)]: a lane still owns one token and runs
+//    of 4 consecutive features.
+//  * K-step (64 bf16) = two k32 steps x two m-halves = 4 chunks of 16 MFMAs; weight fragments of a
+//    k32 step (4) and activation fragments of a chunk (4) are double-buffered in registers and read
+//    one chunk ahead.  The step is rotated so its only barrier sits between chunks 2 and 3:
+//      entry : fragments of chunk 0 in (w0, xa); pieces 0-3 of DMA(k+1) already issued into cur^1
+//      c0    : read chunk 1; issue pieces 4-7 of DMA(k+1);            16 MFMAs
+//      c1,c2 : read chunks 2, 3;                                      16 MFMAs each
+//      sync  : lgkmcnt(0) (every read of `cur` completed), vmcnt(0) (own DMA(k+1) landed), s_barrier
+//      c3    : read chunk 0 of step k+1 from cur^1; issue pieces 0-3 of DMA(k+2) into `cur`; 16 MFMAs
+//  * Persistent: gridDim.x = #CUs workgroups walk the tiles (round r, XCD-remapped slot).  In the
+//    LAST K-step of a tile the idle stage receives K-step 0 of the workgroup's NEXT tile, so the
+//    ~3 us DMA latency that used to open every tile is covered by the epilogue.  The epilogue slabs
+//    live in the stage the last K-step just finished with; the next tile's first barrier separates
+//    them from its DMA(1), and
+//    the next tile starts with a COUNTED vmcnt that leaves exactly the epilogue's stores in flight.
 template <typename TOut, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -601,57 +613,57 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   constexpr int EPC = 8, BK = 64;
   __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
 
-  const int nwg = gridDim.x, b = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
+  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   const int M = *m_total;
-  if (mt * G_BM >= M) return;
+  const int valid_tiles = ((M + G_BM - 1) / G_BM) * n_tiles;
+  int t = slot;
+  if (t >= valid_tiles) return;
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int wn = wave & 3, wm = wave >> 2;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int kl15 = lane & 15, klq = lane >> 4;        // K-loop copies (the epilogue recomputes its own)
+  const int kwn = wave & 3, kwm = wave >> 2;
 
+  // DMA: waves 0-3 bring the weight tile, 4-7 the activation tile, 8 pieces (64 rows) each
   const bool is_w = wave < 4;
   const int prow0 = 64 * (wave & 3);
-  const TIn* gbase = is_w ? W + (size_t)(nt * G_BN + prow0) * K : X + (size_t)(mt * G_BM + prow0) * K;
   const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
   const int lrow = lane >> 3;
   int voff[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par)
     voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
-  auto issue2 = [&](int buf, int k0, int pair) {
+  auto tile_src = [&](int tile) -> const TIn* {
+    const int mt_ = tile / n_tiles, nt_ = tile - mt_ * n_tiles;
+    return is_w ? W + (size_t)(nt_ * G_BN + prow0) * K : X + (size_t)(mt_ * G_BM + prow0) * K;
+  };
+  auto issue2 = [&](int buf, const TIn* gsrc, int k0, int pair) {
     char* base = lds + buf * G_STAGE_BYTES + ldst0;
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int i = 2 * pair + par;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gbase + (size_t)(8 * i) * K + k0 + voff[par]),
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]),
                                        LDS_PTR(base + i * 1024), 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment of k32 step s, 16-row block: lane reads row 16*blk + l15, 16-byte chunk 4s + lq
-  const int swz = (l15 >> 1) & 7;
-  const int woff = (wn * 64 + l15) * ROW_BYTES;
-  const int xoff = G_OP_BYTES + (wm * 128 + l15) * ROW_BYTES;
+  const int swz = (kl15 >> 1) & 7;
+  const int woff = (kwn * 64 + kl15) * ROW_BYTES;
+  const int xoff = G_OP_BYTES + (kwm * 128 + kl15) * ROW_BYTES;
   auto read_w = [&](const char* base, int s2, bf16x8 (&wf)[4]) {
-    const int coff = ((4 * s2 + lq) ^ swz) << 4;
+    const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(base + woff + a * 16 * ROW_BYTES + coff);
   };
   auto read_x = [&](const char* base, int s2, int half, bf16x8 (&xf)[4]) {
-    const int coff = ((4 * s2 + lq) ^ swz) << 4;
+    const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
       xf[bb] = *reinterpret_cast<const bf16x8*>(base + xoff + (4 * half + bb) * 16 * ROW_BYTES + coff);
   };
+
+  f32x4 acc[4][8];
   auto mma16 = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4], int half) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
@@ -660,21 +672,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         acc[a][4 * half + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[bb], acc[a][4 * half + bb], 0, 0, 0);
   };
 
-  // K-step k on stage `cur`, rotated so that the only barrier sits between chunks 2 and 3:
-  //   entry : fragments of chunk 0 in (w0, xa); pieces 0-3 of DMA(k+1) already issued into cur^1
-  //   c0    : read chunk 1; issue pieces 4-7 of DMA(k+1);            16 MFMAs
-  //   c1,c2 : read chunks 2, 3;                                      16 MFMAs each
-  //   sync  : lgkmcnt(0) (every read of `cur` has completed), vmcnt(0) (own DMA(k+1) landed), s_barrier
-  //   c3    : read chunk 0 of K-step k+1 from cur^1; issue pieces 0-3 of DMA(k+2) into `cur`; 16 MFMAs
-  // The LDS-read latency and the barrier skew that used to open every K-step (a third of the wave
-  // time in SQ_WAIT_ANY) now sit in the shadow of chunk 2 / chunk 3 MFMAs.
   bf16x8 w0[4], w1[4], xa[4], xb[4];
-  auto kstep = [&](int cur, int k1, int k2, auto has1_tag, auto has2_tag) {
-    constexpr bool HAS1 = decltype(has1_tag)::value, HAS2 = decltype(has2_tag)::value;
+  // MODE 0: steady state (DMA(k+1) tail + DMA(k+2) head); 1: second-to-last (DMA(k+1) tail only);
+  // 2: last K-step of the tile (prefetch K-step 0 of the next tile into the idle stage, if any)
+  auto kstep = [&](int cur, const TIn* gsrc, int k1, int k2, const TIn* gnext, bool has_next, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
     const char* base = lds + cur * G_STAGE_BYTES;
     const char* nxt = lds + (cur ^ 1) * G_STAGE_BYTES;
     read_x(base, 0, 1, xb);
-    if (HAS1 && ABL != 2) { issue2(cur ^ 1, k1, 2); issue2(cur ^ 1, k1, 3); }
+    if (ABL != 2) {
+      if (MODE <= 1) { issue2(cur ^ 1, gsrc, k1, 2); issue2(cur ^ 1, gsrc, k1, 3); }
+      else if (has_next) { issue2(cur ^ 1, gnext, 0, 0); issue2(cur ^ 1, gnext, 0, 1); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -687,88 +696,130 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (MODE <= 1) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of THIS tile is in flight any more
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS1) { read_w(nxt, 0, w0); read_x(nxt, 0, 0, xa); }
-    if (HAS2 && ABL != 2) { issue2(cur, k2, 0); issue2(cur, k2, 1); }
+    if (MODE <= 1) { read_w(nxt, 0, w0); read_x(nxt, 0, 0, xa); }
+    if (ABL != 2) {
+      if (MODE == 0) { issue2(cur, gsrc, k2, 0); issue2(cur, gsrc, k2, 1); }
+      else if (MODE == 2 && has_next) { issue2(cur ^ 1, gnext, 0, 2); issue2(cur ^ 1, gnext, 0, 3); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
   };
+  typedef std::integral_constant<int, 0> Mode0;
+  typedef std::integral_constant<int, 1> Mode1;
+  typedef std::integral_constant<int, 2> Mode2;
 
-  const int nk = K / BK;
-#pragma unroll
-  for (int pair = 0; pair < 4; ++pair) issue2(0, 0, pair);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  read_w(lds, 0, w0);
-  read_x(lds, 0, 0, xa);
-  if (nk > 1) { issue2(1, BK, 0); issue2(1, BK, 1); }
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, (kt + 2) * BK, std::true_type{}, std::true_type{});
-  if (nk > 1) { kstep(kt & 1, (kt + 1) * BK, 0, std::true_type{}, std::false_type{}); ++kt; }
-  kstep(kt & 1, 0, 0, std::false_type{}, std::false_type{});
-
-  // ---- epilogue: 32-token x 64-feature slabs through a wave-private swizzled LDS slab, whole-row
-  // 16-byte stores / residual loads (see gemm_tn_big_kernel).
-  // (after the last K-step's barrier nobody reads the stages and no DMA is outstanding)
   constexpr int OUT_ROW = 64 * sizeof(TOut);
   constexpr int CHUNKS = OUT_ROW / 16;
   constexpr int OPC = 16 / sizeof(TOut);
-  char* slab = lds + wave * (32 * OUT_ROW);
-  const int nbase = nt * G_BN + wn * 64;
-  f32x4 bv[4];
+  constexpr int ROWS_PER_INST = 64 / CHUNKS;
+  constexpr int NQ = 32 / ROWS_PER_INST;
+  const int nk = K / BK;
+
+  const TIn* gsrc = tile_src(t);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+  for (int pair = 0; pair < 4; ++pair) issue2(0, gsrc, 0, pair);
+  int buf = 0;                       // stage that holds K-step 0 of the current tile
+  bool first = true;
+  while (true) {
+    const int mt = t / n_tiles, nt = t - mt * n_tiles;
+    const int tn = t + G;
+    const bool has_next = tn < valid_tiles;
+    const TIn* gnext = tile_src(has_next ? tn : t);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-      const int row = 16 * b2 + l15;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int nl = 16 * a + 4 * lq;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][2 * j + b2][e] + bv[a][e];
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-        }
-        const int c = nl / OPC;
-        const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
-        store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
-      }
+      for (int bb = 0; bb < 8; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tile prologue: K-step 0 has landed (issued one epilogue ago; the previous tile's stores may fly on)
+    if (first || ABL == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (sizeof(TOut) == 2) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // residual variant: the last slab's 8 stores
     }
-    __builtin_amdgcn_wave_barrier();
-    constexpr int ROWS_PER_INST = 64 / CHUNKS;
-    constexpr int NQ = 32 / ROWS_PER_INST;
-    const int row0 = lane / CHUNKS, sl = lane % CHUNKS;
-    float res[EPI == EPI_BIAS_RES ? NQ : 1][4];
-    if (EPI == EPI_BIAS_RES && ABL != 1) {
+    first = false;
+    __builtin_amdgcn_s_barrier();    // also: every wave has left the previous epilogue's LDS slabs
+    read_w(lds + buf * G_STAGE_BYTES, 0, w0);
+    read_x(lds + buf * G_STAGE_BYTES, 0, 0, xa);
+    if (nk > 1 && ABL != 2) { issue2(buf ^ 1, gsrc, BK, 0); issue2(buf ^ 1, gsrc, BK, 1); }
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, (kt + 2) * BK, gnext, has_next, Mode0{});
+    if (nk > 1) { kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, 0, gnext, has_next, Mode1{}); ++kt; }
+    const int last = (buf + kt) & 1;
+    kstep(last, gsrc, 0, 0, gnext, has_next, Mode2{});
+
+    // ---- epilogue: 32-token x 64-feature slabs through a wave-private XOR-swizzled LDS slab inside
+    // stage `last` (free since the last barrier), whole-row 16-byte stores.
+    // The epilogue's lane-constant addressing is recomputed per tile from an opaque copy of the lane
+    // id: hoisted out of the tile loop it would stay live across the K-loop and spill (the K-loop
+    // already uses ~240 of the 256 registers).
+    int el = lane, ew = wave;
+    asm volatile("" : "+v"(el), "+s"(ew));
+    const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
+    char* slab = lds + last * G_STAGE_BYTES + ew * (32 * OUT_ROW);
+    const int nbase = nt * G_BN + wn * 64;
+    const int row0 = el / CHUNKS, sl = el % CHUNKS;
+    f32x4 bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int row = 16 * b2 + l15;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int nl = 16 * a + 4 * lq;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[a][2 * j + b2][e] + bv[a][e];
+          if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+          }
+          const int c = nl / OPC;
+          const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
+          store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      bf16x4 res[EPI == EPI_BIAS_RES ? NQ : 1];
+      if (EPI == EPI_BIAS_RES && ABL != 1) {          // TOut == float: the slab's residual loads in one batch
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int row = q * ROWS_PER_INST + row0;
+          const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
+          res[q] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int row = q * ROWS_PER_INST + row0;
-        const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
-        load4<TIn>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC, res[q]);
-      }
-    }
+        const int c = sl ^ (row & (CHUNKS - 1));
+        const int m = mt * G_BM + wm * 128 + 32 * j + row;
+        f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+        if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+        if (EPI == EPI_BIAS_RES) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int row = q * ROWS_PER_INST + row0;
-      const int c = sl ^ (row & (CHUNKS - 1));
-      const int m = mt * G_BM + wm * 128 + 32 * j + row;
-      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
-      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
-      if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) raw[e] += res[q][e];
+          for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
+        }
+        if (m < M)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
       }
-      if (m < M)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
+    if (!has_next) break;
+    t = tn;
+    gsrc = gnext;
+    buf = last ^ 1;
   }
 }
 
@@ -776,9 +827,16 @@ template <typename TOut>
 int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
   const int n_tiles = N / G_BN;
-  const int64_t grid = (m_bound / G_BM) * n_tiles;
-  if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
-  dim3 g((unsigned)grid), b(512);
+  const int64_t tiles = (m_bound / G_BM) * n_tiles;
+  if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
+  static int n_cus = 0;                 // persistent grid: one workgroup per CU (128 KiB LDS each)
+  if (!n_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MANNER_HIP_E_RUNTIME, "hipGetDeviceProperties failed");
+    n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* w = static_cast<const bf16_t*>(W);
   const bf16_t* r = static_cast<const bf16_t*>(R);

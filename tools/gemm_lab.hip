@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
     }
     {
       auto runx = [&](int abl) {
-#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), g, b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
+#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), dim3(g.x < 256 ? g.x : 256), b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
 #define BY_ABLX(TO, EPI) switch (abl) { case 0: LAUNCHX(TO, EPI, 0); break; case 1: LAUNCHX(TO, EPI, 1); break; case 2: LAUNCHX(TO, EPI, 2); break; }
         if (s.epi == EPI_BIAS) { BY_ABLX(bf16_t, EPI_BIAS) }
         else if (s.epi == EPI_BIAS_GELU) { BY_ABLX(bf16_t, EPI_BIAS_GELU) }
