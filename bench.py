@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
+    p.add_argument("--no-table", action="store_true", help="skip the table-mode (encode pool once + all-gather) leg")
     return p.parse_args()
 
 
@@ -132,6 +133,56 @@ def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev):
     return cpu, par
 
 
+def table_mode(args, cfg, enc, pool, rank, world, dev):
+    """Mode T: every rank encodes its FLOP-balanced shard of the unique-news pool once,
+    one RCCL all-gather assembles the [N_news, D] table on every rank, then each rank scores its block of
+    MIND-small-shaped impressions (73 152 in total) by index.  Reported beside the headline, never as it."""
+    from manner_amd import distributed as D
+    pool_ids, pool_mask, pool_len = pool
+    n_news = pool_ids.shape[0]
+    shards = D.balanced_news_shards(pool_len, world, cfg.flops_per_news)
+    lo, hi = shards[rank]
+    imp = synth_impressions(MIND_SMALL["n_impressions"], n_news, seed=43)
+    a, b = shard_range(MIND_SMALL["n_impressions"], rank, world)
+    ho, co = imp["hist_off"], imp["cand_off"]
+    dimp = {"hist_idx": torch.from_numpy(imp["hist_idx"][ho[a]:ho[b]]).to(dev), "hist_off": torch.from_numpy(ho[a:b + 1] - ho[a]).to(dev),
+            "cand_idx": torch.from_numpy(imp["cand_idx"][co[a]:co[b]]).to(dev), "cand_off": torch.from_numpy(co[a:b + 1] - co[a]).to(dev)}
+    labels = torch.from_numpy(imp["labels"][co[a]:co[b]]).to(dev)
+    local = torch.empty((hi - lo, cfg.hidden), dtype=torch.float32, device=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    times = {}
+    for it in range(2):                                 # pass 0 warms up (workspace, RCCL channels)
+        sync(); t0 = time.perf_counter()
+        enc.encode_cls(pool_ids[lo:hi], pool_mask[lo:hi], precision=args.precision, host_lengths=pool_len[lo:hi],
+                       max_chunk_tokens=args.chunk_tokens, out=local)
+        sync(); t1 = time.perf_counter()
+        table = D.all_gather_table(local, shards)
+        sync(); t2 = time.perf_counter()
+        res = hotpath.score_impressions([table], dimp, labels=labels, k=10)
+        sync(); t3 = time.perf_counter()
+        times = {"encode_s": t1 - t0, "allgather_s": t2 - t1, "score_s": t3 - t2, "total_s": t3 - t0}
+    st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"]], dtype=torch.float64, device=dev)
+    nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
+        D.allreduce_metric_sums(nd)
+    enc_s, ag_s, sc_s, tot_s = st.tolist()
+    total_c = int(co[-1])
+    hbm_bytes = float(ho[-1] + co[-1]) * (cfg.hidden * 4 + 4) + float(co[-1]) * 4
+    return {"what": "unique-news table: encode shard -> all-gather -> score all 73152 MIND-small-shaped impressions",
+            "candidates_per_s": total_c / tot_s, "news_encoded_per_s": n_news / enc_s,
+            "scorer_pairs_per_s": total_c / sc_s, "scorer_GBps_algorithmic": hbm_bytes / sc_s / 1e9 / world,
+            "scorer_frac_of_8TBps": hbm_bytes / sc_s / 1e9 / world / HBM_PEAK_GBS,
+            "allgather_ms": 1e3 * ag_s, "allgather_bytes_per_rank": (n_news - (hi - lo)) * cfg.hidden * 4 if world > 1 else 0,
+            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item()}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -139,11 +190,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (see docstring)")
+    if os.environ.get("MANNER_BENCH_ONE_DEVICE"):      # rehearsal: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI ("nccl" is RCCL on ROCm); MANNER_DIST_BACKEND=gloo only to rehearse the
+        # multi-rank logic on a one-GPU box
+        backend = os.environ.get("MANNER_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = PRESETS[args.model]
     log("generating seeded weights")
@@ -252,13 +311,28 @@ def main():
                 ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
             kern[cls] = ent
         dom = max((c for c in kern if c in shape), key=lambda c: kern[c]["ms_total"])
+        # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # runs; bench.py cannot collect counters itself): profiles/r1_final/pmc_traffic.json
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_final", "pmc_traffic.json")
+        if os.path.exists(tpath) and args.chunk_tokens == 65536 and args.model == "bert-base-uncased":
+            with open(tpath) as f:
+                tj = json.load(f)
+            if dom in tj:
+                traffic = tj[dom]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r1_final/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, full 65536-token launch)"
         result["kernels"] = kern
         result["roofline"] = {
-            "kernel": dom + " (gemm_tn_kernel)", "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
-            "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": None,
+            "kernel": dom + " (gemm_tn_x16_kernel)", "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+            "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
+            "mfma_only_ceiling_tflops": 2040.0 if args.precision == "bf16" else None,
             "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops_per_launch"]}
     barrier()
 
+    if not args.no_table:
+        tab = table_mode(args, cfg, enc, (pool_ids, pool_mask, pool_len), rank, world, dev)
+        if rank == 0:
+            result["table_mode"] = tab
     if rank == 0 and world == 1 and not args.no_cpu:
         log("CPU baseline (oracle) + parity on the bounded sample")
         cpu, par = cpu_baseline_and_parity(args, cfg, weights, enc, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev)
