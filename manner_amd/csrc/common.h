@@ -38,7 +38,7 @@ int fail(int code, const char* fmt, ...);   // records the thread-local error te
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
-enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_RES_LN = 3 };
 enum DType { DT_F32 = 0, DT_BF16 = 1 };
 
 // Y[m, n] = epi( sum_k X[m, k] * W[n, k] + bias[n] )  for m < *m_total (device scalar).
@@ -48,6 +48,15 @@ enum DType { DT_F32 = 0, DT_BF16 = 1 };
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
             hipStream_t stream);
+
+// bf16 only: Y = LayerNorm(X W^T + bias + Y) * gamma + beta, in place on the residual stream Y [m_bound, N]
+// (K4 / K6 in one launch).  The N/256 column-tile workgroups of a 256-row panel exchange row sums
+// through `sync`: m_bound/256 arrival counters (zeroed here per call), then per row and column tile
+// one {sum, sum of squares} f32 slot (deterministic: summed in tile order, no float atomics).  N % 256 == 0.  `status` |= 4 if a bounded wait expires.
+size_t gemm_ln_sync_bytes(int64_t m_bound, int N);
+int gemm_tn_ln(const void* X, const void* W, const float* bias, void* Y, const float* gamma, const float* beta,
+               float eps, void* sync, int64_t m_bound, int N, int K, const int* m_total, int32_t* status,
+               hipStream_t stream);
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens,

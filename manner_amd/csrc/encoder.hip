@@ -51,11 +51,13 @@ struct manner_hip_encoder {
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
-  // HBM-bound phases of one chunk (epilogues, LayerNorm, attention) overlap the MFMA-bound phases
-  // of the other; MANNER_HIP_STREAMS=1 disables
-  int n_streams = 2;
+  // HBM-bound phases of one chunk overlap the MFMA-bound phases of the other.  Measured +2 % only (the
+  // two streams run the same kernels in lockstep), so it is opt-in: MANNER_HIP_STREAMS=2
+  int n_streams = 1;
+  bool fuse_ln = false;               // experimental, opt-in: MANNER_HIP_FUSE_LN=1
   hipStream_t side = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipEvent_t phase_ev = nullptr;     // recorded mid-layer in the first chunk: the side stream starts there
   // opt-in per-launch timing (manner_hip_encoder_profile)
   bool profiling = false;
   struct Span { hipEvent_t a, b; int cls; };
@@ -110,6 +112,7 @@ struct Workspace {
   float* pre;
   void *x, *qkv, *ctx, *ffn;
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
+  void* ln_sync;                     // row statistics + arrival counters of the fused GEMM+LayerNorm
 };
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
@@ -129,11 +132,13 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   const size_t n_pad = (size_t)round_up(max_news, 256);
   p = take(n_pad * H * es); if (ws) ws->xcls = p;
   p = take(n_pad * H * es); if (ws) ws->qcls = p;
+  p = take(gemm_ln_sync_bytes(m_cap, (int)H)); if (ws) ws->ln_sync = p;
   return off;
 }
 
 int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t lp,
-                 int64_t m_bound, int prec, float* out, const Workspace& ws, hipStream_t s) {
+                 int64_t m_bound, int prec, float* out, const Workspace& ws, hipStream_t s,
+                 hipEvent_t phase_mark = nullptr) {
   const manner_hip_encoder_config& c = e->cfg;
   const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
   const int H = c.hidden, I = c.intermediate;
@@ -151,13 +156,25 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
   }
 #define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
   const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  // The fused GEMM+LayerNorm kernel synchronises the column-tile workgroups of a panel; it needs the
+  // 256-wide tiling (H % 256 == 0) and is not run on two streams at once (two resident-grid kernels
+  // waiting on workgroups of each other could starve).  Measured +0..3 % only (a chain of dependent global
+  // round trips per tile idles the CU), so it stays opt-in: MANNER_HIP_FUSE_LN=1.
+  const bool fuse_ln = dt == DT_BF16 && H % 256 == 0 && e->fuse_ln && (e->profiling || e->n_streams == 1);
   for (int l = 0; l + 1 < c.layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
+    if (fuse_ln) {   // bf16: residual + LayerNorm inside the GEMM epilogue, in place on the residual stream x
+      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_ln(ws.ctx, w.wo, p.bo, ws.x, p.ln1g, p.ln1b, c.ln_eps, ws.ln_sync, m_bound, H, H, ws.m_total, e->status, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_ln(ws.ffn, w.w2, p.b2, ws.x, p.ln2g, p.ln2b, c.ln_eps, ws.ln_sync, m_bound, H, I, ws.m_total, e->status, s))
+      continue;
+    }
     PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
+    if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
@@ -221,6 +238,7 @@ int manner_hip_encoder_destroy(manner_hip_encoder_t enc) {
   if (enc->side) (void)hipStreamDestroy(enc->side);
   if (enc->fork_ev) (void)hipEventDestroy(enc->fork_ev);
   if (enc->join_ev) (void)hipEventDestroy(enc->join_ev);
+  if (enc->phase_ev) (void)hipEventDestroy(enc->phase_ev);
   for (void* p : enc->allocs) (void)hipFree(p);
   delete enc;
   return MANNER_HIP_OK;
@@ -255,10 +273,12 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     if (!guard(dev_alloc(e, 256, (void**)&e->status))) break;
     if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
     if (const char* ev = getenv("MANNER_HIP_STREAMS")) e->n_streams = atoi(ev) >= 2 ? 2 : 1;
+    if (const char* ev = getenv("MANNER_HIP_FUSE_LN")) e->fuse_ln = atoi(ev) != 0;
     if (e->n_streams == 2) {
       if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->phase_ev, hipEventDisableTiming) != hipSuccess) {
         rc = fail(MANNER_HIP_E_RUNTIME, "encoder_create: side stream/event creation failed");
         break;
       }
@@ -357,15 +377,17 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
     const int lane = ns == 2 ? (chunk & 1) : 0;
     hipStream_t s = s0;
     if (lane == 1) {
-      if (!forked) {                                   // side stream starts after the caller's prior work
-        MANNER_HIP_TRY(hipEventRecord(enc->fork_ev, s0));
-        MANNER_HIP_TRY(hipStreamWaitEvent(enc->side, enc->fork_ev, 0));
+      if (!forked) {
+        // the side stream starts when the first chunk on the caller's stream is half a layer in (its
+        // phase mark): from then on the two streams run out of phase, so the HBM-bound kernels of one
+        // (LayerNorm, attention, GEMM epilogues) meet the MFMA-bound main loops of the other
+        MANNER_HIP_TRY(hipStreamWaitEvent(enc->side, enc->phase_ev, 0));
         forked = true;
       }
       s = enc->side;
     }
     int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
-                          out + n0 * H, ws[lane], s);
+                          out + n0 * H, ws[lane], s, (ns == 2 && chunk == 0) ? enc->phase_ev : nullptr);
     if (rc) return rc;
     n0 += cnt;
     ++chunk;
@@ -386,6 +408,7 @@ int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stre
   MANNER_HIP_TRY(hipStreamSynchronize(s));
   if (flag & 1) return fail(MANNER_HIP_E_INPUT, "attention_mask is not a right-padded 0/1 prefix mask with 1..%d real tokens per news", MANNER_HIP_MAX_LEN);
   if (flag & 2) return fail(MANNER_HIP_E_INPUT, "input_ids or position index out of range of the embedding tables");
+  if (flag & 4) return fail(MANNER_HIP_E_RUNTIME, "fused GEMM+LayerNorm: a panel's column tiles did not arrive within the bounded wait");
   return MANNER_HIP_OK;
 }
 

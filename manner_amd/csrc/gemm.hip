@@ -604,11 +604,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(
 //    live in the stage the last K-step just finished with; the next tile's first barrier separates
 //    them from its DMA(1), and
 //    the next tile starts with a COUNTED vmcnt that leaves exactly the epilogue's stores in flight.
+struct LnFuse {                       // EPI_BIAS_RES_LN only
+  const float* gamma;
+  const float* beta;
+  unsigned long long* stats;          // [m_bound][N/256] per-tile {sum, sum of squares} packed as two f32
+  int* counters;                      // [m_bound / 256] arrivals of a panel's column tiles
+  int* status;
+  float eps;
+};
+
 template <typename TOut, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const bf16_t* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
-    int n_tiles) {
+    int n_tiles, LnFuse ln) {
   typedef bf16_t TIn;
   constexpr int EPC = 8, BK = 64;
   __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
@@ -740,6 +749,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     // tile prologue: K-step 0 has landed (issued one epilogue ago; the previous tile's stores may fly on)
     if (first || ABL == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (EPI == EPI_BIAS_RES_LN) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the fused-LN epilogue ends with 16 row stores
     } else if (sizeof(TOut) == 2) {
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
@@ -756,6 +767,135 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const int last = (buf + kt) & 1;
     kstep(last, gsrc, 0, 0, gnext, has_next, Mode2{});
 
+    if constexpr (EPI == EPI_BIAS_RES_LN) {
+      // ---- fused residual + LayerNorm epilogue (K4/K6 tails, modeling_bert.py:289-293, 347-351), all in
+      // the MFMA register layout (lane = token 16b + l15, features 16a + 4lq .. +3):
+      //   v = acc + bias + residual                      (in place in the accumulators)
+      //   row {sum, sum of squares} over the wave's 64 columns: in-lane + 2 shuffles, over the tile's
+      //   256 columns through LDS, written to this tile's slot stats[m][nt] with write-through stores
+      //   arrive on the panel counter, bounded wait for the panel's other column tiles (every
+      //   workgroup publishes BEFORE it waits and the persistent grid is resident: waits cannot cycle)
+      //   read all N/256 slots in fixed order (deterministic, unlike float atomics)
+      //   y = (v - mean) * rstd * gamma + beta -> bf16 slab -> whole 128-byte row segments.
+      int el = lane, ew = wave;
+      asm volatile("" : "+v"(el), "+s"(ew));
+      const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
+      char* stage = lds + last * G_STAGE_BYTES;
+      char* slab = stage + ew * 4096;                               // 32 rows x 64 bf16, XOR-swizzled chunks
+      float2* part = reinterpret_cast<float2*>(stage + 32768);      // [8 waves][128 rows] {s1, s2}
+      const int nbase = nt * G_BN + wn * 64;
+      const int mrow0 = mt * G_BM + wm * 128;
+      {
+        f32x4 bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+        // all 32 residual loads of the tile in flight before the first use (the fragment registers of
+        // the K-loop are dead here); issued per token block they would expose the memory latency 8 times
+        bf16x4 res[8][4];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          const int m = min(mrow0 + 16 * bb + l15, M - 1);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) res[bb][a] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + 16 * a + 4 * lq);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[a][bb][e] + bv[a][e] + (float)res[bb][a][e];
+              acc[a][bb][e] = x;
+              p1 += x;
+              p2 = fmaf(x, x, p2);
+            }
+          p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
+          p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
+          if (lq == 0) part[ew * 128 + 16 * bb + l15] = float2{p1, p2};
+        }
+      }
+      __syncthreads();
+      if (el < 32) {                                                // 4 waves of a row group: 32 rows each
+        const int row = 32 * wn + el;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) { const float2 p = part[(wm * 4 + w4) * 128 + row]; a1 += p.x; a2 += p.y; }
+        const int m = mrow0 + row;
+        if (m < M) {
+          const unsigned long long raw = (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32);
+          __hip_atomic_store(ln.stats + (size_t)m * n_tiles + nt, raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's write-through stores are done
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ln.counters + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ln.counters + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 400000) { atomicOr(ln.status, 4); break; }    // bounded (~0.1 s): never hang the GPU
+        }
+      }
+      __syncthreads();
+      {
+        float2* mr = part + ew * 128;                               // mean / rstd of the wave's 128 rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 2 * el + i;
+          const int m = min(mrow0 + row, M - 1);
+          float s1 = 0.f, s2 = 0.f;
+          for (int j = 0; j < n_tiles; ++j) {                       // fixed order: bitwise reproducible
+            const unsigned long long raw = __hip_atomic_load(ln.stats + (size_t)m * n_tiles + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __uint_as_float((unsigned)raw);
+            s2 += __uint_as_float((unsigned)(raw >> 32));
+          }
+          const float mean = s1 / (float)N;
+          const float var = fmaxf(s2 / (float)N - mean * mean, 0.f);
+          mr[row] = float2{mean, 1.0f / sqrtf(var + ln.eps)};
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 g4[4], b4[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          g4[a] = *reinterpret_cast<const f32x4*>(ln.gamma + nbase + 16 * a + 4 * lq);
+          b4[a] = *reinterpret_cast<const f32x4*>(ln.beta + nbase + 16 * a + 4 * lq);
+        }
+        const int row0 = el >> 3, sl = el & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int b2 = 0; b2 < 2; ++b2) {
+            const int row = 16 * b2 + l15;
+            const float2 ms = mr[32 * j + row];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (acc[a][2 * j + b2][e] - ms.x) * ms.y * g4[a][e] + b4[a][e];
+              const int c = (16 * a + 4 * lq) / 8;
+              store4<bf16_t>(reinterpret_cast<bf16_t*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)), o[0], o[1], o[2], o[3]);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + row0;
+            const int c = sl ^ (row & 7);
+            const int m = mrow0 + 32 * j + row;
+            const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * 128 + (sl << 4));
+            if (m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<bf16_t*>(Y) + (size_t)m * N + nbase + 8 * c) = raw;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (!has_next) break;
+      t = tn;
+      gsrc = gnext;
+      buf = last ^ 1;
+      continue;
+    }
     // ---- epilogue: 32-token x 64-feature slabs through a wave-private XOR-swizzled LDS slab inside
     // stage `last` (free since the last barrier), whole-row 16-byte stores.
     // The epilogue's lane-constant addressing is recomputed per tile from an opaque copy of the lane
@@ -843,14 +983,16 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
   TOut* y = static_cast<TOut*>(Y);
   switch (epi) {
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
       break;
     case EPI_BIAS_RES:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
       break;
+    default:
+      return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
@@ -883,6 +1025,45 @@ int launch_big(Epilogue epi, const void* X, const void* W, const float* bias, co
 }
 
 }  // namespace
+
+static int device_cus() {
+  static int n_cus = 0;
+  if (!n_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n_cus;
+}
+
+size_t gemm_ln_sync_bytes(int64_t m_bound, int N) { return (size_t)(m_bound / G_BM) * 4 + 256 + (size_t)m_bound * (N / G_BN) * 8; }
+
+int gemm_tn_ln(const void* X, const void* W, const float* bias, void* Y, const float* gamma, const float* beta,
+               float eps, void* sync, int64_t m_bound, int N, int K, const int* m_total, int32_t* status,
+               hipStream_t stream) {
+  if (N % G_BN || (K * 2) % ROW_BYTES || m_bound % G_BM || !sync)
+    return fail(MANNER_HIP_E_INVALID, "gemm_ln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  const int n_tiles = N / G_BN;
+  const int64_t tiles = (m_bound / G_BM) * n_tiles;
+  // persistent grid, a whole number of panels per round: a panel's column tiles always run in the
+  // same round on neighbouring slots
+  int64_t grid = (device_cus() / n_tiles) * n_tiles;
+  if (grid <= 0) grid = n_tiles;
+  if (tiles < grid) grid = tiles;
+  // only the arrival counters need zeroing; every stats slot is written before it is read
+  const size_t cbytes = (size_t)round_up((m_bound / G_BM) * 4, 256);
+  MANNER_HIP_TRY(hipMemsetAsync(sync, 0, cbytes, stream));
+  LnFuse ln;
+  ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.status = status;
+  ln.counters = static_cast<int*>(sync);
+  ln.stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(sync) + cbytes);
+  hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_BIAS_RES_LN>), dim3((unsigned)grid), dim3(512), 0, stream,
+                     static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(W), bias, static_cast<const bf16_t*>(Y),
+                     static_cast<bf16_t*>(Y), N, K, m_total, n_tiles, ln);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
 
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,

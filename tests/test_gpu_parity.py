@@ -104,6 +104,36 @@ def test_encoder_padding_and_order_invariance_full_size():
     enc.status()
 
 
+def test_optional_paths_agree_with_default(monkeypatch):
+    """Opt-in execution modes (read from the environment at encoder creation): two phase-shifted
+    streams run the same kernels (bit-identical); the fused GEMM+LayerNorm epilogue uses a one-pass
+    variance and must stay within bf16 noise of the default path."""
+    cfg = PRESETS["bert-base-uncased"]
+    w = make_plm_weights(cfg, seed=42, std=0.02)
+    ids, mask = synth_news_tokens(3000, cfg, seed=21, profile="title_abstract")
+    base, _ = _encoder("bert-base-uncased", 42, 0.02)
+    lens = mask.sum(1)
+    ref = base.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    monkeypatch.setenv("MANNER_HIP_STREAMS", "2")
+    two = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
+    out2 = two.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    two.status()
+    assert torch.equal(ref, out2)
+    two.close()
+    monkeypatch.setenv("MANNER_HIP_STREAMS", "1")
+    monkeypatch.setenv("MANNER_HIP_FUSE_LN", "1")
+    fused = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
+    out3 = fused.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    fused.status()                                   # raises if a panel wait had expired
+    out3b = fused.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    assert torch.equal(out3, out3b)                  # deterministic (fixed-order slot sums, no float atomics)
+    d = (out3 - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(out3, ref, dim=1).min().item()
+    print(f"fused-LN vs default bf16: max-abs {d:.3e}, min cosine {cos:.6f}")
+    assert d < 0.1 and cos > 0.9995
+    fused.close()
+
+
 def test_encoder_rejects_bad_mask():
     enc, cfg = _encoder("tiny-bert", 7, 0.05)
     ids, mask = synth_news_tokens(4, cfg, seed=1, lengths=np.array([5, 6, 7, 8]))

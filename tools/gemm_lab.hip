@@ -66,7 +66,8 @@ int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 65536;
   struct Shape { const char* name; int N, K; Epilogue epi; bool f32out; };
   Shape shapes[] = {{"qkv", 2304, 768, EPI_BIAS, false}, {"out", 768, 768, EPI_BIAS_RES, true},
-                    {"ffn1", 3072, 768, EPI_BIAS_GELU, false}, {"ffn2", 768, 3072, EPI_BIAS_RES, true}};
+                    {"ffn1", 3072, 768, EPI_BIAS_GELU, false}, {"ffn2", 768, 3072, EPI_BIAS_RES, true},
+                    {"ffn1h", 1536, 768, EPI_BIAS_GELU, false}, {"qkvh", 1280, 768, EPI_BIAS, false}, {"qkv1", 256, 768, EPI_BIAS, false}};
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
   const size_t maxe = (size_t)M * 3072;
@@ -115,7 +116,7 @@ int main(int argc, char** argv) {
     }
     {
       auto runx = [&](int abl) {
-#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), dim3(g.x < 256 ? g.x : 256), b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
+#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), dim3(g.x < 256 ? g.x : 256), b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles, LnFuse{})
 #define BY_ABLX(TO, EPI) switch (abl) { case 0: LAUNCHX(TO, EPI, 0); break; case 1: LAUNCHX(TO, EPI, 1); break; case 2: LAUNCHX(TO, EPI, 2); break; }
         if (s.epi == EPI_BIAS) { BY_ABLX(bf16_t, EPI_BIAS) }
         else if (s.epi == EPI_BIAS_GELU) { BY_ABLX(bf16_t, EPI_BIAS_GELU) }
