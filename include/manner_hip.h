@@ -142,6 +142,26 @@ int manner_hip_additive_pool(const float* x, const float* lin_w, const float* li
                              int64_t B, int64_t S, int32_t D, int32_t Q, float* out, float* scratch,
                              manner_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- entity branch (K8)
+ * manner_hip_entity_encode replaces MannerEntityEncoder.forward — manner/models/components/news_encoder.py:60-72:
+ * Embedding -> nn.MultiheadAttention(D, heads) -> AdditiveAttention(D -> Q), eval mode.  BATCH-FAITHFUL
+ * to the reference: the MHA is batch_first=False but receives [N, E, D], so attention
+ * runs across the N news of the call at each entity slot, without key_padding_mask; the result for
+ * a news depends on the other news of the call, exactly as in the reference.
+ *   entity_ids int64 [N, E] (0 = padding slot, looked up like any other row); table f32 [n_entities, D];
+ *   in_proj_w [3D, D], in_proj_b [3D], out_proj_w [D, D], out_proj_b [D] (nn.MultiheadAttention keys);
+ *   pool_w [Q, D], pool_b [Q], pool_q [Q] (AdditiveAttention keys); out f32 [N, D].
+ * manner_hip_linear replaces the nn.Linear(H + D -> H) on cat[text, entity] — news_encoder.py:109-113,
+ * 122-124: y[R, O] = x[R, K] weight[O, K]^T + bias[O] (bias may be NULL). */
+size_t manner_hip_entity_workspace_bytes(int64_t N, int64_t E, int32_t D);
+int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, const float* table, int64_t n_entities,
+                             int32_t D, int32_t heads, const float* in_proj_w, const float* in_proj_b,
+                             const float* out_proj_w, const float* out_proj_b, const float* pool_w,
+                             const float* pool_b, const float* pool_q, int32_t Q, float* out, void* workspace,
+                             size_t workspace_bytes, manner_hip_stream_t stream);
+int manner_hip_linear(const float* x, const float* weight, const float* bias, int64_t R, int32_t K, int32_t O,
+                      float* y, manner_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- scorer (K12, K9+K10+K12)
  * Replaces DotProduct.forward — manner/models/components/click_predictors.py:9-12:
  * out[b,c] = <user[b,:], cand[b,:,c]>.  `cand` is addressed with element strides so that the

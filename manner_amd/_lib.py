@@ -40,6 +40,9 @@ SIGNATURES = {
     "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
     "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
+    "manner_hip_entity_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
+    "manner_hip_entity_encode": (C.c_int, [_P, _I64, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
+    "manner_hip_linear": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "manner_hip_dot": (C.c_int, [_P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P]),
     "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P]),
     "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P]),

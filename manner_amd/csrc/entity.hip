@@ -1,0 +1,160 @@
+// K8: the entity branch of MannerNewsEncoder (reference manner/models/components/news_encoder.py:40-72,
+// 98-113, 119-124) — small f32 VALU kernels, batch-faithful to the reference's quirk Q1:
+// nn.MultiheadAttention is built with batch_first=False but fed [N, E, D], so attention runs ACROSS THE
+// N NEWS OF THE CALL at each entity slot e (sequence axis = news, batch axis = entity slot), with no
+// key_padding_mask.  A news embedding therefore depends on the other news of the batch, exactly as
+// in the reference; the table architecture is not offered for use_entities=True.
+#include <math.h>
+
+#include "common.h"
+
+namespace manner {
+namespace {
+
+constexpr int LIN_ROWS = 8;      // rows per workgroup of the generic linear kernel
+
+// y[r, o] = b[o] + sum_k x[r, k] W[o, k]   (nn.Linear; x rows may be gathered through `gather`)
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ gather,
+                                                          int64_t n_src_rows, const float* __restrict__ W,
+                                                          const float* __restrict__ b, int64_t R, int K, int O,
+                                                          float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];     // [LIN_ROWS][K]
+  const int64_t r0 = (int64_t)blockIdx.x * LIN_ROWS;
+  const int nr = (int)min((int64_t)LIN_ROWS, R - r0);
+  for (int i = threadIdx.x; i < nr * K; i += 256) {
+    const int rr = i / K, k = i - rr * K;
+    int64_t src = r0 + rr;
+    if (gather) { src = gather[src]; src = src < 0 ? 0 : (src >= n_src_rows ? n_src_rows - 1 : src); }
+    xs[rr * K + k] = x[src * K + k];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < O; o += 256) {
+    const float* w = W + (size_t)o * K;
+    float acc[LIN_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < LIN_ROWS; ++rr) acc[rr] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float wv = w[k];
+#pragma unroll
+      for (int rr = 0; rr < LIN_ROWS; ++rr) acc[rr] = fmaf(xs[rr * K + k], wv, acc[rr]);
+    }
+    const float bv = b ? b[o] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < LIN_ROWS; ++rr)
+      if (rr < nr) y[(r0 + rr) * O + o] = acc[rr] + bv;
+  }
+}
+
+// attention over the NEWS axis for one (entity slot, head): qkv [N, E, 3D] = [q | k | v], out [N, E, D].
+// One thread per query news, keys streamed through LDS tiles, online softmax (dh = D / heads <= 16).
+template <int DH>
+__global__ __launch_bounds__(256) void entity_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                          int64_t N, int E, int D, int heads) {
+  __shared__ float ks[256 * DH], vs[256 * DH];
+  const int eh = blockIdx.x, e = eh / heads, hh = eh - e * heads;
+  const int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const size_t ld = (size_t)E * 3 * D;
+  const float* base = qkv + (size_t)e * 3 * D + hh * DH;
+  float q[DH], o[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { q[d] = n < N ? base[n * ld + d] * scale : 0.f; o[d] = 0.f; }   // q is scaled first, as torch does
+  float mx = -INFINITY, sum = 0.f;
+  for (int64_t t0 = 0; t0 < N; t0 += 256) {
+    const int64_t kn = t0 + threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      ks[threadIdx.x * DH + d] = kn < N ? base[kn * ld + D + d] : 0.f;
+      vs[threadIdx.x * DH + d] = kn < N ? base[kn * ld + 2 * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int cnt = (int)min((int64_t)256, N - t0);
+    for (int j = 0; j < cnt; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s = fmaf(q[d], ks[j * DH + d], s);
+      if (s > mx) {
+        const float f = expf(mx - s);
+        sum *= f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] *= f;
+        mx = s;
+      }
+      const float p = expf(s - mx);
+      sum += p;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] = fmaf(p, vs[j * DH + d], o[d]);
+    }
+  }
+  if (n < N) {
+    const float inv = 1.0f / sum;
+    float* dst = out + (size_t)n * E * D + (size_t)e * D + hh * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dst[d] = o[d] * inv;
+  }
+}
+
+int launch_linear(const float* x, const int64_t* gather, int64_t n_src, const float* W, const float* b, int64_t R, int K,
+                  int O, float* y, hipStream_t s) {
+  if (R == 0) return MANNER_HIP_OK;
+  if (K <= 0 || O <= 0 || K > 4096) return fail(MANNER_HIP_E_INVALID, "linear: K=%d O=%d unsupported (K <= 4096)", K, O);
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)((R + LIN_ROWS - 1) / LIN_ROWS)), dim3(256), LIN_ROWS * K * sizeof(float), s,
+                     x, gather, n_src, W, b, R, K, O, y);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+}  // namespace
+}  // namespace manner
+
+using namespace manner;
+
+extern "C" {
+
+int manner_hip_linear(const float* x, const float* weight, const float* bias, int64_t R, int32_t K, int32_t O, float* y,
+                      manner_hip_stream_t stream) {
+  if (R < 0 || (R > 0 && (!x || !weight || !y))) return fail(MANNER_HIP_E_INVALID, "linear: null pointer");
+  return launch_linear(x, nullptr, 0, weight, bias, R, K, O, y, (hipStream_t)stream);
+}
+
+size_t manner_hip_entity_workspace_bytes(int64_t N, int64_t E, int32_t D) {
+  if (N <= 0 || E <= 0 || D <= 0) return 0;
+  return (size_t)(N * E) * (size_t)(6 * D + 1) * sizeof(float) + 1024;
+}
+
+int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, const float* table, int64_t n_entities,
+                             int32_t D, int32_t heads, const float* in_proj_w, const float* in_proj_b,
+                             const float* out_proj_w, const float* out_proj_b, const float* pool_w, const float* pool_b,
+                             const float* pool_q, int32_t Q, float* out, void* workspace, size_t workspace_bytes,
+                             manner_hip_stream_t stream) {
+  if (N == 0) return MANNER_HIP_OK;
+  if (!entity_ids || !table || !in_proj_w || !in_proj_b || !out_proj_w || !out_proj_b || !pool_w || !pool_b || !pool_q || !out || !workspace)
+    return fail(MANNER_HIP_E_INVALID, "entity_encode: null pointer");
+  if (N < 0 || E <= 0 || D <= 0 || heads <= 0 || D % heads || D % 4 || n_entities <= 0)
+    return fail(MANNER_HIP_E_INVALID, "entity_encode: N=%lld E=%lld D=%d heads=%d unsupported", (long long)N, (long long)E, D, heads);
+  if (workspace_bytes < manner_hip_entity_workspace_bytes(N, E, D)) return fail(MANNER_HIP_E_WORKSPACE, "entity_encode: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t R = N * E;
+  float* qkv = static_cast<float*>(workspace);          // [R, 3D]
+  float* att = qkv + (size_t)R * 3 * D;                 // [R, D]
+  float* proj = att + (size_t)R * D;                    // [R, D]
+  float* scratch = proj + (size_t)R * D;                // [R] logits of the additive pooler (+ D spare)
+  int rc;
+  // embedding lookup fused into the in-projection (rows gathered from the table)
+  if ((rc = launch_linear(table, entity_ids, n_entities, in_proj_w, in_proj_b, R, D, 3 * D, qkv, s))) return rc;
+  const int dh = D / heads;
+  dim3 g((unsigned)(E * heads), (unsigned)((N + 255) / 256)), b(256);
+  switch (dh) {
+    case 10: hipLaunchKernelGGL(entity_attn_kernel<10>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 8: hipLaunchKernelGGL(entity_attn_kernel<8>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 16: hipLaunchKernelGGL(entity_attn_kernel<16>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 4: hipLaunchKernelGGL(entity_attn_kernel<4>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    default: return fail(MANNER_HIP_E_INVALID, "entity_encode: head_dim %d unsupported (4, 8, 10, 16)", dh);
+  }
+  MANNER_LAUNCH_CHECK();
+  if ((rc = launch_linear(att, nullptr, 0, out_proj_w, out_proj_b, R, D, D, proj, s))) return rc;
+  return manner_hip_additive_pool(proj, pool_w, pool_b, pool_q, N, E, D, Q, out, scratch, stream);
+}
+
+}  // extern "C"

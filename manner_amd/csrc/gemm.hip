@@ -223,6 +223,8 @@ int launch(Epilogue epi, const void* X, const void* W, const float* bias, const 
     case EPI_BIAS_RES:
       hipLaunchKernelGGL((gemm_tn_kernel<TIn, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
       break;
+    default:
+      return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
@@ -1019,6 +1021,8 @@ int launch_big(Epilogue epi, const void* X, const void* W, const float* bias, co
     case EPI_BIAS_RES:
       hipLaunchKernelGGL((gemm_tn_big_kernel<TIn, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles);
       break;
+    default:
+      return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;

@@ -167,6 +167,44 @@ def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Ten
     return out
 
 
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """nn.Linear forward on f32 rows: x [R, K] -> [R, O]."""
+    x = _dev(x, torch.float32, "input").contiguous()
+    weight = _dev(weight, torch.float32, "weight").contiguous()
+    r, k = x.shape
+    o = weight.shape[0]
+    assert weight.shape[1] == k
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "bias").contiguous()
+    y = torch.empty((r, o), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().manner_hip_linear(_ptr(x), _ptr(weight), _ptr(bias), r, k, o, _ptr(y), _stream()))
+    return y
+
+
+def entity_encode(entity_ids: Tensor, table: Tensor, in_proj_w: Tensor, in_proj_b: Tensor, out_proj_w: Tensor,
+                  out_proj_b: Tensor, pool_w: Tensor, pool_b: Tensor, pool_q: Tensor, heads: int) -> Tensor:
+    """MannerEntityEncoder.forward (eval), batch-faithful to the reference: [N, E] ids -> [N, D]."""
+    ids = _dev(entity_ids, torch.int64, "entities").contiguous()
+    n, e = ids.shape
+    ts = [_dev(t, torch.float32, nm).contiguous() for t, nm in
+          ((table, "pretrained_embedding.weight"), (in_proj_w, "in_proj_weight"), (in_proj_b, "in_proj_bias"),
+           (out_proj_w, "out_proj.weight"), (out_proj_b, "out_proj.bias"), (pool_w, "linear.weight"),
+           (pool_b, "linear.bias"), (pool_q, "query"))]
+    d, q = ts[0].shape[1], ts[5].shape[0]
+    out = torch.empty((n, d), dtype=torch.float32, device=ids.device)
+    if n == 0:
+        return out
+    lib = _lib.load()
+    need = int(lib.manner_hip_entity_workspace_bytes(n, e, d))
+    ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
+    with torch.cuda.device(ids.device):
+        _lib.check(lib.manner_hip_entity_encode(_ptr(ids), n, e, _ptr(ts[0]), ts[0].shape[0], d, heads, _ptr(ts[1]), _ptr(ts[2]),
+                                                _ptr(ts[3]), _ptr(ts[4]), _ptr(ts[5]), _ptr(ts[6]), _ptr(ts[7]), q, _ptr(out),
+                                                _ptr(ws), need, _stream()))
+    return out
+
+
 def dot(user: Tensor, cand: Tensor) -> Tensor:
     """DotProduct contract: user [B,1,D], cand [B,D,C] (any strides, e.g. a permuted [B,C,D]) -> [B,C]."""
     user, cand = _dev(user, torch.float32, "clicked_news_vector"), _dev(cand, torch.float32, "candidate_news_vector")

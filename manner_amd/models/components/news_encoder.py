@@ -134,11 +134,12 @@ class MannerTextEncoder(nn.Module):
 
 
 class MannerEntityEncoder(nn.Module):
-    """reference news_encoder.py:40-72 — parameters only (checkpoint compatibility).
+    """reference news_encoder.py:40-72.
 
-    The reference feeds a batch-first tensor to a batch_first=False nn.MultiheadAttention, so entity
-    attention mixes the news of a batch; the HIP path does not reproduce that yet and
-    refuses instead of returning different numbers."""
+    BATCH-FAITHFUL to the reference: its nn.MultiheadAttention is batch_first=False but receives
+    [N, E, D], so entity attention runs across the N news of the call at each entity slot and there is
+    no key_padding_mask.  The HIP path reproduces exactly that, so — as in the
+    reference — a news embedding depends on the other news of the batch when use_entities=True."""
 
     def __init__(self, pretrained_embedding: nn.Embedding, embedding_dim: int, num_attention_heads: int,
                  query_vector_dim: int, dropout_probability: float) -> None:
@@ -149,9 +150,13 @@ class MannerEntityEncoder(nn.Module):
         self.dropout = nn.Dropout(p=dropout_probability)
 
     def forward(self, entity_sequence: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "use_entities=True: the reference's entity encoder couples the news of a batch (SURVEY.md Q1); "
-            "the HIP hot path covers use_entities=False (the *_title_* configs) and refuses this one")
+        if self.training:
+            raise RuntimeError("manner_amd MannerEntityEncoder is inference-only; call .eval()")
+        mha, pool = self.multihead_attention, self.additive_attention
+        return hip.entity_encode(entity_sequence, self.pretrained_embedding.weight.detach(), mha.in_proj_weight.detach(),
+                                 mha.in_proj_bias.detach(), mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
+                                 pool.linear.weight.detach(), pool.linear.bias.detach(), pool.query.detach(),
+                                 heads=mha.num_heads)
 
 
 class MannerNewsEncoder(nn.Module):
@@ -175,6 +180,11 @@ class MannerNewsEncoder(nn.Module):
                                     out_features=text_embedding_dim)
 
     def forward(self, news: Dict[str, Any]) -> torch.Tensor:
-        if self.use_entities:
-            return self.entity_encoder(news["entities"])      # raises: see MannerEntityEncoder
-        return self.text_encoder(news["text"])
+        # text embedding
+        text_vector = self.text_encoder(news["text"])
+        if not self.use_entities:
+            return text_vector
+        # entity embedding, concat, linear (news_encoder.py:119-124)
+        entity_vector = self.entity_encoder(news["entities"])
+        return hip.linear(torch.cat([text_vector, entity_vector], dim=-1), self.linear.weight.detach(),
+                          self.linear.bias.detach())

@@ -88,3 +88,25 @@ def make_additive_attention_weights(input_dim: int, query_dim: int, seed: int = 
 
 def tensor_sha256(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_entity_weights(n_entities: int, dim: int = 100, query_dim: int = 200, hidden: int = 768, seed: int = 42,
+                        with_linear: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded parameters of the reference's entity branch (news_encoder.py:98-113), reference key names:
+    ``entity_encoder.*`` and ``linear.*`` as they sit under ``news_encoder.`` in a checkpoint."""
+    out: Dict[str, np.ndarray] = {}
+
+    def put(name, shape, scale):
+        out[name] = (scale * _stream(seed, name).standard_normal(shape, dtype=np.float32)).astype(np.float32)
+
+    put("entity_encoder.pretrained_embedding.weight", (n_entities, dim), 0.5)
+    put("entity_encoder.multihead_attention.in_proj_weight", (3 * dim, dim), 0.15)
+    put("entity_encoder.multihead_attention.in_proj_bias", (3 * dim,), 0.05)
+    put("entity_encoder.multihead_attention.out_proj.weight", (dim, dim), 0.15)
+    put("entity_encoder.multihead_attention.out_proj.bias", (dim,), 0.05)
+    for k, v in make_additive_attention_weights(dim, query_dim, seed=seed, prefix="entity_encoder.additive_attention.").items():
+        out[k] = v
+    if with_linear:
+        put("linear.weight", (hidden, hidden + dim), 0.03)
+        put("linear.bias", (hidden,), 0.02)
+    return out

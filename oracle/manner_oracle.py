@@ -110,6 +110,37 @@ def encode_cls(ids, mask, w, cfg) -> Tensor:
         return encode_tokens(ids, mask, w, cfg)[:, 0, :].contiguous()
 
 
+# --------------------------------------------------------------------------- entity branch (K8)
+
+def entity_encoder(entity_ids: Tensor, w: Dict[str, Tensor], heads: int) -> Tensor:
+    """MannerEntityEncoder.forward (reference news_encoder.py:60-72), eval mode, INCLUDING quirk Q1: the
+    nn.MultiheadAttention is batch_first=False (news_encoder.py:52-54) but receives [N, E, D], so the
+    sequence axis is the N news of the call and the batch axis the entity slot; no key_padding_mask.
+    ``w`` uses the reference's keys: pretrained_embedding.weight, multihead_attention.{in_proj_weight,
+    in_proj_bias, out_proj.weight, out_proj.bias}, additive_attention.{linear.weight, linear.bias, query}."""
+    w = {k: _t(v) for k, v in w.items()}
+    ev = w["pretrained_embedding.weight"][_t(entity_ids).long()]                       # [N, E, D]
+    n, e, d = ev.shape
+    dh = d // heads
+    qkv = ev @ w["multihead_attention.in_proj_weight"].T + w["multihead_attention.in_proj_bias"]
+    q, k, v = qkv.split(d, dim=-1)
+
+    def split_heads(t):                                   # torch MHA: (L, B*heads, dh) with L = N, B = E
+        return t.reshape(n, e * heads, dh).transpose(0, 1)
+
+    att = torch.softmax((split_heads(q) * dh ** -0.5) @ split_heads(k).transpose(1, 2), dim=-1)
+    o = (att @ split_heads(v)).transpose(0, 1).reshape(n, e, d)
+    o = o @ w["multihead_attention.out_proj.weight"].T + w["multihead_attention.out_proj.bias"]
+    return additive_attention(o, w["additive_attention.linear.weight"], w["additive_attention.linear.bias"],
+                              w["additive_attention.query"])
+
+
+def news_encoder_with_entities(text_vec: Tensor, entity_vec: Tensor, lin_w: Tensor, lin_b: Tensor) -> Tensor:
+    """MannerNewsEncoder.forward, use_entities=True (reference news_encoder.py:119-124):
+    linear(cat([text_vector, entity_vector], dim=-1))."""
+    return F.linear(torch.cat([_t(text_vec), _t(entity_vec)], dim=-1), _t(lin_w), _t(lin_b))
+
+
 # --------------------------------------------------------------------------- pooler / scorer
 
 def additive_attention(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:

@@ -31,7 +31,7 @@ sys.dont_write_bytecode = True
 
 from manner_amd.config import ARCH_BERT, PRESETS  # noqa: E402
 from manner_amd.synth import synth_news_tokens  # noqa: E402
-from manner_amd.weights import (make_additive_attention_weights, make_plm_weights,  # noqa: E402
+from manner_amd.weights import (make_additive_attention_weights, make_entity_weights, make_plm_weights,  # noqa: E402
                                 tensor_sha256)
 
 from manner.models.components.attention import AdditiveAttention  # noqa: E402
@@ -120,6 +120,45 @@ def gen_components(seed=42):
     return sorted(ue.state_dict().keys())
 
 
+def gen_entities(seed=42):
+    """Entity branch (K8) from the reference's own MannerNewsEncoder(use_entities=True) over tiny-bert,
+    incl. the Q1 negative: the same news encoded alone differs from its row in the batch."""
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=seed, std=0.05)
+    ew = make_entity_weights(60, dim=100, query_dim=200, hidden=cfg.hidden, seed=seed)
+    ids, mask = synth_news_tokens(9, cfg, seed=seed, max_len=24)
+    g = np.random.Generator(np.random.PCG64(seed + 1))
+    ent = g.integers(1, 60, size=(9, 6), dtype=np.int64)
+    for r, keep in enumerate((6, 5, 3, 1, 0, 2, 6, 4, 1)):        # right-padded with id 0 (reference collate)
+        ent[r, keep:] = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        enc = MannerNewsEncoder(plm_model=hf_model_dir(cfg, w, tmp), frozen_layers=[], dropout_probability=0.2,
+                                use_entities=True, entity_embeddings=ew["entity_encoder.pretrained_embedding.weight"],
+                                entity_embedding_dim=100, num_attention_heads=10, query_vector_dim=200,
+                                text_embedding_dim=cfg.hidden).eval()
+        missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in ew.items()}, strict=False)
+        assert not unexpected and all(m.startswith("text_encoder.") for m in missing), (missing, unexpected)
+        from transformers import BatchEncoding
+
+        def run(sel):
+            return enc({"text": BatchEncoding({"input_ids": torch.from_numpy(ids[sel]), "attention_mask": torch.from_numpy(mask[sel])}),
+                        "entities": torch.from_numpy(ent[sel])})
+
+        allrows = np.arange(9)
+        out = run(allrows).numpy()
+        ent_only = enc.entity_encoder(torch.from_numpy(ent)).numpy()
+        single = run(allrows[:1]).numpy()
+        keys = sorted(enc.state_dict().keys())
+    assert np.abs(single[0] - out[0]).max() > 1e-3            # Q1: batch-coupled
+    np.savez_compressed(os.path.join(HERE, "entities.npz"), ids=ids, mask=mask, entities=ent, out=out, entity_vec=ent_only,
+                        single0=single,
+                        meta=json.dumps({"source": "reference MannerNewsEncoder(use_entities=True) / MannerEntityEncoder "
+                                                   "(news_encoder.py:40-129)", "preset": "tiny-bert", "seed": seed, "std": 0.05,
+                                         "n_entities": 60, "heads": 10, "query_dim": 200}))
+    print("entities", out.shape, float(np.abs(single[0] - out[0]).max()))
+    return keys
+
+
 def gen_pipeline(seed=42):
     """Lightning-level restatement fixtures (source: oracle)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -167,6 +206,7 @@ if __name__ == "__main__":
                                             std=0.02, lengths=lens)
     gen_encoder("enc_bert_base_spread", "bert-base-uncased", n=16, lp=96, seed=44, std=0.05, lengths=lens)
     keys["user_encoder"] = gen_components()
+    keys["tiny-bert-entities"] = gen_entities()
     gen_pipeline()
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0)

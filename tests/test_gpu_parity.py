@@ -234,6 +234,46 @@ def test_module_surface_matches_reference(golden_dir):
     assert np.abs(DotProduct()(_cuda(zd["user"]), _cuda(zd["cand"])).cpu().numpy() - zd["out"]).max() < 1e-4
 
 
+def test_entity_branch_matches_reference(golden_dir):
+    """use_entities=True through the module mirror: text + batch-coupled entity attention (Q1) + linear,
+    against the reference's own output; plus a larger random case against the oracle."""
+    import warnings
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder
+    from manner_amd.weights import make_entity_weights
+    z, meta = _load(golden_dir, "entities")
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    ew = make_entity_weights(meta["n_entities"], 100, meta["query_dim"], cfg.hidden, seed=meta["seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder(plm_model="tiny-bert", frozen_layers=[], dropout_probability=0.2, use_entities=True,
+                                entity_embeddings=ew["entity_encoder.pretrained_embedding.weight"], entity_embedding_dim=100,
+                                num_attention_heads=meta["heads"], query_vector_dim=meta["query_dim"],
+                                text_embedding_dim=cfg.hidden)
+    sd = {"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in w.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in ew.items()})
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).eval()
+    enc.text_encoder.precision = "fp32"
+    news = {"text": {"input_ids": _cuda(z["ids"]), "attention_mask": _cuda(z["mask"])}, "entities": _cuda(z["entities"])}
+    with torch.no_grad():
+        out = enc(news).cpu().numpy()
+        ent = enc.entity_encoder(news["entities"]).cpu().numpy()
+        single = enc({"text": {"input_ids": _cuda(z["ids"][:1]), "attention_mask": _cuda(z["mask"][:1])},
+                      "entities": _cuda(z["entities"][:1])}).cpu().numpy()
+    assert np.abs(ent - z["entity_vec"]).max() < 1e-5
+    assert np.abs(out - z["out"]).max() < FP32_TOL
+    assert np.abs(single - z["single0"]).max() < FP32_TOL        # Q1 reproduced: differs from out[0]
+    # larger batch (several key tiles, ragged entity counts) vs the oracle
+    g = np.random.Generator(np.random.PCG64(3))
+    ents = g.integers(0, meta["n_entities"], size=(700, 11), dtype=np.int64)
+    sub = {k[len("entity_encoder."):]: v for k, v in ew.items() if k.startswith("entity_encoder.")}
+    ref = O.entity_encoder(ents, sub, meta["heads"]).numpy()
+    with torch.no_grad():
+        big = enc.entity_encoder(_cuda(ents)).cpu().numpy()
+    assert np.abs(big - ref).max() < 1e-4
+
+
 @pytest.mark.parametrize("late_fusion", [True, False])
 def test_cr_forward_matches_oracle(late_fusion):
     """CRModule.forward restated on the HIP path vs the oracle's restatement, tiny encoder, B = 6."""

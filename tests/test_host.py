@@ -19,7 +19,7 @@ from manner_amd.synth import segment_ids, shard_range, synth_impressions, synth_
 def test_library_exports_every_header_symbol():
     lib = _lib.load()
     syms = _lib.header_symbols()
-    assert len(syms) >= 14 and set(syms) == set(_lib.SIGNATURES)
+    assert len(syms) >= 17 and set(syms) == set(_lib.SIGNATURES)
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
     assert lib.manner_hip_abi_version() == 1
@@ -77,8 +77,9 @@ def test_module_surface_matches_reference_signatures(golden_dir):
         enc({"text": {"input_ids": torch.zeros(1, 4, dtype=torch.long), "attention_mask": torch.ones(1, 4, dtype=torch.long)}})
     with pytest.raises(RuntimeError, match="GPU"):
         DotProduct()(torch.zeros(1, 1, 4), torch.zeros(1, 4, 2))
-    with pytest.raises(NotImplementedError):
-        ent.eval()({"entities": torch.zeros(1, 2, dtype=torch.long)})
+    with pytest.raises(RuntimeError, match="GPU"):
+        ent.eval().entity_encoder(torch.zeros(1, 2, dtype=torch.long))
+    assert sorted(ent.state_dict()) == ref_keys["tiny-bert-entities"]
 
 
 def test_local_hf_directory_loading(tmp_path):

@@ -55,6 +55,26 @@ def test_dot_product_matches_reference(golden_dir):
     assert np.abs(O.dot_product(z["user"], z["cand"]).numpy() - z["out"]).max() < 1e-4
 
 
+def test_entity_branch_matches_reference(golden_dir):
+    """K8 incl. quirk Q1 (attention across the news of the batch) against the reference's own
+    MannerNewsEncoder(use_entities=True)."""
+    from manner_amd.weights import make_entity_weights
+    z, meta = _load(golden_dir, "entities")
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    ew = make_entity_weights(meta["n_entities"], 100, meta["query_dim"], cfg.hidden, seed=meta["seed"])
+    sub = {k[len("entity_encoder."):]: v for k, v in ew.items() if k.startswith("entity_encoder.")}
+    ent = O.entity_encoder(z["entities"], sub, meta["heads"])
+    assert np.abs(ent.numpy() - z["entity_vec"]).max() < 1e-5
+    text = O.encode_cls(z["ids"], z["mask"], w, cfg)
+    out = O.news_encoder_with_entities(text, ent, ew["linear.weight"], ew["linear.bias"]).numpy()
+    assert np.abs(out - z["out"]).max() < 2e-5
+    # Q1 negative: the first news encoded alone is NOT its row of the batch (entity attention mixes news)
+    alone = O.news_encoder_with_entities(text[:1], O.entity_encoder(z["entities"][:1], sub, meta["heads"]),
+                                         ew["linear.weight"], ew["linear.bias"]).numpy()
+    assert np.abs(alone - z["single0"]).max() < 2e-5 and np.abs(alone[0] - z["out"][0]).max() > 1e-3
+
+
 def test_state_dict_keys_match_reference(golden_dir):
     """Our weight naming is the reference checkpoint naming."""
     with open(os.path.join(golden_dir, "state_dict_keys.json")) as f:
