@@ -303,6 +303,42 @@ def test_cr_forward_matches_oracle(late_fusion):
     assert out.shape == ref.shape and np.abs(out - ref).max() < FP32_TOL
 
 
+@pytest.mark.parametrize("weights", [(0.0, 0.0), (-0.3, 0.0), (-0.3, 0.2)])
+def test_ensemble_forward_matches_oracle(weights):
+    """EnsembleModule.forward (a8) end to end: three tiny encoders (CR + two A-modules), every occurrence
+    encoded, late fusion, per-impression z-score, weighted sum; zero-weight modules are skipped."""
+    cfg = PRESETS["tiny-bert"]
+    seeds = (7, 8, 9)
+    ws = [make_plm_weights(cfg, seed=sd, std=0.05) for sd in seeds]
+    encs = [_encoder("tiny-bert", sd, 0.05)[0] for sd in seeds]
+    imp = synth_impressions(7, 50, seed=4, max_hist=8, max_cand=11)
+    pool_ids, pool_mask = synth_news_tokens(50, cfg, seed=4, max_len=28)
+
+    def sub(idx):
+        m = pool_mask[idx]
+        lp = int(m.sum(1).max())
+        return pool_ids[idx][:, :lp], m[:, :lp]
+
+    (hi, hm), (ci, cm) = sub(imp["hist_idx"]), sub(imp["cand_idx"])
+    bh, bc = torch.from_numpy(segment_ids(imp["hist_off"])), torch.from_numpy(segment_ids(imp["cand_off"]))
+    vecs = [(O.encode_cls(hi, hm, w, cfg), O.encode_cls(ci, cm, w, cfg)) for w in ws]
+    ref = O.ensemble_scores(vecs, bh, bc, weights).numpy()
+    batch = {"x_hist": {"input_ids": _cuda(hi), "attention_mask": _cuda(hm)},
+             "x_cand": {"input_ids": _cuda(ci), "attention_mask": _cuda(cm)},
+             "batch_hist": bh.to(DEV), "batch_cand": bc.to(DEV), "users": torch.zeros(7, dtype=torch.int64, device=DEV)}
+    calls = []
+
+    def wrap(i):
+        def f(x):
+            calls.append(i)
+            return encs[i].encode_cls(x["input_ids"], x["attention_mask"], precision="fp32")
+        return f
+
+    out = hotpath.ensemble_forward([wrap(0), wrap(1), wrap(2)], batch, weights).cpu().numpy()
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 2e-3       # z-scores: O(1) values, std-normalised
+    assert set(calls) == {0} | {i + 1 for i, wv in enumerate(weights) if wv != 0}
+
+
 def test_scorer_linearity_full_size():
     """Property at MIND-small table shape: scores are linear in the table (late fusion), so
     score(a*T) == a^2 * score(T) and the top-10 ranking is scale-invariant."""
