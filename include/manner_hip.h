@@ -194,9 +194,24 @@ int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K,
  * Replaces what RetrievalNormalizedDCG(top_k=k) computes per impression (constructed at
  * manner/models/cr_module.py:83-84, fed at :267-273): stable descending rank of each candidate.
  * topk_idx int32 [B,k]: position (within the impression) of the r-th ranked candidate, -1 padded.
- * ndcg f32 [B]: DCG@k/IDCG@k, 0 for impressions without a positive label. Either may be NULL. */
+ * ndcg f32 [B]: DCG@k/IDCG@k, 0 for impressions without a positive label.
+ * mrr  f32 [B]: 1/(1 + rank of the best-ranked positive) over ALL candidates (RetrievalMRR, constructed at
+ *               manner/models/cr_module.py:82), 0 without a positive.  Any output may be NULL. */
 int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B,
-                         int32_t k, int32_t* topk_idx, float* ndcg, manner_hip_stream_t stream);
+                         int32_t k, int32_t* topk_idx, float* ndcg, float* mrr, manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- aspect metrics
+ * Replaces Diversity / Personalization @k — manner/metrics/functional.py:8-28, 31-62, 65-70 grouped per
+ * impression as manner/metrics/base.py:92-129 and torchmetrics RetrievalMetric.compute do (constructed at
+ * manner/models/ensemble_module.py:56-84).  topk_idx is the output of manner_hip_rank_ndcg for the same k.
+ *   cand_aspect int32 [total candidates], hist_aspect int32 [total history] : class ids in [0, num_classes)
+ *   diversity f32 [B]      : entropy of the class distribution of the top-k / ln(num_classes)
+ *   personalization f32 [B]: generalised Jaccard of the top-k class counts vs the history class counts
+ * Both are 0 for an impression whose candidate class ids sum to 0 (reference behaviour). Either may be NULL. */
+int manner_hip_aspect_metrics(const int32_t* topk_idx, const int32_t* cand_aspect, const int32_t* hist_aspect,
+                              const int64_t* cand_off, const int64_t* hist_off, int64_t B, int32_t k,
+                              int32_t num_classes, float* diversity, float* personalization,
+                              manner_hip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -185,7 +185,8 @@ __device__ __forceinline__ bool ranks_before(float a, int ia, float b, int ib) {
 
 __global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
                                                         const int64_t* __restrict__ off, int64_t B, int k,
-                                                        int32_t* __restrict__ topk, float* __restrict__ ndcg) {
+                                                        int32_t* __restrict__ topk, float* __restrict__ ndcg,
+                                                        float* __restrict__ mrr) {
   constexpr int CAP = 512;
   __shared__ float ssm[4][CAP];
   __shared__ float lsm[4][CAP];
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict_
   if (topk)
     for (int r = lane; r < k; r += 64) if (r >= c) topk[i * k + r] = -1;
   float dcg = 0.f, idcg = 0.f, pos = 0.f;
+  int best = 0x7fffffff;                               // rank of the best-ranked positive (RetrievalMRR)
   for (int a = lane; a < c; a += 64) {
     const float sa = s[a];
     int rank = 0;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict_
     if (l) {
       const float la = l[a];
       if (rank < k) dcg += la / log2f((float)rank + 2.0f);
+      if (la > 0.f) best = min(best, rank);
       int lrank = 0;
       for (int j = 0; j < c; ++j) lrank += ranks_before(l[j], j, la, a) ? 1 : 0;
       if (lrank < k) idcg += la / log2f((float)lrank + 2.0f);
@@ -223,6 +226,55 @@ __global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict_
   if (ndcg && l) {
     dcg = wave_sum(dcg); idcg = wave_sum(idcg); pos = wave_sum(pos);
     if (lane == 0) ndcg[i] = pos == 0.f ? 0.f : dcg / idcg;   // empty_target_action="neg" -> 0
+  }
+  if (mrr && l) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+    if (lane == 0) mrr[i] = best == 0x7fffffff ? 0.f : 1.0f / (float)(best + 1);
+  }
+}
+
+// ---------------------------------------------------------------- aspect Diversity / Personalization @k
+// (reference manner/metrics/functional.py:8-28, 31-62, 65-70 over the per-impression grouping of
+// manner/metrics/base.py:92-129).  One wave per impression, lane c owns aspect class c (<= 64 classes):
+//   diversity       = H(class distribution of the top-k candidates) / ln(num_classes)
+//                     (the reference divides the counts by num_classes, not k, before Categorical —
+//                      which renormalises, so only the distribution matters)
+//   personalization = sum_c min(top-k count_c, history count_c) / sum_c max(...)   (generalised Jaccard)
+// Both are 0 for an impression whose candidate aspect labels sum to 0 (the metric base classes treat
+// that as "no positive target", empty_target_action="neg" — reproduced as is).
+__global__ __launch_bounds__(256) void aspect_metrics_kernel(const int32_t* __restrict__ topk, const int32_t* __restrict__ cand_aspect,
+                                                             const int32_t* __restrict__ hist_aspect,
+                                                             const int64_t* __restrict__ cand_off, const int64_t* __restrict__ hist_off,
+                                                             int64_t B, int k, int num_classes, float* __restrict__ div,
+                                                             float* __restrict__ pers) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  const int64_t c0 = cand_off[i], c1 = cand_off[i + 1];
+  int any = 0;
+  for (int64_t j = c0 + lane; j < c1; j += 64) any |= cand_aspect[j] != 0;
+  any = __any(any);
+  int top_cnt = 0, n_top = 0;
+  for (int r = 0; r < k; ++r) {
+    const int idx = topk[i * k + r];                    // wave-uniform
+    if (idx < 0) break;
+    ++n_top;
+    top_cnt += cand_aspect[c0 + idx] == lane ? 1 : 0;
+  }
+  if (div) {
+    float h = 0.f;
+    if (top_cnt > 0 && lane < num_classes) { const float p = (float)top_cnt / (float)n_top; h = -p * logf(p); }
+    h = wave_sum(h);
+    if (lane == 0) div[i] = any ? h / logf((float)num_classes) : 0.f;
+  }
+  if (pers) {
+    int hist_cnt = 0;
+    for (int64_t j = hist_off[i]; j < hist_off[i + 1]; ++j) hist_cnt += hist_aspect[j] == lane ? 1 : 0;
+    float mn = lane < num_classes ? (float)min(top_cnt, hist_cnt) : 0.f;
+    float mxv = lane < num_classes ? (float)max(top_cnt, hist_cnt) : 0.f;
+    mn = wave_sum(mn); mxv = wave_sum(mxv);
+    if (lane == 0) pers[i] = any ? mn / mxv : 0.f;
   }
 }
 
@@ -284,12 +336,24 @@ int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K,
   return MANNER_HIP_OK;
 }
 
-int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t k,
-                         int32_t* topk_idx, float* ndcg, manner_hip_stream_t stream) {
+int manner_hip_aspect_metrics(const int32_t* topk_idx, const int32_t* cand_aspect, const int32_t* hist_aspect,
+                              const int64_t* cand_off, const int64_t* hist_off, int64_t B, int32_t k, int32_t num_classes,
+                              float* diversity, float* personalization, manner_hip_stream_t stream) {
   if (B == 0) return MANNER_HIP_OK;
-  if (!scores || !cand_off || k < 1 || (ndcg && !labels)) return fail(MANNER_HIP_E_INVALID, "rank_ndcg: bad argument");
+  if (!topk_idx || !cand_aspect || !cand_off || k < 1 || num_classes < 2 || num_classes > 64 || (personalization && (!hist_aspect || !hist_off)))
+    return fail(MANNER_HIP_E_INVALID, "aspect_metrics: bad argument (2 <= num_classes <= 64)");
+  hipLaunchKernelGGL(aspect_metrics_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, topk_idx, cand_aspect,
+                     hist_aspect, cand_off, hist_off, B, k, num_classes, diversity, personalization);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t k,
+                         int32_t* topk_idx, float* ndcg, float* mrr, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!scores || !cand_off || k < 1 || ((ndcg || mrr) && !labels)) return fail(MANNER_HIP_E_INVALID, "rank_ndcg: bad argument");
   hipLaunchKernelGGL(rank_ndcg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, labels, cand_off,
-                     B, k, topk_idx, ndcg);
+                     B, k, topk_idx, ndcg, mrr);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -254,17 +254,40 @@ def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor) -> T
     return out
 
 
-def rank_ndcg(scores: Tensor, labels: Optional[Tensor], cand_off: Tensor, k: int = 10) -> Tuple[Tensor, Optional[Tensor]]:
-    """Per impression: top-k candidate positions int32 [B,k] (-1 padded) and nDCG@k float32 [B]."""
+def rank_ndcg(scores: Tensor, labels: Optional[Tensor], cand_off: Tensor, k: int = 10, with_mrr: bool = False):
+    """Per impression: top-k candidate positions int32 [B,k] (-1 padded), nDCG@k float32 [B] and, with
+    ``with_mrr``, the reciprocal rank of the best-ranked positive float32 [B]."""
     scores = _dev(scores, torch.float32, "scores").contiguous()
     cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
     nb = cand_off.numel() - 1
     topk = torch.empty((nb, k), dtype=torch.int32, device=scores.device)
-    ndcg = None
+    ndcg = mrr = None
     if labels is not None:
         labels = _dev(labels, torch.float32, "labels").contiguous()
         ndcg = torch.empty((nb,), dtype=torch.float32, device=scores.device)
+        if with_mrr:
+            mrr = torch.empty((nb,), dtype=torch.float32, device=scores.device)
     with torch.cuda.device(scores.device):
         _lib.check(_lib.load().manner_hip_rank_ndcg(_ptr(scores), _ptr(labels), _ptr(cand_off), nb, k, _ptr(topk),
-                                                    _ptr(ndcg), _stream()))
-    return topk, ndcg
+                                                    _ptr(ndcg), _ptr(mrr), _stream()))
+    return (topk, ndcg, mrr) if with_mrr else (topk, ndcg)
+
+
+def aspect_metrics(topk: Tensor, cand_aspect: Tensor, cand_off: Tensor, num_classes: int,
+                   hist_aspect: Optional[Tensor] = None, hist_off: Optional[Tensor] = None):
+    """Aspect Diversity@k (and, with the history aspects, Personalization@k) per impression from the
+    top-k positions of ``rank_ndcg``: float32 [B] each."""
+    topk = _dev(topk, torch.int32, "topk").contiguous()
+    cand_aspect = _dev(cand_aspect, torch.int32, "cand_aspect").contiguous()
+    cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
+    nb, k = topk.shape
+    div = torch.empty((nb,), dtype=torch.float32, device=topk.device)
+    pers = None
+    if hist_aspect is not None:
+        hist_aspect = _dev(hist_aspect, torch.int32, "hist_aspect").contiguous()
+        hist_off = _dev(hist_off, torch.int64, "hist_off").contiguous()
+        pers = torch.empty((nb,), dtype=torch.float32, device=topk.device)
+    with torch.cuda.device(topk.device):
+        _lib.check(_lib.load().manner_hip_aspect_metrics(_ptr(topk), _ptr(cand_aspect), _ptr(hist_aspect), _ptr(cand_off),
+                                                         _ptr(hist_off), nb, k, num_classes, _ptr(div), _ptr(pers), _stream()))
+    return div, pers

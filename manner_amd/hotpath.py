@@ -122,5 +122,5 @@ def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights:
         scores = planes[0]
     else:
         scores = hip.zscore_fuse(torch.stack(planes), [w for w in weights if w != 0], imp["cand_off"])
-    topk, ndcg = hip.rank_ndcg(scores, labels, imp["cand_off"], k)
-    return {"scores": scores, "topk": topk, "ndcg": ndcg}
+    topk, ndcg, mrr = hip.rank_ndcg(scores, labels, imp["cand_off"], k, with_mrr=True)
+    return {"scores": scores, "topk": topk, "ndcg": ndcg, "mrr": mrr}

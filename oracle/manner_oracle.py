@@ -256,6 +256,53 @@ def ndcg_at_k(scores: Tensor, target: Tensor, offsets: Sequence[int], k: int) ->
     return float(per_t.mean()) if per else 0.0, per_t
 
 
+def mrr(scores: Tensor, target: Tensor, offsets: Sequence[int]) -> Tuple[float, Tensor]:
+    """RetrievalMRR restated (constructed at reference cr_module.py:82): per impression the reciprocal
+    rank of the first positive in descending-score order, 0 without a positive; mean over impressions."""
+    per = []
+    for i in range(len(offsets) - 1):
+        s, t = scores[offsets[i]:offsets[i + 1]], target[offsets[i]:offsets[i + 1]]
+        hit = torch.nonzero(t[torch.argsort(s, descending=True, stable=True)] > 0)
+        per.append(1.0 / (int(hit[0]) + 1) if hit.numel() else 0.0)
+    per_t = torch.tensor(per, dtype=torch.float64)
+    return float(per_t.mean()) if per else 0.0, per_t
+
+
+def diversity_at_k(scores: Tensor, cand_aspect: Tensor, cand_off: Sequence[int], num_classes: int, k: int) -> Tensor:
+    """Diversity@k per impression: reference manner/metrics/functional.py:8-28 inside the grouping of
+    torchmetrics RetrievalMetric.compute (``if not mini_target.sum()`` -> 0, empty_target_action='neg')."""
+    out = []
+    for i in range(len(cand_off) - 1):
+        s, a = scores[cand_off[i]:cand_off[i + 1]], cand_aspect[cand_off[i]:cand_off[i + 1]].long()
+        if not a.sum():
+            out.append(0.0)
+            continue
+        top = a[torch.argsort(s, dim=-1, descending=True, stable=True)][:k]            # functional.py:19
+        cnt = F.pad(torch.bincount(top), pad=(0, num_classes - int(top.max()) - 1))     # :20-21
+        prob = cnt / cnt.shape[0]                                                        # :22 (divides by num_classes)
+        ent = torch.distributions.Categorical(prob).entropy()                            # :23 (renormalises)
+        out.append(float(ent / torch.log(torch.tensor(float(num_classes)))))             # :25-27
+    return torch.tensor(out, dtype=torch.float64)
+
+
+def personalization_at_k(scores: Tensor, cand_aspect: Tensor, hist_aspect: Tensor, cand_off: Sequence[int],
+                         hist_off: Sequence[int], num_classes: int, k: int) -> Tensor:
+    """Personalization@k per impression: reference manner/metrics/functional.py:31-70 inside the grouping of
+    manner/metrics/base.py:92-129 (same empty-target rule)."""
+    out = []
+    for i in range(len(cand_off) - 1):
+        s, a = scores[cand_off[i]:cand_off[i + 1]], cand_aspect[cand_off[i]:cand_off[i + 1]].long()
+        h = hist_aspect[hist_off[i]:hist_off[i + 1]].long()
+        if not a.sum():
+            out.append(0.0)
+            continue
+        top = a[torch.argsort(s, dim=-1, descending=True, stable=True)][:k]
+        pc = torch.bincount(top, minlength=num_classes)
+        tc = torch.bincount(h, minlength=num_classes)
+        out.append(float(torch.min(pc, tc).sum() / torch.max(pc, tc).sum()))            # generalized_jaccard :65-70
+    return torch.tensor(out, dtype=torch.float64)
+
+
 # --------------------------------------------------------------------------- whole-path drivers
 
 def offsets_to_batch(offsets: Sequence[int]) -> Tensor:

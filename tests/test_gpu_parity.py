@@ -339,6 +339,32 @@ def test_ensemble_forward_matches_oracle(weights):
     assert set(calls) == {0} | {i + 1 for i, wv in enumerate(weights) if wv != 0}
 
 
+def test_mrr_and_aspect_metrics_match_oracle():
+    """MRR, aspect Diversity@k and Personalization@k on device vs the restatement
+    (19 category / 4 sentiment classes as in configs/model/ensemble_module.yaml:8-9)."""
+    imp = synth_impressions(300, 5000, seed=12)
+    g = np.random.Generator(np.random.PCG64(12))
+    total_c, total_h = int(imp["cand_off"][-1]), int(imp["hist_off"][-1])
+    scores = g.standard_normal(total_c).astype(np.float32)
+    co, ho = imp["cand_off"], imp["hist_off"]
+    for ncls in (19, 4):
+        ca = g.integers(0, ncls, total_c).astype(np.int32)
+        ha = g.integers(0, ncls, total_h).astype(np.int32)
+        ca[co[5]:co[6]] = 0                               # the "class ids sum to 0" quirk -> 0
+        for k in (5, 10):
+            topk, ndcg, mrr = hip.rank_ndcg(_cuda(scores), _cuda(imp["labels"]), _cuda(co), k, with_mrr=True)
+            div, pers = hip.aspect_metrics(topk, _cuda(ca), _cuda(co), ncls, _cuda(ha), _cuda(ho))
+            st, ct = torch.from_numpy(scores), torch.from_numpy(ca)
+            rd = O.diversity_at_k(st, ct, co.tolist(), ncls, k)
+            rp = O.personalization_at_k(st, ct, torch.from_numpy(ha), co.tolist(), ho.tolist(), ncls, k)
+            assert np.abs(div.cpu().numpy() - rd.numpy()).max() < 1e-5 and div[5].item() == 0.0
+            assert np.abs(pers.cpu().numpy() - rp.numpy()).max() < 1e-6 and pers[5].item() == 0.0
+            _, rm = O.mrr(st, torch.from_numpy(imp["labels"]), co.tolist())
+            assert np.abs(mrr.cpu().numpy() - rm.numpy()).max() < 1e-7
+            only_div, none = hip.aspect_metrics(topk, _cuda(ca), _cuda(co), ncls)
+            assert none is None and torch.equal(only_div, div)
+
+
 def test_scorer_linearity_full_size():
     """Property at MIND-small table shape: scores are linear in the table (late fusion), so
     score(a*T) == a^2 * score(T) and the top-10 ranking is scale-invariant."""

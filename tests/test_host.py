@@ -19,7 +19,7 @@ from manner_amd.synth import segment_ids, shard_range, synth_impressions, synth_
 def test_library_exports_every_header_symbol():
     lib = _lib.load()
     syms = _lib.header_symbols()
-    assert len(syms) >= 17 and set(syms) == set(_lib.SIGNATURES)
+    assert len(syms) >= 18 and set(syms) == set(_lib.SIGNATURES)
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
     assert lib.manner_hip_abi_version() == 1

@@ -132,3 +132,30 @@ def test_ndcg_hand_example():
     assert abs(val - per.mean().item()) < 1e-12
     val0, _ = O.ndcg_at_k(scores, torch.zeros(6), off, 10)
     assert val0 == 0.0
+
+
+def test_mrr_and_aspect_metrics_hand_examples():
+    """Restated metrics against values worked out by hand from reference metrics/functional.py."""
+    scores = torch.tensor([0.1, 0.9, 0.5, 0.3, 0.2, 0.8, 0.7])
+    target = torch.tensor([0.0, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0])
+    off = [0, 3, 7]
+    val, per = O.mrr(scores, target, off)
+    assert per.tolist() == [0.5, 0.25] and abs(val - 0.375) < 1e-12      # positives ranked 2nd and 4th
+    aspects = torch.tensor([2, 1, 1, 0, 3, 3, 1])
+    # impression 0, k=2: top-2 = items 1, 2 -> classes {1, 1}: entropy 0 ; impression 1, k=3: top-3 = items
+    # 5, 6, 3 -> classes {3, 1, 0}: uniform over 3 of 4 classes -> ln3 / ln4
+    d = O.diversity_at_k(scores, aspects, off, 4, 2)
+    assert abs(d[0]) < 1e-6               # Categorical clamps probabilities at eps: not exactly 0
+    d3 = O.diversity_at_k(scores, aspects, off, 4, 3)
+    assert abs(d3[1] - np.log(3) / np.log(4)) < 1e-6
+    hist = torch.tensor([1, 1, 2, 3, 3, 3, 0])
+    hoff = [0, 3, 7]
+    # impression 1, k=3: predicted counts [1,1,0,1], history counts [1,0,0,3] -> min 2 / max 5
+    p = O.personalization_at_k(scores, aspects, hist, off, hoff, 4, 3)
+    assert abs(p[1] - 2 / 5) < 1e-12
+    # impression 0, k=3: predicted [0,2,1,0] vs history [0,2,1,0] -> 1.0
+    assert abs(p[0] - 1.0) < 1e-12
+    # quirk: candidate class ids that sum to 0 (all class 0) count as "no target" -> 0
+    z = torch.zeros(7, dtype=torch.long)
+    assert O.diversity_at_k(scores, z, off, 4, 3).tolist() == [0.0, 0.0]
+    assert O.personalization_at_k(scores, z, hist, off, hoff, 4, 3).tolist() == [0.0, 0.0]
