@@ -152,9 +152,9 @@ def test_mrr_and_aspect_metrics_hand_examples():
     hoff = [0, 3, 7]
     # impression 1, k=3: predicted counts [1,1,0,1], history counts [1,0,0,3] -> min 2 / max 5
     p = O.personalization_at_k(scores, aspects, hist, off, hoff, 4, 3)
-    assert abs(p[1] - 2 / 5) < 1e-12
+    assert abs(p[1] - 2 / 5) < 1e-7              # float32 division in the reference functional
     # impression 0, k=3: predicted [0,2,1,0] vs history [0,2,1,0] -> 1.0
-    assert abs(p[0] - 1.0) < 1e-12
+    assert abs(p[0] - 1.0) < 1e-7
     # quirk: candidate class ids that sum to 0 (all class 0) count as "no target" -> 0
     z = torch.zeros(7, dtype=torch.long)
     assert O.diversity_at_k(scores, z, off, 4, 3).tolist() == [0.0, 0.0]
