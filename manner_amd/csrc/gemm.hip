@@ -595,14 +595,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(
 //  * K-step (64 bf16) = two k32 steps x two m-halves = 4 chunks of 16 MFMAs; weight fragments of a
 //    k32 step (4) and activation fragments of a chunk (4) are double-buffered in registers and read
 //    one chunk ahead.  The step is rotated so its only barrier sits between chunks 2 and 3:
-//      entry : fragments of chunk 0 in (w0, xa); pieces 0-3 of DMA(k+1) already issued into cur^1
-//      c0    : read chunk 1; issue pieces 4-7 of DMA(k+1);            16 MFMAs
+//      entry : fragments of chunk 0 in (w0, xa); the weight half of DMA(k+1) already issued into cur^1
+//      c0    : read chunk 1; waves 4-7 issue the activation half of DMA(k+1);   16 MFMAs
 //      c1,c2 : read chunks 2, 3;                                      16 MFMAs each
 //      sync  : lgkmcnt(0) (every read of `cur` completed), vmcnt(0) (own DMA(k+1) landed), s_barrier
-//      c3    : read chunk 0 of step k+1 from cur^1; issue pieces 0-3 of DMA(k+2) into `cur`; 16 MFMAs
+//      c3    : read chunk 0 of step k+1 from cur^1; waves 0-3 issue the weight half of DMA(k+2) into `cur`;
+//              16 MFMAs   (DMA issue staggered between the two waves of a SIMD, see kstep)
 //  * Persistent: gridDim.x = #CUs workgroups walk the tiles (round r, XCD-remapped slot).  In the
-//    LAST K-step of a tile the idle stage receives K-step 0 of the workgroup's NEXT tile, so the
-//    ~3 us DMA latency that used to open every tile is covered by the epilogue.  The epilogue slabs
+//    last two K-steps of a tile the stage that has just been freed receives K-step 0 of the workgroup's
+//    NEXT tile, so the ~3 us DMA latency that used to open every tile is covered by the epilogue.  The epilogue slabs
 //    live in the stage the last K-step just finished with; the next tile's first barrier separates
 //    them from its DMA(1), and
 //    the next tile starts with a COUNTED vmcnt that leaves exactly the epilogue's stores in flight.
@@ -684,16 +685,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   };
 
   bf16x8 w0[4], w1[4], xa[4], xb[4];
-  // MODE 0: steady state (DMA(k+1) tail + DMA(k+2) head); 1: second-to-last (DMA(k+1) tail only);
-  // 2: last K-step of the tile (prefetch K-step 0 of the next tile into the idle stage, if any)
+  // DMA issue is STAGGERED between the two waves of a SIMD (waves w and w+4): an LDS-DMA piece costs the
+  // issuing wave ~60-100 cycles, 8 pieces per K-step; if both partners issued in the same chunk neither
+  // could feed the matrix pipe meanwhile.  Waves 0-3 (weight tile) issue all 8 pieces of step k+2 in
+  // chunk 3 (right after the barrier that frees stage `cur`), waves 4-7 (activation tile) all 8 pieces
+  // of step k+1 in chunk 0; each half has >= 2.5 chunks to land before the vmcnt(0) of the sync.
+  // MODE 0: steady state; 1: second-to-last step (chunk 3 prefetches K-step 0 of the NEXT tile instead of
+  // step k+2); 2: last step (chunk 0 prefetches the activation half of the next tile's step 0).
+  auto issue_all = [&](int buf, const TIn* src, int k0) {
+#pragma unroll
+    for (int pair = 0; pair < 4; ++pair) issue2(buf, src, k0, pair);
+  };
   auto kstep = [&](int cur, const TIn* gsrc, int k1, int k2, const TIn* gnext, bool has_next, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     const char* base = lds + cur * G_STAGE_BYTES;
     const char* nxt = lds + (cur ^ 1) * G_STAGE_BYTES;
     read_x(base, 0, 1, xb);
-    if (ABL != 2) {
-      if (MODE <= 1) { issue2(cur ^ 1, gsrc, k1, 2); issue2(cur ^ 1, gsrc, k1, 3); }
-      else if (has_next) { issue2(cur ^ 1, gnext, 0, 0); issue2(cur ^ 1, gnext, 0, 1); }
+    if (ABL != 2 && !is_w) {                                   // waves 4-7
+      if (MODE <= 1) issue_all(cur ^ 1, gsrc, k1);
+      else if (has_next) issue_all(cur ^ 1, gnext, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xa, 0);
@@ -715,9 +725,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (MODE <= 1) { read_w(nxt, 0, w0); read_x(nxt, 0, 0, xa); }
-    if (ABL != 2) {
-      if (MODE == 0) { issue2(cur, gsrc, k2, 0); issue2(cur, gsrc, k2, 1); }
-      else if (MODE == 2 && has_next) { issue2(cur ^ 1, gnext, 0, 2); issue2(cur ^ 1, gnext, 0, 3); }
+    if (ABL != 2 && is_w) {                                    // waves 0-3
+      if (MODE == 0) issue_all(cur, gsrc, k2);
+      else if (MODE == 1 && has_next) issue_all(cur, gnext, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xb, 1);
@@ -735,8 +745,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int nk = K / BK;
 
   const TIn* gsrc = tile_src(t);
-#pragma unroll
-  for (int pair = 0; pair < 4; ++pair) issue2(0, gsrc, 0, pair);
+  issue_all(0, gsrc, 0);
   int buf = 0;                       // stage that holds K-step 0 of the current tile
   bool first = true;
   while (true) {
@@ -762,10 +771,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     __builtin_amdgcn_s_barrier();    // also: every wave has left the previous epilogue's LDS slabs
     read_w(lds + buf * G_STAGE_BYTES, 0, w0);
     read_x(lds + buf * G_STAGE_BYTES, 0, 0, xa);
-    if (nk > 1 && ABL != 2) { issue2(buf ^ 1, gsrc, BK, 0); issue2(buf ^ 1, gsrc, BK, 1); }
+    if (ABL != 2 && is_w) issue_all(buf ^ 1, gsrc, BK);      // weight half of step 1 (nk >= 2, see launch_x16)
     int kt = 0;
     for (; kt + 2 < nk; ++kt) kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, (kt + 2) * BK, gnext, has_next, Mode0{});
-    if (nk > 1) { kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, 0, gnext, has_next, Mode1{}); ++kt; }
+    kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, 0, gnext, has_next, Mode1{});
+    ++kt;
     const int last = (buf + kt) & 1;
     kstep(last, gsrc, 0, 0, gnext, has_next, Mode2{});
 
@@ -1079,7 +1089,7 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
     static const bool use_x32 = getenv("MANNER_HIP_GEMM_X32") != nullptr;   // A/B: bf16 on the 32x32x16 shape
-    if (in == DT_BF16 && !use_x32) {
+    if (in == DT_BF16 && !use_x32 && K >= 128) {          // the staggered DMA schedule needs >= 2 K-steps
       if (out == DT_BF16) return launch_x16<bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
       return launch_x16<float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
     }
