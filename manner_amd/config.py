@@ -57,6 +57,10 @@ PRESETS = {
     # small architectures for fast unit tests (same code paths, head_dim 64)
     "tiny-bert": EncoderConfig(hidden=128, layers=2, heads=2, intermediate=512, vocab=2048,
                                max_pos=128),
+    # two roberta-large-shaped layers (H=1024, 16 heads, I=4096): exercises the 4/12/16-column-tile GEMM
+    # shapes and the 4-vector LayerNorm of configs[4] without 355 M parameters
+    "mini-roberta-large": EncoderConfig(arch=ARCH_ROBERTA, hidden=1024, layers=2, heads=16, intermediate=4096,
+                                        vocab=4096, max_pos=130, type_vocab=1, ln_eps=1e-5, pad_id=1),
     "tiny-roberta": EncoderConfig(arch=ARCH_ROBERTA, hidden=128, layers=2, heads=2,
                                   intermediate=512, vocab=2048, max_pos=130, type_vocab=1,
                                   ln_eps=1e-5, pad_id=1),

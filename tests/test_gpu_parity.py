@@ -86,6 +86,22 @@ def test_encoder_matches_oracle_ragged_chunks():
     enc.status()
 
 
+def test_roberta_large_shape_matches_oracle():
+    """H=1024 / 16 heads / I=4096 tiling (the roberta-large shape of BASELINE configs[4]) and the RoBERTa
+    position rule, fp32 within 1e-4 and bf16 within bf16 noise of the oracle."""
+    enc, cfg = _encoder("mini-roberta-large", 5, 0.03)
+    w = make_plm_weights(cfg, seed=5, std=0.03)
+    lens = np.array([96, 64, 33, 17, 5, 96, 80, 2] * 40)           # 320 news, ~19.7k tokens: many tiles
+    ids, mask = synth_news_tokens(len(lens), cfg, seed=5, lengths=lens)
+    ref = O.encode_cls(ids, mask, w, cfg).numpy()
+    out = enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32", host_lengths=lens).cpu().numpy()
+    assert np.abs(out - ref).max() < FP32_TOL
+    outb = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens).cpu().numpy()
+    cos = (outb * ref).sum(1) / np.linalg.norm(outb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert np.abs(outb - ref).max() < 0.1 and cos.min() > 0.999
+    enc.status()
+
+
 def test_encoder_padding_and_order_invariance_full_size():
     """Size-independent properties at the bert-base shape: (Q5) the CLS row does not depend on the
     padded width, nor on which other news share the launch / their order."""
