@@ -98,12 +98,12 @@ def run_step(enc, b, precision, chunk_tokens, table_buf):
     return scores, topk, ndcg
 
 
-def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev):
+def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev, nb=None):
     """Oracle (CPU port of the reference path) on a bounded sample + parity of the HIP path on it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import manner_oracle as O
     pool_ids, pool_mask, pool_len = pool
-    nb = args.cpu_impressions
+    nb = nb or args.cpu_impressions
     ho, co = imp["hist_off"][: nb + 1], imp["cand_off"][: nb + 1]
     hi, ci = imp["hist_idx"][: ho[-1]], imp["cand_idx"][: co[-1]]
     # the GPU box grants a CPU share of 16 cores per GPU; os.cpu_count() reports the whole host
@@ -338,6 +338,14 @@ def main():
         cpu, par = cpu_baseline_and_parity(args, cfg, weights, enc, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev)
         result["cpu_baseline"] = cpu
         result["parity"] = par
+        # the same check on "trained-like" weights (matrices ~N(0, 0.05^2)): with HF-init weights the CLS
+        # vectors of different news are almost collinear, so bf16 rounding reorders near-tied scores
+        log("parity on spread weights (std 0.05)")
+        w2 = make_plm_weights(cfg, seed=44, std=0.05)
+        enc2 = hip.HipEncoder(cfg, w2, precisions=("bf16", "fp32"), device=dev)
+        _, par2 = cpu_baseline_and_parity(args, cfg, w2, enc2, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb=4)
+        enc2.close()
+        result["parity_spread_weights"] = par2
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
