@@ -623,7 +623,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     int n_tiles, LnFuse ln) {
   typedef bf16_t TIn;
   constexpr int EPC = 8, BK = 64;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
+  // 2 weight stages [0, 64 KiB) + 3 activation stages [64, 160 KiB): the activation tile's first touch
+  // comes from HBM (~2 us), so it is prefetched TWO K-steps ahead; weights are L2-resident (one ahead)
+  __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
+  constexpr int XB = 2 * G_OP_BYTES;                                        // base of the activation ring
 
   const int G = gridDim.x, b = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   // DMA: waves 0-3 bring the weight tile, 4-7 the activation tile, 8 pieces (64 rows) each
   const bool is_w = wave < 4;
   const int prow0 = 64 * (wave & 3);
-  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
+  const int ldst0 = (is_w ? 0 : XB) + prow0 * ROW_BYTES;
   const int lrow = lane >> 3;
   int voff[2];
 #pragma unroll
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     return is_w ? W + (size_t)(nt_ * G_BN + prow0) * K : X + (size_t)(mt_ * G_BM + prow0) * K;
   };
   auto issue2 = [&](int buf, const TIn* gsrc, int k0, int pair) {
-    char* base = lds + buf * G_STAGE_BYTES + ldst0;
+    char* base = lds + buf * G_OP_BYTES + ldst0;          // buf: weight stage 0..1 / activation stage 0..2
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int i = 2 * pair + par;
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 
   const int swz = (kl15 >> 1) & 7;
   const int woff = (kwn * 64 + kl15) * ROW_BYTES;
-  const int xoff = G_OP_BYTES + (kwm * 128 + kl15) * ROW_BYTES;
+  const int xoff = (kwm * 128 + kl15) * ROW_BYTES;
   auto read_w = [&](const char* base, int s2, bf16x8 (&wf)[4]) {
     const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
@@ -696,36 +699,45 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
     for (int pair = 0; pair < 4; ++pair) issue2(buf, src, k0, pair);
   };
-  auto kstep = [&](int cur, const TIn* gsrc, int k1, int k2, const TIn* gnext, bool has_next, auto mode_tag) {
+  // xs = activation stage of this K-step (ring of 3, continuous across tiles); its successor holds the
+  // next step (already requested), the one after receives, in chunk 0, the step TWO ahead:
+  // MODE 0: step k+2 of this tile; MODE 1 (k = nk-2): step 0 of the next tile; MODE 2 (k = nk-1): its step 1.
+  auto kstep = [&](int cur, int xs, const TIn* gsrc, int k1, int k2, const TIn* gnext, bool has_next, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
-    const char* base = lds + cur * G_STAGE_BYTES;
-    const char* nxt = lds + (cur ^ 1) * G_STAGE_BYTES;
-    read_x(base, 0, 1, xb);
-    if (ABL != 2 && !is_w) {                                   // waves 4-7
-      if (MODE <= 1) issue_all(cur ^ 1, gsrc, k1);
-      else if (has_next) issue_all(cur ^ 1, gnext, 0);
+    const char* wbase = lds + cur * G_OP_BYTES;
+    const char* wnxt = lds + (cur ^ 1) * G_OP_BYTES;
+    const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+    const char* xbase = lds + XB + xs * G_OP_BYTES;
+    const char* xnxt = lds + XB + xs1 * G_OP_BYTES;
+    read_x(xbase, 0, 1, xb);
+    if (ABL != 2 && !is_w) {                                   // waves 4-7: activations two steps ahead
+      if (MODE == 0) issue_all(xs2, gsrc, k2);
+      else if (has_next) issue_all(xs2, gnext, MODE == 1 ? 0 : BK);
     }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
-    read_w(base, 1, w1);
-    read_x(base, 1, 0, xa);
+    read_w(wbase, 1, w1);
+    read_x(xbase, 1, 0, xa);
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    read_x(base, 1, 1, xb);
+    read_x(xbase, 1, 1, xb);
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
+    // every read of this step's stages has completed; the NEXT step's tiles have landed: waves 0-3 wait
+    // for all their DMA, waves 4-7 leave the 8 newest pieces (two steps ahead) in flight
     if (MODE <= 1) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (is_w) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of THIS tile is in flight any more
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) { read_w(nxt, 0, w0); read_x(nxt, 0, 0, xa); }
-    if (ABL != 2 && is_w) {                                    // waves 0-3
+    if (MODE <= 1) { read_w(wnxt, 0, w0); read_x(xnxt, 0, 0, xa); }
+    if (ABL != 2 && is_w) {                                    // waves 0-3: weights one step ahead of the sync
       if (MODE == 0) issue_all(cur, gsrc, k2);
       else if (MODE == 1 && has_next) issue_all(cur, gnext, 0);
     }
@@ -745,8 +757,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int nk = K / BK;
 
   const TIn* gsrc = tile_src(t);
-  issue_all(0, gsrc, 0);
-  int buf = 0;                       // stage that holds K-step 0 of the current tile
+  issue_all(0, gsrc, 0);             // K-step 0: weight stage 0 / activation stage 0
+  if (!is_w) issue_all(1, gsrc, BK); // activations of K-step 1 (nk >= 2)
+  int buf = 0;                       // weight stage that holds K-step 0 of the current tile
+  int xs = 0;                        // activation stage of the current K-step (ring of 3 across tiles)
   bool first = true;
   while (true) {
     const int mt = t / n_tiles, nt = t - mt * n_tiles;
@@ -758,26 +772,35 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
       for (int bb = 0; bb < 8; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // tile prologue: K-step 0 has landed (issued one epilogue ago; the previous tile's stores may fly on)
-    if (first || ABL == 1) {
+    if (first) {
+      if (is_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step 1's activations may still fly
+    } else if (ABL == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (EPI == EPI_BIAS_RES_LN) {
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the fused-LN epilogue ends with 16 row stores
     } else if (sizeof(TOut) == 2) {
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // residual variant: the last slab's 8 stores
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // residual variant: the last half slab's 4 stores
     }
     first = false;
     __builtin_amdgcn_s_barrier();    // also: every wave has left the previous epilogue's LDS slabs
-    read_w(lds + buf * G_STAGE_BYTES, 0, w0);
-    read_x(lds + buf * G_STAGE_BYTES, 0, 0, xa);
+    read_w(lds + buf * G_OP_BYTES, 0, w0);
+    read_x(lds + XB + xs * G_OP_BYTES, 0, 0, xa);
     if (ABL != 2 && is_w) issue_all(buf ^ 1, gsrc, BK);      // weight half of step 1 (nk >= 2, see launch_x16)
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, (kt + 2) * BK, gnext, has_next, Mode0{});
-    kstep((buf + kt) & 1, gsrc, (kt + 1) * BK, 0, gnext, has_next, Mode1{});
+    for (; kt + 2 < nk; ++kt) {
+      kstep((buf + kt) & 1, xs, gsrc, (kt + 1) * BK, (kt + 2) * BK, gnext, has_next, Mode0{});
+      xs = xs == 2 ? 0 : xs + 1;
+    }
+    kstep((buf + kt) & 1, xs, gsrc, (kt + 1) * BK, 0, gnext, has_next, Mode1{});
+    xs = xs == 2 ? 0 : xs + 1;
     ++kt;
     const int last = (buf + kt) & 1;
-    kstep(last, gsrc, 0, 0, gnext, has_next, Mode2{});
+    kstep(last, xs, gsrc, 0, 0, gnext, has_next, Mode2{});
+    const int xfree = xs;              // activation stage of the last step: free for the epilogue slabs
+    xs = xs == 2 ? 0 : xs + 1;
 
     if constexpr (EPI == EPI_BIAS_RES_LN) {
       // ---- fused residual + LayerNorm epilogue (K4/K6 tails, modeling_bert.py:289-293, 347-351), all in
@@ -792,9 +815,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       int el = lane, ew = wave;
       asm volatile("" : "+v"(el), "+s"(ew));
       const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
-      char* stage = lds + last * G_STAGE_BYTES;
-      char* slab = stage + ew * 4096;                               // 32 rows x 64 bf16, XOR-swizzled chunks
-      float2* part = reinterpret_cast<float2*>(stage + 32768);      // [8 waves][128 rows] {s1, s2}
+      char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;       // 32 rows x 64 bf16, XOR-swizzled chunks
+      float2* part = reinterpret_cast<float2*>(lds + last * G_OP_BYTES);   // [8 waves][128 rows] {s1, s2}
       const int nbase = nt * G_BN + wn * 64;
       const int mrow0 = mt * G_BM + wm * 128;
       {
@@ -908,31 +930,35 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       buf = last ^ 1;
       continue;
     }
-    // ---- epilogue: 32-token x 64-feature slabs through a wave-private XOR-swizzled LDS slab inside
-    // stage `last` (free since the last barrier), whole-row 16-byte stores.
+    // ---- epilogue: 4 KiB slabs through a wave-private XOR-swizzled LDS slab, whole-row 16-byte stores.
     // The epilogue's lane-constant addressing is recomputed per tile from an opaque copy of the lane
     // id: hoisted out of the tile loop it would stay live across the K-loop and spill (the K-loop
     // already uses ~240 of the 256 registers).
     int el = lane, ew = wave;
     asm volatile("" : "+v"(el), "+s"(ew));
     const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
-    char* slab = lds + last * G_STAGE_BYTES + ew * (32 * OUT_ROW);
+    // slabs: 4 KiB per wave in the activation stage the last K-step has finished with (32 KiB); the
+    // f32 output path therefore moves 16-token half slabs
+    char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;
     const int nbase = nt * G_BN + wn * 64;
     const int row0 = el / CHUNKS, sl = el % CHUNKS;
     f32x4 bv[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+    constexpr int SLAB_ROWS = 4096 / OUT_ROW;          // 32 tokens (bf16) / 16 tokens (f32) per slab
+    constexpr int MB = SLAB_ROWS / 16;                 // MFMA token blocks per slab
+    constexpr int SQ = SLAB_ROWS / ROWS_PER_INST;      // row-contiguous 16-byte instructions per slab (4)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 128 / SLAB_ROWS; ++j) {
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
+      for (int b2 = 0; b2 < MB; ++b2) {
         const int row = 16 * b2 + l15;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int nl = 16 * a + 4 * lq;
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[a][2 * j + b2][e] + bv[a][e];
+          for (int e = 0; e < 4; ++e) v[e] = acc[a][MB * j + b2][e] + bv[a][e];
           if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
@@ -943,20 +969,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         }
       }
       __builtin_amdgcn_wave_barrier();
-      bf16x4 res[EPI == EPI_BIAS_RES ? NQ : 1];
+      bf16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
       if (EPI == EPI_BIAS_RES && ABL != 1) {          // TOut == float: the slab's residual loads in one batch
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
+          const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
           res[q] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
         }
       }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
+      for (int q = 0; q < SQ; ++q) {
         const int row = q * ROWS_PER_INST + row0;
         const int c = sl ^ (row & (CHUNKS - 1));
-        const int m = mt * G_BM + wm * 128 + 32 * j + row;
+        const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
         f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
         if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
         if (EPI == EPI_BIAS_RES) {
