@@ -411,180 +411,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ping-pong variant of the 256x256 kernel (MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3
-// (group A) and their SIMD partners 4-7 (group B) run the same K-step half a step apart.  A K-step
-// of a wave is a LOAD segment (all 24 ds_read_b128 of the step into registers, plus DMA issue) and a
-// COMPUTE segment (32 MFMAs on registers only), each ended by s_barrier; while one wave of a SIMD
-// computes, its partner loads, so the matrix pipe always has a feeder and LDS/DMA issue is hidden.
-//   segment:        2k              2k+1            2k+2             2k+3
-//   group A:     LOAD(k)+DMA(k+1)  COMPUTE(k)     LOAD(k+1)+DMA(k+2) COMPUTE(k+1)
-//   group B:     COMPUTE(k-1)+DMA(k+1)  LOAD(k)   COMPUTE(k)+DMA(k+2)  LOAD(k+1)
-// Stage k%2 is read in segments 2k (A) and 2k+1 (B); both groups issue their half of DMA(j) in
-// segment 2j-2 (the stage was last read in 2j-4, 2j-3) and wait vmcnt(0) before the barrier that
-// ends segment 2j-1, so the data is visible from segment 2j on.
-template <typename TIn, typename TOut, int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(
-    const TIn* __restrict__ X, const TIn* __restrict__ W, const float* __restrict__ bias,
-    const TIn* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
-    int n_tiles) {
-  constexpr int EPC = 16 / sizeof(TIn);
-  constexpr int BK = ROW_BYTES / sizeof(TIn);
-  typedef typename Frag<TIn>::type frag_t;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
-
-  const int nwg = gridDim.x, b = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int mt = t / n_tiles, nt = t - mt * n_tiles;
-  const int M = *m_total;
-  if (mt * G_BM >= M) return;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rr = lane & 31, h = lane >> 5;
-  const int wn = wave & 3, wm = wave >> 2;          // wm is also the ping-pong group
-
-  const bool is_w = wave < 4;                        // group A brings the weight tile, B the activations
-  const int prow0 = 64 * (wave & 3);
-  const TIn* gbase = is_w ? W + (size_t)(nt * G_BN + prow0) * K : X + (size_t)(mt * G_BM + prow0) * K;
-  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
-  const int lrow = lane >> 3;
-  int voff[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-    voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
-  auto issue_all = [&](int buf, int k0) {
-    char* base = lds + buf * G_STAGE_BYTES + ldst0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gbase + (size_t)(8 * i) * K + k0 + voff[i & 1]),
-                                       LDS_PTR(base + i * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int swz = (rr >> 1) & 7;
-  const int woff = (wn * 64 + rr) * ROW_BYTES;
-  const int xoff = G_OP_BYTES + (wm * 128 + rr) * ROW_BYTES;
-  frag_t wf[4][2], xf[4][4];
-  auto load_seg = [&](int buf) {
-    const char* base = lds + buf * G_STAGE_BYTES;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const int coff = ((2 * kc + h) ^ swz) << 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[kc][i] = *reinterpret_cast<const frag_t*>(base + woff + i * 32 * ROW_BYTES + coff);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[kc][j] = *reinterpret_cast<const frag_t*>(base + xoff + j * 32 * ROW_BYTES + coff);
-    }
-  };
-  auto compute_seg = [&]() {
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) mma_chunk<TIn>(wf[kc][i], xf[kc][j], acc[i][j]);
-  };
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-  const int nk = K / BK;
-  issue_all(0, 0);
-  if (nk > 1) {
-    issue_all(1, BK);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else {
-    PP_WAIT_VM0();
-  }
-  PP_BARRIER();                                        // every wave's DMA(0) is in LDS
-  if (wm == 0) {                                       // ---- group A
-    for (int k = 0; k < nk; ++k) {
-      load_seg(k & 1);
-      if (k >= 1 && k + 1 < nk) issue_all((k + 1) & 1, (k + 1) * BK);
-      PP_BARRIER();                                    // end of segment 2k
-      compute_seg();
-      PP_WAIT_VM0();                                   // own DMA(k+1) landed
-      PP_BARRIER();                                    // end of segment 2k+1
-    }
-  } else {                                             // ---- group B (half a K-step behind)
-    PP_BARRIER();                                      // end of segment 0
-    for (int k = 0; k < nk; ++k) {
-      load_seg(k & 1);
-      PP_WAIT_VM0();                                   // own DMA(k+1) landed (issued in segment 2k)
-      PP_BARRIER();                                    // end of segment 2k+1
-      if (k + 2 < nk) issue_all(k & 1, (k + 2) * BK);
-      compute_seg();
-      if (k + 1 < nk) PP_BARRIER();                    // end of segment 2k+2
-    }
-  }
-#undef PP_BARRIER
-#undef PP_WAIT_VM0
-
-  // ---- epilogue (as in gemm_tn_big_kernel): slabs through wave-private LDS, whole-row 16-byte stores.
-  // After the last common barrier nobody reads the K-loop stages and no DMA is outstanding.
-  constexpr int OUT_ROW = 64 * sizeof(TOut);
-  constexpr int CHUNKS = OUT_ROW / 16;
-  constexpr int OPC = 16 / sizeof(TOut);
-  char* slab = lds + wave * (32 * OUT_ROW);
-  const int nbase = nt * G_BN + wn * 64;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = 32 * i + 8 * g + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + nbase + nl);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_for<TIn>(v[e]);
-        }
-        const int c = nl / OPC;
-        const int off = rr * OUT_ROW + ((c ^ (rr & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * h : 0);
-        store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    constexpr int ROWS_PER_INST = 64 / CHUNKS;
-    constexpr int NQ = 32 / ROWS_PER_INST;
-    const int row0 = lane / CHUNKS, sl = lane % CHUNKS;
-    float res[EPI == EPI_BIAS_RES ? NQ : 1][4];
-    if (EPI == EPI_BIAS_RES && ABL != 1) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int row = q * ROWS_PER_INST + row0;
-        const int m = min(mt * G_BM + wm * 128 + 32 * j + row, M - 1);
-        load4<TIn>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC, res[q]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int row = q * ROWS_PER_INST + row0;
-      const int c = sl ^ (row & (CHUNKS - 1));
-      const int m = mt * G_BM + wm * 128 + 32 * j + row;
-      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
-      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
-      if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) raw[e] += res[q][e];
-      }
-      if (m < M)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // bf16 production kernel: the 256x256 / 8-wave / 2-stage structure of gemm_tn_big_kernel on
 // v_mfma_f32_16x16x32_bf16, PERSISTENT over tiles.
 //  * MFMA shape: on MI355X with random operands a register-only MFMA loop sustains 2.04 PFLOP/s with
