@@ -120,6 +120,55 @@ def test_encoder_padding_and_order_invariance_full_size():
     enc.status()
 
 
+def test_table_mode_equals_reference_faithful_mode_at_size():
+    """Domain property at the bert-base shape: scoring impressions through the per-news table
+    (each unique news encoded once) gives bit-identical scores and rankings to encoding every history and
+    candidate occurrence (what CRModule.forward does), because a CLS row does not depend on its batch."""
+    enc, cfg = _encoder("bert-base-uncased", 42, 0.02)
+    n_news = 4000
+    ids, mask = synth_news_tokens(n_news, cfg, seed=31, profile="title_abstract")
+    lens = mask.sum(1)
+    imp = synth_impressions(96, n_news, seed=31)
+    dids, dmask = _cuda(ids), _cuda(mask)
+    table = hotpath.encode_table(enc, dids, dmask, precision="bf16", host_lengths=lens)
+    dimp = {k: _cuda(v) for k, v in imp.items() if k != "labels"}
+    t_res = hotpath.score_impressions([table], dimp, labels=_cuda(imp["labels"]), k=10)
+    occ = np.concatenate([imp["hist_idx"], imp["cand_idx"]]).astype(np.int64)
+    occ_d = _cuda(occ)
+    r_table = enc.encode_cls(dids[occ_d], dmask[occ_d], precision="bf16", host_lengths=lens[occ])
+    nh = imp["hist_idx"].shape[0]
+    r_scores = hip.score_late_fusion(r_table, torch.arange(nh, dtype=torch.int32, device=DEV), dimp["hist_off"],
+                                     torch.arange(nh, occ.shape[0], dtype=torch.int32, device=DEV), dimp["cand_off"])
+    assert torch.equal(r_scores, t_res["scores"])
+    r_top, r_ndcg = hip.rank_ndcg(r_scores, _cuda(imp["labels"]), dimp["cand_off"], 10)
+    assert torch.equal(r_top, t_res["topk"]) and torch.equal(r_ndcg, t_res["ndcg"])
+    enc.status()
+
+
+def test_encode_cls_is_graph_capturable():
+    """The path has no host synchronisation or allocation inside: one encode_cls call (device-side lengths,
+    no host_lengths) can be captured into a HIP graph and replayed on new inputs."""
+    enc, cfg = _encoder("tiny-bert", 7, 0.05)
+    ids_a, mask_a = synth_news_tokens(64, cfg, seed=1, max_len=40, pad_to=40)
+    ids_b, mask_b = synth_news_tokens(64, cfg, seed=2, max_len=40, pad_to=40)
+    ids, mask = _cuda(ids_a), _cuda(mask_a)
+    out = torch.empty((64, cfg.hidden), dtype=torch.float32, device=DEV)
+    eager_a = enc.encode_cls(ids, mask, precision="bf16").clone()           # also sizes the workspace
+    eager_b = enc.encode_cls(_cuda(ids_b), _cuda(mask_b), precision="bf16").clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        enc.encode_cls(ids, mask, precision="bf16", out=out)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager_a)
+    ids.copy_(_cuda(ids_b)); mask.copy_(_cuda(mask_b))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager_b)
+    enc.status()
+
+
 def test_optional_paths_agree_with_default(monkeypatch):
     """Opt-in execution modes (read from the environment at encoder creation): two phase-shifted
     streams run the same kernels (bit-identical); the fused GEMM+LayerNorm epilogue uses a one-pass
