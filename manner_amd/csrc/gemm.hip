@@ -535,22 +535,28 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
     const char* xbase = lds + XB + xs * G_OP_BYTES;
     const char* xnxt = lds + XB + xs1 * G_OP_BYTES;
-    read_x(xbase, 0, 1, xb);
     if (ABL != 2 && !is_w) {                                   // waves 4-7: activations two steps ahead
       if (MODE == 0) issue_all(xs2, gsrc, k2);
       else if (has_next) issue_all(xs2, gnext, MODE == 1 ? 0 : BK);
     }
+    // fragments are read one chunk ahead, each batch issued right AFTER the MFMA cluster of the current
+    // chunk: the lgkmcnt(0) the compiler puts in front of a cluster then waits only for reads that are a
+    // whole cluster old, never for reads issued a moment ago
     __builtin_amdgcn_sched_barrier(0);
     mma16(w0, xa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(xbase, 0, 1, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma16(w0, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
     read_w(wbase, 1, w1);
     read_x(xbase, 1, 0, xa);
     __builtin_amdgcn_sched_barrier(0);
-    mma16(w0, xb, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma16(w1, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_x(xbase, 1, 1, xb);
-    __builtin_amdgcn_sched_barrier(0);
-    mma16(w1, xa, 0);
     __builtin_amdgcn_sched_barrier(0);
     // every read of this step's stages has completed; the NEXT step's tiles have landed: waves 0-3 wait
     // for all their DMA, waves 4-7 leave the 8 newest pieces (two steps ahead) in flight
@@ -562,13 +568,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) { read_w(wnxt, 0, w0); read_x(xnxt, 0, 0, xa); }
     if (ABL != 2 && is_w) {                                    // waves 0-3: weights one step ahead of the sync
       if (MODE == 0) issue_all(cur, gsrc, k2);
       else if (MODE == 1 && has_next) issue_all(cur, gnext, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     mma16(w1, xb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE <= 1) { read_w(wnxt, 0, w0); read_x(xnxt, 0, 0, xa); }
     __builtin_amdgcn_sched_barrier(0);
   };
   typedef std::integral_constant<int, 0> Mode0;
