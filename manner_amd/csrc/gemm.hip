@@ -586,7 +586,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   constexpr int CHUNKS = OUT_ROW / 16;
   constexpr int OPC = 16 / sizeof(TOut);
   constexpr int ROWS_PER_INST = 64 / CHUNKS;
-  constexpr int NQ = 32 / ROWS_PER_INST;
   const int nk = K / BK;
 
   const TIn* gsrc = tile_src(t);
