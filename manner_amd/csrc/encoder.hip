@@ -51,9 +51,10 @@ struct manner_hip_encoder {
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
-  // HBM-bound phases of one chunk overlap the MFMA-bound phases of the other.  Measured +2 % only (the
-  // two streams run the same kernels in lockstep), so it is opt-in: MANNER_HIP_STREAMS=2
-  int n_streams = 1;
+  // HBM-bound phases of one chunk overlap the MFMA-bound phases of the other (the side stream starts half
+  // a layer late; in lockstep the two would just run the same kernels together).  Bit-identical results,
+  // +4 % measured.  MANNER_HIP_STREAMS=1 disables
+  int n_streams = 2;
   bool fuse_ln = false;               // experimental, opt-in: MANNER_HIP_FUSE_LN=1
   hipStream_t side = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -274,6 +275,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
     if (const char* ev = getenv("MANNER_HIP_STREAMS")) e->n_streams = atoi(ev) >= 2 ? 2 : 1;
     if (const char* ev = getenv("MANNER_HIP_FUSE_LN")) e->fuse_ln = atoi(ev) != 0;
+    if (e->fuse_ln) e->n_streams = 1;   // the fused kernel's workgroups wait on each other: never two such grids at once
     if (e->n_streams == 2) {
       if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess ||

@@ -170,22 +170,22 @@ def test_encode_cls_is_graph_capturable():
 
 
 def test_optional_paths_agree_with_default(monkeypatch):
-    """Opt-in execution modes (read from the environment at encoder creation): two phase-shifted
-    streams run the same kernels (bit-identical); the fused GEMM+LayerNorm epilogue uses a one-pass
-    variance and must stay within bf16 noise of the default path."""
+    """Execution modes read from the environment at encoder creation: one stream vs the default two
+    phase-shifted streams run the same kernels (bit-identical); the opt-in fused GEMM+LayerNorm epilogue
+    uses a one-pass variance and must stay within bf16 noise of the default path."""
     cfg = PRESETS["bert-base-uncased"]
     w = make_plm_weights(cfg, seed=42, std=0.02)
     ids, mask = synth_news_tokens(3000, cfg, seed=21, profile="title_abstract")
     base, _ = _encoder("bert-base-uncased", 42, 0.02)
     lens = mask.sum(1)
     ref = base.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
-    monkeypatch.setenv("MANNER_HIP_STREAMS", "2")
+    monkeypatch.setenv("MANNER_HIP_STREAMS", "1")          # the default is two phase-shifted streams
     two = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
     out2 = two.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
     two.status()
     assert torch.equal(ref, out2)
     two.close()
-    monkeypatch.setenv("MANNER_HIP_STREAMS", "1")
+    monkeypatch.delenv("MANNER_HIP_STREAMS")
     monkeypatch.setenv("MANNER_HIP_FUSE_LN", "1")
     fused = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
     out3 = fused.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
