@@ -56,9 +56,10 @@ struct manner_hip_encoder {
   // +4 % measured.  MANNER_HIP_STREAMS=1 disables
   int n_streams = 2;
   bool fuse_ln = false;               // experimental, opt-in: MANNER_HIP_FUSE_LN=1
-  hipStream_t side = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  hipEvent_t phase_ev = nullptr;     // recorded mid-layer in the first chunk: the side stream starts there
+  static constexpr int MAX_STREAMS = 4;
+  hipStream_t side[MAX_STREAMS] = {};      // side[0] unused (the caller's stream)
+  hipEvent_t join_ev[MAX_STREAMS] = {};
+  hipEvent_t phase_ev[MAX_STREAMS] = {};   // recorded mid-layer in the first chunk of stream i: stream i+1 starts there
   // opt-in per-launch timing (manner_hip_encoder_profile)
   bool profiling = false;
   struct Span { hipEvent_t a, b; int cls; };
@@ -236,10 +237,11 @@ int manner_hip_encoder_destroy(manner_hip_encoder_t enc) {
   if (!enc) return MANNER_HIP_OK;
   for (auto& sp : enc->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t ev : enc->free_events) (void)hipEventDestroy(ev);
-  if (enc->side) (void)hipStreamDestroy(enc->side);
-  if (enc->fork_ev) (void)hipEventDestroy(enc->fork_ev);
-  if (enc->join_ev) (void)hipEventDestroy(enc->join_ev);
-  if (enc->phase_ev) (void)hipEventDestroy(enc->phase_ev);
+  for (int i = 0; i < manner_hip_encoder::MAX_STREAMS; ++i) {
+    if (enc->side[i]) (void)hipStreamDestroy(enc->side[i]);
+    if (enc->join_ev[i]) (void)hipEventDestroy(enc->join_ev[i]);
+    if (enc->phase_ev[i]) (void)hipEventDestroy(enc->phase_ev[i]);
+  }
   for (void* p : enc->allocs) (void)hipFree(p);
   delete enc;
   return MANNER_HIP_OK;
@@ -273,18 +275,19 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_EMB_LN_B], H, &e->embb, s))) break;
     if (!guard(dev_alloc(e, 256, (void**)&e->status))) break;
     if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
-    if (const char* ev = getenv("MANNER_HIP_STREAMS")) e->n_streams = atoi(ev) >= 2 ? 2 : 1;
+    if (const char* ev = getenv("MANNER_HIP_STREAMS")) {
+      const int v = atoi(ev);
+      e->n_streams = v < 1 ? 1 : (v > manner_hip_encoder::MAX_STREAMS ? manner_hip_encoder::MAX_STREAMS : v);
+    }
     if (const char* ev = getenv("MANNER_HIP_FUSE_LN")) e->fuse_ln = atoi(ev) != 0;
     if (e->fuse_ln) e->n_streams = 1;   // the fused kernel's workgroups wait on each other: never two such grids at once
-    if (e->n_streams == 2) {
-      if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->phase_ev, hipEventDisableTiming) != hipSuccess) {
+    for (int i = 0; i < e->n_streams && !rc; ++i) {
+      if ((i > 0 && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) ||
+          hipEventCreateWithFlags(&e->join_ev[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->phase_ev[i], hipEventDisableTiming) != hipSuccess)
         rc = fail(MANNER_HIP_E_RUNTIME, "encoder_create: side stream/event creation failed");
-        break;
-      }
     }
+    if (rc) break;
     e->params.resize(L);
     for (int p = 0; p < 2; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
     for (int l = 0; l < L && !rc; ++l) {
@@ -352,10 +355,10 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
     m_cap -= 256;
   }
   if (m_cap < 256 || m_cap < padded_len) return fail(MANNER_HIP_E_WORKSPACE, "encode_cls: workspace of %zu bytes cannot hold one 256-token tile per stream", workspace_bytes);
-  Workspace ws[2];
+  Workspace ws[manner_hip_encoder::MAX_STREAMS];
   for (int i = 0; i < ns; ++i) carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace) + i * ws_each, &ws[i]);
   hipStream_t s0 = (hipStream_t)stream;
-  bool forked = false;
+  int forked = 0;                                       // side streams in use so far
   int64_t n0 = 0;
   int chunk = 0;
   while (n0 < n_news) {
@@ -376,27 +379,24 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
       if (cnt > n_news - n0) cnt = n_news - n0;
       m_bound = round_up(cnt * padded_len, 256);
     }
-    const int lane = ns == 2 ? (chunk & 1) : 0;
-    hipStream_t s = s0;
-    if (lane == 1) {
-      if (!forked) {
-        // the side stream starts when the first chunk on the caller's stream is half a layer in (its
-        // phase mark): from then on the two streams run out of phase, so the HBM-bound kernels of one
-        // (LayerNorm, attention, GEMM epilogues) meet the MFMA-bound main loops of the other
-        MANNER_HIP_TRY(hipStreamWaitEvent(enc->side, enc->phase_ev, 0));
-        forked = true;
-      }
-      s = enc->side;
+    const int lane = chunk % ns;
+    hipStream_t s = lane == 0 ? s0 : enc->side[lane];
+    if (lane > 0 && chunk < ns) {
+      // stream `lane` starts when the first chunk of stream lane-1 is half a layer in (its phase mark): from
+      // then on the streams run out of phase, so the HBM-bound kernels of one (LayerNorm, attention, GEMM
+      // epilogues) meet the MFMA-bound main loops of another
+      MANNER_HIP_TRY(hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0));
+      forked = lane;
     }
     int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
-                          out + n0 * H, ws[lane], s, (ns == 2 && chunk == 0) ? enc->phase_ev : nullptr);
+                          out + n0 * H, ws[lane], s, (ns > 1 && chunk < ns - 1) ? enc->phase_ev[lane] : nullptr);
     if (rc) return rc;
     n0 += cnt;
     ++chunk;
   }
-  if (forked) {                                        // join: the caller's stream waits for the side stream
-    MANNER_HIP_TRY(hipEventRecord(enc->join_ev, enc->side));
-    MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev, 0));
+  for (int i = 1; i <= forked; ++i) {                   // join: the caller's stream waits for every side stream
+    MANNER_HIP_TRY(hipEventRecord(enc->join_ev[i], enc->side[i]));
+    MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev[i], 0));
   }
   return MANNER_HIP_OK;
 }
