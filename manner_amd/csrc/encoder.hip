@@ -343,7 +343,7 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
   // largest (news, tokens) chunk capacity the workspace admits: tokens scale the big buffers.
   // With two streams the workspace is split into two independent halves.
   const int ns = enc->profiling ? 1 : enc->n_streams;   // per-kernel timing wants un-overlapped launches
-  const size_t ws_each = (workspace_bytes / ns) / 256 * 256;
+  const size_t ws_each = (workspace_bytes / enc->n_streams) / 256 * 256;   // same chunk size with or without profiling
   const size_t es = precision == MANNER_HIP_PREC_BF16 ? 2 : 4;
   const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es;
   int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;
