@@ -1,13 +1,14 @@
 // K3: bidirectional multi-head self-attention over packed variable-length news
 // (HF BertSelfAttention / eager_attention_forward, transformers/models/bert/modeling_bert.py:111-136,
 // 188-203; additive padding mask of :704-708).  Tokens are packed, so the padding mask becomes
-// "keys of the same news only"; head_dim is 64 and a news has at most 128 tokens, so the whole
-// score row of a query fits in registers and softmax needs no online rescaling.
+// "keys of the same news only"; head_dim is 64 and a news has at most 128 tokens (<= 4 key tiles).
 //
 // bf16 path — one 64-lane wave per (news, head), no workgroup barriers:
 //   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K rows as the A operand: a lane then owns ONE query
 //                 (column) and 16 keys per 32-key tile, so max / sum are in-lane reductions plus
-//                 one exchange with lane^32;
+//                 one exchange with lane^32; softmax runs ONLINE over the key tiles so that only one
+//                 S^T tile is live and the registers it frees hold the Q fragments of every query
+//                 block (one load phase per wave instead of one exposed round trip per block);
 //   O^T = V^T P^T the S^T accumulators, converted pairwise to bf16, ARE the B operand of the second
 //                 product (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
 //                 operand"), k-order permuted: element j of lane half h is key 16s+8(j>>2)+4h+(j&3);
@@ -48,6 +49,16 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
     for (int ks = 0; ks < 4; ++ks)
       kf[kt][ks] = *reinterpret_cast<const bf16x8*>(Kb + (size_t)key * ld + (2 * ks + h) * 8);
   }
+  // Q fragments of EVERY 32-query block, requested together with K and V: the wave has one load phase
+  // instead of one exposed memory round trip per query block
+  bf16x8 qf[NKT][4];
+#pragma unroll
+  for (int qb = 0; qb < NKT; ++qb) {
+    const int qrow = min(32 * qb + rr, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[qb][ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ld + (2 * ks + h) * 8);
+  }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own V image is in LDS
 
@@ -59,51 +70,60 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
   for (int qb = 0; qb < NKT; ++qb) {
     if (32 * qb >= L) break;
-    const int qrow = min(32 * qb + rr, L - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ld + (2 * ks + h) * 8);
-
-    f32x16 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], s[kt], 0, 0, 0);
-    }
-    // scale (head_dim^-0.5 = 1/8), mask keys of other/padded positions, softmax over keys
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float v = key < L ? s[kt][e] * 0.125f : -INFINITY;
-        s[kt][e] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-    bf16x8 pf[NKT][2];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const bf16_t p = (bf16_t)__expf(s[kt][e] - mx);
-        pf[kt][e >> 3][e & 7] = p;
-        sum += (float)p;               // normalise by the sum of the ROUNDED weights
-      }
-    sum += __shfl_xor(sum, 32, 64);
-
+    // online softmax over the 32-key tiles (one S^T tile = 16 registers live at a time): running max m of
+    // the RAW scores, running sum l, O^T rescaled by exp(m_old - m_new) only when some row's max moved.
+    // The kernel is issue-bound on this VALU work, so it is kept minimal: scale (1/8) and log2(e) are
+    // folded into one FMA in front of v_exp_f32, and only the last key tile is masked.
+    constexpr float C = 0.125f * 1.44269504088896340736f;   // head_dim^-0.5 * log2(e)
+    float m = -INFINITY, l = 0.f;
     f32x16 o[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qb][ks], st, 0, 0, 0);
+      if (kt == NKT - 1) {                             // L > 32 (NKT - 1): earlier tiles hold real keys only
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          st[e] = key < L ? st[e] : -INFINITY;
+        }
+      }
+      float tmx = fmaxf(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])), fmaxf(fmaxf(st[4], st[5]), fmaxf(st[6], st[7])));
+      tmx = fmaxf(tmx, fmaxf(fmaxf(fmaxf(st[8], st[9]), fmaxf(st[10], st[11])), fmaxf(fmaxf(st[12], st[13]), fmaxf(st[14], st[15]))));
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+      const float mn = fmaxf(m, tmx);                  // finite: tile 0 always holds key 0 < L
+      const float nmc = -mn * C;
+      float rs = 0.f;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[e], C, nmc));   // exp((s - max) / 8); 0 for masked keys
+        pf[e >> 3][e & 7] = (bf16_t)p;
+        rs += p;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      if (kt == 0) {
+        l = rs;
+      } else {
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * C);
+        l = l * alpha + rs;
+        if (__any(mn > m)) {                           // wave-uniform: some query's running max moved
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        }
+      }
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const char* a0 = vl + tr_base + (32 * kt + 16 * s2) * 128 + (32 * dt) * 2;
@@ -112,12 +132,13 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[dt], 0, 0, 0);
         }
+      }
     }
     const int q = 32 * qb + rr;
     if (q < L) {
-      const float inv = 1.0f / sum;
+      const float inv = 1.0f / l;
       bf16_t* dst = ctx + (size_t)(tok0 + q) * H + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
