@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
+    p.add_argument("--no-collate", action="store_true", help="skip the device-side collate leg")
     p.add_argument("--no-table", action="store_true", help="skip the table-mode (encode pool once + all-gather) leg")
     return p.parse_args()
 
@@ -131,6 +132,44 @@ def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev, nb=None):
            "sample": f"oracle/manner_oracle.py mode R on the first {nb} impressions "
                      f"({int(ho[-1] + co[-1])} news encodes, {cpu_s:.1f} s, torch {torch.__version__} CPU fp32)"}
     return cpu, par
+
+
+def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
+    """Device-side collate of one step's impressions from the tokenised store: checked against
+    the step's own input tensors, timed with events; algorithmic bytes = 4 B read + 16 B written per token slot
+    (int32 store row -> int64 ids + int64 mask) + 8 B per segment id."""
+    from manner_amd.data.components.mind_rec_dataset import DeviceCollate, NewsStore, ParsedBehaviors
+    store = NewsStore.from_arrays(pool_ids_np, pool_len, cfg.pad_id, device=dev)
+    nb = imp["hist_off"].shape[0] - 1
+    bhv = ParsedBehaviors(np.zeros(nb, np.int64), imp["hist_idx"].astype(np.int32), imp["hist_off"].astype(np.int64),
+                          imp["cand_idx"].astype(np.int32), imp["cand_off"].astype(np.int64), imp["labels"].astype(np.float32))
+    collate = DeviceCollate(store, bhv)
+    rng = range(lo, lo + args.impressions)
+    mb = collate(rng)
+    lp = b.ids.shape[1]
+    same = True
+    off = 0
+    for side in ("x_hist", "x_cand"):
+        ids, mask = mb[side]["text"]["input_ids"], mb[side]["text"]["attention_mask"]
+        m, w = ids.shape
+        same &= bool(torch.equal(ids, b.ids[off:off + m, :w])) and bool(torch.equal(mask, b.mask[off:off + m, :w]))
+        same &= bool((b.mask[off:off + m, w:] == 0).all())
+        off += m
+    same &= off == b.ids.shape[0] and bool(torch.equal(mb["labels"], b.labels))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        mb = collate(rng)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    slots = sum(mb[s]["text"]["input_ids"].numel() for s in ("x_hist", "x_cand"))
+    nbytes = 20 * slots + 8 * (mb["batch_hist"].numel() + mb["batch_cand"].numel())
+    return {"ms_per_batch": ms, "matches_step_inputs": same, "impressions": args.impressions, "token_slots": slots,
+            "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "padded_len": [int(mb[s]["text"]["input_ids"].shape[1]) for s in ("x_hist", "x_cand")],
+            "note": "wall time of DeviceCollate.__call__ incl. host offset slicing and 10 small kernel launches; "
+                    "launch-bound at this batch size, HBM roofline applies to the text kernel only"}
 
 
 def table_mode(args, cfg, enc, pool, rank, world, dev):
@@ -329,6 +368,8 @@ def main():
             "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops_per_launch"]}
     barrier()
 
+    if rank == 0 and not args.no_collate:
+        result["collate"] = collate_leg(args, cfg, imp_all, pool_ids_np, pool_len, batches[-1], lo_r + (n_steps - 1) * args.impressions, dev)
     if not args.no_table:
         tab = table_mode(args, cfg, enc, (pool_ids, pool_mask, pool_len), rank, world, dev)
         if rank == 0:

@@ -213,6 +213,46 @@ int manner_hip_aspect_metrics(const int32_t* topk_idx, const int32_t* cand_aspec
                               int32_t num_classes, float* diversity, float* personalization,
                               manner_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- global AUC
+ * Replaces AUROC(task="binary") — constructed at manner/models/cr_module.py:81 (and ensemble_module.py), fed the
+ * ragged preds / targets of every impression at cr_module.py:267-273; the arithmetic is torchmetrics'
+ * (>=0.11.4, requirements.txt:4): ONE curve over all pairs of the run, not a per-impression mean.
+ *   scores f32 [n], labels f32 [n] (positive iff > 0.5), n < 2^31.
+ *   sigmoid_rule != 0 reproduces torchmetrics' format step: if any score lies outside [0, 1] every score is
+ *   passed through the logistic function (f32) before thresholds are formed, so saturated scores tie.
+ *   auc f64 [1] (device): (2U) / (2 P N), U = #(pos > neg) + #(pos == neg)/2, i.e. the trapezoid area through the
+ *   distinct thresholds; 0 when there is no positive or no negative.
+ *   counts int64 [3] (device, may be NULL): {2U, P, N} — exact integers, so ranks can be combined across
+ *   shards only by re-running on the gathered scores (AUC does not decompose over impressions).
+ * Either of auc / counts may be NULL, not both. */
+size_t manner_hip_auc_workspace_bytes(int64_t n);
+int manner_hip_auc(const float* scores, const float* labels, int64_t n, int32_t sigmoid_rule, void* workspace,
+                   size_t workspace_bytes, double* auc, int64_t* counts, manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- device-side collate
+ * Replaces the per-step host work of MINDCollate.__call__ — manner/data/components/mind_rec_dataset.py:114-137
+ * (pd.concat of the impressions' news rows + tokenizer call + padding) — and of MINDRecDatasetTest.__getitem__
+ * (:87-99, DataFrame.loc per impression).  The news are tokenised ONCE into a device-resident store:
+ *   store_ids int32 [n_news, Ls] (tokenizer output truncated to tokenizer_max_length), store_len int32 [n_news];
+ *   store_ent int32 [n_news, Es] entity indices, store_cnt int32 [n_news]; category / sentiment int32 [n_news],
+ *   sentiment_score f32 [n_news]  (columns of the parsed news frame, mind_dataframe.py:245-246).
+ * `rows` int32 [M] are the store rows of the batch's concatenated history (or candidate) news.
+ *   collate_segments: _make_batch_assignees (:171-174) — seg int64 [total] = repeat_interleave(arange(B), sizes)
+ *                     from the int64 offsets [B+1] (this is MINDRecBatch.batch_hist / batch_cand).
+ *   collate_text    : BatchEncoding of tokenizer(padding=True, truncation=True) (:134-137): ids / mask int64 [M, Lp],
+ *                     Lp = longest news of the batch (the host knows the lengths), pad_id outside, mask 1/0.
+ *   collate_entities: _tokenize_entities (:139-144): int64 [M, E], right-padded with 0 to the batch max E.
+ *   collate_aspects : category / sentiment int64 [M], sentiment_score f32 [M] (:164-168); any output may be NULL. */
+int manner_hip_collate_segments(const int64_t* off, int64_t B, int64_t total, int64_t* seg, manner_hip_stream_t stream);
+int manner_hip_collate_text(const int32_t* store_ids, const int32_t* store_len, int64_t n_news, int32_t Ls,
+                            const int32_t* rows, int64_t M, int32_t Lp, int32_t pad_id, int64_t* ids, int64_t* mask,
+                            manner_hip_stream_t stream);
+int manner_hip_collate_entities(const int32_t* store_ent, const int32_t* store_cnt, int64_t n_news, int32_t Es,
+                                const int32_t* rows, int64_t M, int32_t E, int64_t* out, manner_hip_stream_t stream);
+int manner_hip_collate_aspects(const int32_t* category, const int32_t* sentiment, const float* sentiment_score,
+                               int64_t n_news, const int32_t* rows, int64_t M, int64_t* out_category,
+                               int64_t* out_sentiment, float* out_score, manner_hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

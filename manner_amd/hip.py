@@ -291,3 +291,89 @@ def aspect_metrics(topk: Tensor, cand_aspect: Tensor, cand_off: Tensor, num_clas
         _lib.check(_lib.load().manner_hip_aspect_metrics(_ptr(topk), _ptr(cand_aspect), _ptr(hist_aspect), _ptr(cand_off),
                                                          _ptr(hist_off), nb, k, num_classes, _ptr(div), _ptr(pers), _stream()))
     return div, pers
+
+
+def auc(scores: Tensor, labels: Tensor, sigmoid_rule: bool = True, return_counts: bool = False):
+    """Global binary AUC over every (score, label) pair — torchmetrics ``AUROC(task="binary")`` as the
+    reference feeds it (cr_module.py:81, :267-273).  Returns a float64 scalar tensor on the device (and, with
+    ``return_counts``, the exact int64 triple ``[2U, P, N]``)."""
+    scores = _dev(scores, torch.float32, "scores").contiguous().reshape(-1)
+    labels = _dev(labels, torch.float32, "labels").contiguous().reshape(-1)
+    n = scores.numel()
+    if labels.numel() != n or n == 0:
+        raise ValueError("auc: scores and labels must be non-empty and of equal size")
+    lib = _lib.load()
+    ws_bytes = lib.manner_hip_auc_workspace_bytes(n)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=scores.device)
+    out = torch.empty((1,), dtype=torch.float64, device=scores.device)
+    counts = torch.empty((3,), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(lib.manner_hip_auc(_ptr(scores), _ptr(labels), n, int(bool(sigmoid_rule)), _ptr(ws), ws_bytes, _ptr(out),
+                                      _ptr(counts), _stream()))
+    return (out[0], counts) if return_counts else out[0]
+
+
+# ---------------------------------------------------------------- device-side collate (SURVEY §8f rank 2)
+def collate_segments(off: Tensor) -> Tensor:
+    """``repeat_interleave(arange(B), sizes)`` from int64 offsets [B+1] (reference _make_batch_assignees,
+    mind_rec_dataset.py:171-174).  ``off[-1]`` is read on the host once to size the output."""
+    off = _dev(off, torch.int64, "off").contiguous()
+    nb = off.numel() - 1
+    total = int(off[-1]) if nb > 0 else 0
+    seg = torch.empty((total,), dtype=torch.int64, device=off.device)
+    with torch.cuda.device(off.device):
+        _lib.check(_lib.load().manner_hip_collate_segments(_ptr(off), nb, total, _ptr(seg), _stream()))
+    return seg
+
+
+def collate_segments_sized(off: Tensor, total: int) -> Tensor:
+    """As ``collate_segments`` when the host already knows ``off[-1]`` (no device read)."""
+    off = _dev(off, torch.int64, "off").contiguous()
+    seg = torch.empty((total,), dtype=torch.int64, device=off.device)
+    with torch.cuda.device(off.device):
+        _lib.check(_lib.load().manner_hip_collate_segments(_ptr(off), off.numel() - 1, total, _ptr(seg), _stream()))
+    return seg
+
+
+def collate_text(store_ids: Tensor, store_len: Tensor, rows: Tensor, padded_len: int, pad_id: int):
+    """BatchEncoding tensors (ids, mask: int64 [M, padded_len]) of the store rows ``rows``."""
+    store_ids = _dev(store_ids, torch.int32, "store_ids").contiguous()
+    store_len = _dev(store_len, torch.int32, "store_len").contiguous()
+    rows = _dev(rows, torch.int32, "rows").contiguous()
+    m = rows.numel()
+    ids = torch.empty((m, padded_len), dtype=torch.int64, device=rows.device)
+    mask = torch.empty((m, padded_len), dtype=torch.int64, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(_lib.load().manner_hip_collate_text(_ptr(store_ids), _ptr(store_len), store_ids.shape[0], store_ids.shape[1],
+                                                       _ptr(rows), m, padded_len, pad_id, _ptr(ids), _ptr(mask), _stream()))
+    return ids, mask
+
+
+def collate_entities(store_ent: Tensor, store_cnt: Tensor, rows: Tensor, width: int) -> Tensor:
+    """Entity index matrix int64 [M, width], right-padded with 0 (reference _tokenize_entities)."""
+    store_ent = _dev(store_ent, torch.int32, "store_ent").contiguous()
+    store_cnt = _dev(store_cnt, torch.int32, "store_cnt").contiguous()
+    rows = _dev(rows, torch.int32, "rows").contiguous()
+    m = rows.numel()
+    out = torch.empty((m, width), dtype=torch.int64, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(_lib.load().manner_hip_collate_entities(_ptr(store_ent), _ptr(store_cnt), store_ent.shape[0],
+                                                           store_ent.shape[1], _ptr(rows), m, width, _ptr(out), _stream()))
+    return out
+
+
+def collate_aspects(category: Tensor, sentiment: Tensor, sentiment_score: Tensor, rows: Tensor):
+    """category / sentiment int64 [M] and sentiment_score float32 [M] of the store rows ``rows``."""
+    category = _dev(category, torch.int32, "category").contiguous()
+    sentiment = _dev(sentiment, torch.int32, "sentiment").contiguous()
+    sentiment_score = _dev(sentiment_score, torch.float32, "sentiment_score").contiguous()
+    rows = _dev(rows, torch.int32, "rows").contiguous()
+    m = rows.numel()
+    ocat = torch.empty((m,), dtype=torch.int64, device=rows.device)
+    osent = torch.empty((m,), dtype=torch.int64, device=rows.device)
+    oscore = torch.empty((m,), dtype=torch.float32, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(_lib.load().manner_hip_collate_aspects(_ptr(category), _ptr(sentiment), _ptr(sentiment_score),
+                                                          category.numel(), _ptr(rows), m, _ptr(ocat), _ptr(osent), _ptr(oscore),
+                                                          _stream()))
+    return ocat, osent, oscore

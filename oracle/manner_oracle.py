@@ -268,6 +268,32 @@ def mrr(scores: Tensor, target: Tensor, offsets: Sequence[int]) -> Tuple[float, 
     return float(per_t.mean()) if per else 0.0, per_t
 
 
+def binary_auroc(scores: Tensor, target: Tensor, sigmoid_rule: bool = True) -> Tuple[float, Tuple[int, int, int]]:
+    """AUROC(task="binary") restated (constructed at reference cr_module.py:81; torchmetrics >= 0.11.4,
+    requirements.txt:4, not installed here — SURVEY.md §8c "[external]"): ONE ROC curve over all pairs.
+    Format step: if any pred lies outside [0, 1] all preds go through ``sigmoid``.  Curve: preds sorted
+    descending, one point per DISTINCT threshold (cumulative tps / fps), origin prepended, trapezoid area;
+    no positive or no negative -> 0.  The trapezoid is evaluated in float64 here (torchmetrics uses float32
+    ratios, i.e. agrees to ~1e-7).  Also returns the exact integers (2U, P, N) of the equivalent
+    Mann-Whitney form, U = #(pos > neg) + #(pos == neg) / 2."""
+    p = scores.detach().reshape(-1).to(torch.float32)
+    t = (target.detach().reshape(-1) > 0.5).to(torch.int64)
+    if sigmoid_rule and not bool(torch.all((p >= 0) & (p <= 1))):
+        p = p.sigmoid()
+    order = torch.argsort(p, descending=True, stable=True)
+    p, t = p[order], t[order]
+    last = torch.cat([torch.nonzero(p[1:] - p[:-1]).reshape(-1), torch.tensor([p.numel() - 1])])   # end of each tie run
+    tps = torch.cumsum(t, 0)[last]
+    fps = 1 + last - tps
+    n_pos, n_neg = int(tps[-1]), int(fps[-1])
+    tps0 = torch.cat([torch.zeros(1, dtype=torch.int64), tps])
+    fps0 = torch.cat([torch.zeros(1, dtype=torch.int64), fps])
+    twice_u = int(((fps0[1:] - fps0[:-1]) * (tps0[1:] + tps0[:-1])).sum())        # trapezoid, scaled by 2 P N
+    if n_pos == 0 or n_neg == 0:
+        return 0.0, (twice_u, n_pos, n_neg)
+    return twice_u / (2.0 * n_pos * n_neg), (twice_u, n_pos, n_neg)
+
+
 def diversity_at_k(scores: Tensor, cand_aspect: Tensor, cand_off: Sequence[int], num_classes: int, k: int) -> Tensor:
     """Diversity@k per impression: reference manner/metrics/functional.py:8-28 inside the grouping of
     torchmetrics RetrievalMetric.compute (``if not mini_target.sum()`` -> 0, empty_target_action='neg')."""
@@ -331,3 +357,62 @@ def reference_faithful_scores(ids: Tensor, mask: Tensor, hist_idx: Tensor, hist_
     hv, cv = enc(_t(hist_idx).long()), enc(_t(cand_idx).long())
     bh, bc = offsets_to_batch(hist_off), offsets_to_batch(cand_off)
     return ragged(cr_scores(hv, bh, cv, bc, late_fusion=True), bc)
+
+
+# ---------------------------------------------------------------------------------------------- collate
+def make_batch_assignees(items: Sequence[Sequence]) -> Tensor:
+    """reference manner/data/components/mind_rec_dataset.py:171-174"""
+    sizes = torch.tensor([len(x) for x in items], dtype=torch.int64)
+    return torch.repeat_interleave(torch.arange(len(items)), sizes)
+
+
+def load_behaviors_frame(path: str, uid2index=None):
+    """The reference's two read paths for a behaviours file, restated with pandas (mind_dataframe.py:278-288 for
+    the cached frame, :291-357 for raw behaviors.tsv).  Returns columns user / history / candidates / labels."""
+    import pandas as pd
+    with open(path) as f:
+        first = f.readline().rstrip("\n").split("\t")
+    if first[:4] == ["user", "history", "candidates", "labels"]:
+        return pd.read_table(path, converters={
+            "history": lambda x: x.strip("[]").replace("'", "").split(", "),
+            "candidates": lambda x: x.strip("[]").replace("'", "").split(", "),
+            "labels": lambda x: list(map(int, x.strip("[]").split(", ")))})
+    names = ["impid", "uid", "time", "history", "impressions"]
+    b = pd.read_table(path, header=None, names=names, usecols=range(len(names)))
+    b["history"] = b["history"].fillna("").str.split()
+    b["impressions"] = b["impressions"].str.split()
+    b["candidates"] = b["impressions"].apply(lambda x: [i.split("-")[0] for i in x])
+    b["labels"] = b["impressions"].apply(lambda x: [int(i.split("-")[1]) for i in x])
+    b = b[b["history"].apply(len) > 0].reset_index(drop=True)
+    b["user"] = b["uid"].apply(lambda x: (uid2index or {}).get(x, 0))
+    return b[["user", "history", "candidates", "labels"]]
+
+
+def collate(news: dict, batch_rows: Sequence[dict], max_history_length: int, pad_id: int) -> dict:
+    """MINDRecDatasetTest.__getitem__ + MINDCollate.__call__ (mind_rec_dataset.py:87-99, 114-168) with the tokenizer
+    replaced by its stored output: ``news[nid] = {"tokens": [...], "entities": [...], "category", "sentiment",
+    "sentiment_score"}``; ``batch_rows`` = behaviour rows {"user", "history", "candidates", "labels"}.
+    Padding follows tokenizer(padding=True): to the longest news of the concatenated frame; entities are
+    right-padded with 0 to the longest list (F.pad, :141-143)."""
+    def side(id_lists):
+        flat = [news[n] for ids in id_lists for n in ids]
+        lp = max((len(r["tokens"]) for r in flat), default=0)
+        ids = torch.full((len(flat), lp), pad_id, dtype=torch.int64)
+        mask = torch.zeros((len(flat), lp), dtype=torch.int64)
+        for i, r in enumerate(flat):
+            ids[i, :len(r["tokens"])] = torch.tensor(r["tokens"], dtype=torch.int64)
+            mask[i, :len(r["tokens"])] = 1
+        width = max((len(r["entities"]) for r in flat), default=0)
+        ent = torch.zeros((len(flat), width), dtype=torch.int64)
+        for i, r in enumerate(flat):
+            ent[i, :len(r["entities"])] = torch.tensor(r["entities"], dtype=torch.int64)
+        return {"text": {"input_ids": ids, "attention_mask": mask}, "entities": ent,
+                "category": torch.tensor([r["category"] for r in flat], dtype=torch.int64),
+                "sentiment": torch.tensor([r["sentiment"] for r in flat], dtype=torch.int64),
+                "sentiment_score": torch.tensor([r["sentiment_score"] for r in flat], dtype=torch.float32)}
+    hist = [list(r["history"])[:max_history_length] for r in batch_rows]
+    cand = [list(r["candidates"]) for r in batch_rows]
+    return {"batch_hist": make_batch_assignees(hist), "batch_cand": make_batch_assignees(cand),
+            "x_hist": side(hist), "x_cand": side(cand),
+            "labels": torch.tensor([l for r in batch_rows for l in r["labels"]], dtype=torch.float32),
+            "users": torch.tensor([int(r["user"]) for r in batch_rows], dtype=torch.int64)}

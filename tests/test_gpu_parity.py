@@ -451,3 +451,80 @@ def test_scorer_linearity_full_size():
         u = tc[imp_np["hist_idx"][ho[i]:ho[i + 1]].astype(np.int64)].sum(0) / float(ho[i + 1] - ho[i])
         ref = tc[imp_np["cand_idx"][co[i]:co[i + 1]].astype(np.int64)] @ u
         assert (s1[co[i]:co[i + 1]].cpu() - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_auc_matches_oracle():
+    """Global AUC (SURVEY §8f rank 1): exact integer Mann-Whitney counts, ties included, bit-equal to the oracle;
+    the sigmoid format step on an integer score grid (saturation ties at |x| >= 17); degenerate label sets."""
+    g = np.random.Generator(np.random.PCG64(5))
+    for n, levels in ((1, 0), (2, 0), (777, 13), (100_003, 0), (1_500_000, 5000)):
+        s = g.random(n).astype(np.float32)
+        if levels:
+            s = (np.floor(s * levels) / levels).astype(np.float32)
+        y = (g.random(n) < 0.1).astype(np.float32)
+        if n >= 2:
+            y[0], y[1] = 1.0, 0.0
+        want, cnt = O.binary_auroc(torch.from_numpy(s), torch.from_numpy(y))
+        got, counts = hip.auc(torch.from_numpy(s).cuda(), torch.from_numpy(y).cuda(), return_counts=True)
+        assert tuple(counts.tolist()) == cnt
+        assert float(got) == want
+    s = g.integers(-40, 41, 20_000).astype(np.float32)
+    y = (g.random(20_000) < 0.3).astype(np.float32)
+    for rule in (True, False):
+        want, cnt = O.binary_auroc(torch.from_numpy(s), torch.from_numpy(y), sigmoid_rule=rule)
+        got, counts = hip.auc(torch.from_numpy(s).cuda(), torch.from_numpy(y).cuda(), sigmoid_rule=rule, return_counts=True)
+        assert tuple(counts.tolist()) == cnt and float(got) == want
+    ones = torch.ones(10, device="cuda")
+    assert float(hip.auc(torch.rand(10, device="cuda"), ones)) == 0.0
+    assert float(hip.auc(torch.rand(10, device="cuda"), 0 * ones)) == 0.0
+    # continuous scores with the sigmoid step: device expf vs torch.sigmoid may split a tie differently
+    s = (4 * g.standard_normal(50_000)).astype(np.float32)
+    y = (g.random(50_000) < 0.2).astype(np.float32)
+    want, _ = O.binary_auroc(torch.from_numpy(s), torch.from_numpy(y))
+    assert abs(float(hip.auc(torch.from_numpy(s).cuda(), torch.from_numpy(y).cuda())) - want) < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_collate_matches_oracle(tmp_path):
+    """§8f rank 2: every tensor of the MINDRecBatch built on the device is bit-equal to MINDCollate restated on the
+    host — contiguous and shuffled batches, odd / even padded length, a batch with no entities at all."""
+    from test_host import _toy_behaviors, _toy_news
+    from manner_amd.data.components.mind_rec_dataset import DeviceCollate, NewsStore, parse_behaviors
+    g = np.random.Generator(np.random.PCG64(8))
+    news = _toy_news(g, 300)
+    for n in list(news)[:6]:
+        news[n]["entities"] = []
+    news["N1"]["tokens"] = news["N1"]["tokens"][:2] + [7] * 93 + [102]      # 96 tokens: the store's widest row
+    news["N2"]["tokens"] = [101, 102]
+    news["N4"]["tokens"] = [101] + [9] * 93 + [102]                          # 95: an odd padded length
+    news["N5"]["tokens"] = news["N5"]["tokens"][:3]
+    _, parsed_path, rows = _toy_behaviors(g, news, 64, tmp_path)
+    rows.append({"user": 4, "history": ["N2", "N3"], "candidates": ["N4", "N5", "N2"], "labels": [0, 1, 0]})   # no entities
+    import pandas as pd
+    pd.DataFrame(rows).to_csv(parsed_path, sep="\t", index=False)
+    nids = list(news)
+    store = NewsStore(nids, [news[n]["tokens"] for n in nids], pad_id=0, entities=[news[n]["entities"] for n in nids],
+                      category=[news[n]["category"] for n in nids], sentiment=[news[n]["sentiment"] for n in nids],
+                      sentiment_score=[news[n]["sentiment_score"] for n in nids])
+    bhv = parse_behaviors(parsed_path, store.nid2row, 50)
+    collate = DeviceCollate(store, bhv)
+
+    def check(indices):
+        got = collate(indices)
+        want = O.collate(news, [rows[i] for i in indices], 50, pad_id=0)
+        for key in ("batch_hist", "batch_cand", "labels", "users"):
+            assert got[key].dtype == want[key].dtype and torch.equal(got[key].cpu(), want[key]), key
+        for side in ("x_hist", "x_cand"):
+            for key in ("entities", "category", "sentiment", "sentiment_score"):
+                assert got[side][key].dtype == want[side][key].dtype and torch.equal(got[side][key].cpu(), want[side][key]), (side, key)
+            for key in ("input_ids", "attention_mask"):
+                assert torch.equal(got[side]["text"][key].cpu(), want[side]["text"][key]), (side, key)
+        return got
+
+    check(range(0, 8))
+    check(range(8, 9))
+    check(range(0, len(rows)))
+    check([5, 2, 40, 11, 11, 0])
+    last = check(range(len(rows) - 1, len(rows)))
+    assert last["x_hist"]["entities"].shape == (2, 0) and last["x_cand"]["text"]["input_ids"].shape[1] % 2 == 1

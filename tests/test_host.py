@@ -186,3 +186,58 @@ def test_two_rank_table_allgather_and_impression_sharding_gloo(tmp_path):
     assert torch.allclose(both, ref, atol=1e-4)
     nd, per = O.ndcg_at_k(ref, torch.from_numpy(imp["labels"]), imp["cand_off"].tolist(), 10)
     assert abs(r0["sums"][0].item() / 11 - nd) < 1e-6
+
+
+def _toy_news(g, n, vocab=2000, lmax=96):
+    news = {}
+    for i in range(n):
+        length = int(g.integers(3, lmax + 1))
+        news[f"N{i + 1}"] = {"tokens": [101] + g.integers(1000, vocab, length - 2).tolist() + [102],
+                             "entities": g.integers(1, 500, int(g.integers(0, 7))).tolist(),
+                             "category": int(g.integers(0, 19)), "sentiment": int(g.integers(0, 4)),
+                             "sentiment_score": float(np.float32(g.uniform(-1, 1)))}
+    return news
+
+
+def _toy_behaviors(g, news, n_rows, tmp_path, empty_history_every=5):
+    """Writes the SAME impressions in both wire formats of the reference: raw behaviors.tsv and the cached frame."""
+    import pandas as pd
+    nids = list(news)
+    raw, rows = [], []
+    for i in range(n_rows):
+        h = [] if (i % empty_history_every == 3) else [nids[j] for j in g.integers(0, len(nids), int(g.integers(1, 70)))]
+        c = [nids[j] for j in g.integers(0, len(nids), int(g.integers(1, 40)))]
+        lab = (g.random(len(c)) < 0.2).astype(int).tolist()
+        uid = f"U{int(g.integers(0, 9))}"
+        raw.append("\t".join([str(i + 1), uid, "11/15/2019 8:55:22 AM", " ".join(h), " ".join(f"{n}-{l}" for n, l in zip(c, lab))]))
+        if h:
+            rows.append({"user": {"U1": 1, "U2": 2, "U5": 3}.get(uid, 0), "history": h, "candidates": c, "labels": lab})
+    raw_path, parsed_path = str(tmp_path / "behaviors.tsv"), str(tmp_path / "parsed_behaviors.tsv")
+    with open(raw_path, "w") as f:
+        f.write("\n".join(raw) + "\n")
+    pd.DataFrame(rows).to_csv(parsed_path, sep="\t", index=False)          # reference file_utils.to_tsv
+    return raw_path, parsed_path, rows
+
+
+def test_parse_behaviors_both_wire_formats(tmp_path):
+    """CSR parse == the reference's pandas read paths (restated in the oracle), raw and cached formats."""
+    from manner_amd.data.components.mind_rec_dataset import parse_behaviors
+    import manner_oracle as O
+    g = np.random.Generator(np.random.PCG64(3))
+    news = _toy_news(g, 50)
+    nid2row = {n: i for i, n in enumerate(news)}
+    raw_path, parsed_path, rows = _toy_behaviors(g, news, 40, tmp_path)
+    uid2index = {"U1": 1, "U2": 2, "U5": 3}
+    for path in (raw_path, parsed_path):
+        frame = O.load_behaviors_frame(path, uid2index)
+        got = parse_behaviors(path, nid2row, 50, uid2index)
+        assert len(got) == len(frame) == len(rows)
+        assert got.users.tolist() == frame["user"].tolist()
+        for i in range(len(frame)):
+            h = [nid2row[n] for n in frame["history"][i][:50]]
+            c = [nid2row[n] for n in frame["candidates"][i]]
+            assert got.hist_rows[got.hist_off[i]:got.hist_off[i + 1]].tolist() == h
+            assert got.cand_rows[got.cand_off[i]:got.cand_off[i + 1]].tolist() == c
+            assert got.labels[got.cand_off[i]:got.cand_off[i + 1]].tolist() == [float(x) for x in frame["labels"][i]]
+    with pytest.raises(KeyError):
+        parse_behaviors(["user\thistory\tcandidates\tlabels", "1\t['N1']\t['N999999']\t[1]"], nid2row, 50)

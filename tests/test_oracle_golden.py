@@ -159,3 +159,28 @@ def test_mrr_and_aspect_metrics_hand_examples():
     z = torch.zeros(7, dtype=torch.long)
     assert O.diversity_at_k(scores, z, off, 4, 3).tolist() == [0.0, 0.0]
     assert O.personalization_at_k(scores, z, hist, off, hoff, 4, 3).tolist() == [0.0, 0.0]
+
+
+def test_binary_auroc_against_sklearn_and_brute_force():
+    """The AUROC restatement is pinned by an independent implementation (scikit-learn's roc_auc_score: same
+    trapezoid through distinct thresholds) and by the O(n^2) Mann-Whitney count, with heavy ties."""
+    from sklearn.metrics import roc_auc_score
+    g = np.random.Generator(np.random.PCG64(11))
+    for n, levels in ((50, 7), (400, 40), (3000, 0)):
+        s = g.random(n).astype(np.float32)
+        if levels:
+            s = (np.floor(s * levels) / levels).astype(np.float32)           # many exact ties, all inside [0, 1]
+        y = (g.random(n) < 0.2).astype(np.float32)
+        y[0], y[1] = 1.0, 0.0
+        auc, (u2, p, q) = O.binary_auroc(torch.from_numpy(s), torch.from_numpy(y))
+        pos, neg = s[y > 0.5], s[y <= 0.5]
+        brute = 2 * int((pos[:, None] > neg[None, :]).sum()) + int((pos[:, None] == neg[None, :]).sum())
+        assert (u2, p, q) == (brute, len(pos), len(neg))
+        assert abs(auc - roc_auc_score(y, s)) < 1e-12
+    # format step: scores outside [0, 1] are squashed first, so everything above ~17 ties at 1.0
+    s = torch.tensor([30.0, 25.0, 18.0, 2.0, -1.0, -40.0])
+    y = torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0, 0.0])
+    auc_sig, (u2, p, q) = O.binary_auroc(s, y)
+    auc_raw, _ = O.binary_auroc(s, y, sigmoid_rule=False)
+    assert (p, q) == (3, 3) and u2 == 2 * (1 + 1 + 1 + 1 + 1) + 2 and abs(auc_raw - 5 / 9) < 1e-12 and auc_sig == u2 / 18
+    assert O.binary_auroc(torch.tensor([0.3, 0.6]), torch.tensor([1.0, 1.0]))[0] == 0.0
