@@ -38,7 +38,7 @@ int fail(int code, const char* fmt, ...);   // records the thread-local error te
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
-enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_RES_LN = 3 };
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5 };
 enum DType { DT_F32 = 0, DT_BF16 = 1 };
 
 // Y[m, n] = epi( sum_k X[m, k] * W[n, k] + bias[n] )  for m < *m_total (device scalar).
@@ -49,14 +49,14 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
             hipStream_t stream);
 
-// bf16 only: Y = LayerNorm(X W^T + bias + Y) * gamma + beta, in place on the residual stream Y [m_bound, N]
-// (K4 / K6 in one launch).  The N/256 column-tile workgroups of a 256-row panel exchange row sums
-// through `sync`: m_bound/256 arrival counters (zeroed here per call), then per row and column tile
-// one {sum, sum of squares} f32 slot (deterministic: summed in tile order, no float atomics).  N % 256 == 0.  `status` |= 4 if a bounded wait expires.
-size_t gemm_ln_sync_bytes(int64_t m_bound, int N);
-int gemm_tn_ln(const void* X, const void* W, const float* bias, void* Y, const float* gamma, const float* beta,
-               float eps, void* sync, int64_t m_bound, int N, int K, const int* m_total, int32_t* status,
-               hipStream_t stream);
+// Deferred-LayerNorm GEMMs (bf16 in/out, 256x256 tiles: N % 256 == 0, m_bound % 256 == 0, K >= 128).  The residual
+// stream holds pre-LayerNorm sums `raw` plus per-row {mean, rstd} (`mr`, float2 [m_bound]):
+//   EPI_NORM / EPI_NORM_GELU : Y = [gelu]( rstd * (X W'^T - mean * vec) + bias ),  X = raw, W' = gamma-folded weight,
+//                              vec = c1 (column sums of W'), bias = c2 (see fold_layernorm)
+//   EPI_NRES (in place on Y) : Y = X W^T + bias + ((Y - mean) * rstd) * vec,  vec = gamma, bias = b + beta;
+//                              also writes part[m][N/64] = per-wave {sum, sum of squares} of the new rows.
+int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens,
@@ -67,6 +67,21 @@ int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padde
                     void* x, int32_t* status, hipStream_t stream);
 int layernorm_rows(DType out, const float* pre, const float* gamma, const float* beta, int H, float eps,
                    void* x, int64_t m_bound, const int* m_total, hipStream_t stream);
+// ---- deferred LayerNorm helpers (bf16 path)
+// raw[cu[n]+t] = bf16(word + type + pos) and mr = {mean, rstd} of the rounded row (K1 without the normalisation)
+int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
+              const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
+              void* raw, void* mr, int32_t* status, hipStream_t stream);
+// mr[m] = {mean, rstd} from the groups partial sums of row m (fixed summation order)
+int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
+                 hipStream_t stream);
+// dst[n] = bf16(LN(raw[cu[n]])) — the [CLS] rows of the last layer, normalised on the way
+int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
+                  const float* beta, void* dst, hipStream_t stream);
+// pack time: wf[n,k] = bf16(gamma[k] w[n,k]); c1[n] = sum_k wf[n,k]; c2[n] = bias[n] + sum_k beta[k] w[n,k]
+int fold_layernorm(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
+                   float* c1, float* c2, hipStream_t stream);
+int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);
 int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);

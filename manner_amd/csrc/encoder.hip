@@ -8,8 +8,12 @@
 //             ctx = attention(qkv)        (per news, per head)
 //             pre = ctx Wo^T + b + x      (f32)         x = LN(pre)
 //             ffn = gelu(x W1^T + b)                    pre = ffn W2^T + b + x ; x = LN(pre)
-// Activations x/qkv/ctx/ffn are bf16 (MANNER_HIP_PREC_BF16) or f32 (MANNER_HIP_PREC_F32); the
-// pre-LayerNorm sums, LayerNorm statistics, softmax and all accumulation are f32 in both modes.
+// Activations x/qkv/ctx/ffn are bf16 (MANNER_HIP_PREC_BF16) or f32 (MANNER_HIP_PREC_F32); LayerNorm statistics,
+// softmax and all accumulation are f32 in both modes.
+// bf16 with 256-tileable shapes runs the DEFERRED-LayerNorm schedule: no LayerNorm kernel and no f32 `pre`
+// round trip — the residual stream keeps the pre-LayerNorm sums (bf16) plus {mean, rstd} per row, the
+// normalisation is folded into the consuming GEMM (gamma into the weight, mean/rstd into its epilogue) and
+// rebuilt on the fly where the normalised value is the residual (see DlnAux in gemm.hip).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,9 +39,13 @@ struct LayerWeights {
   void* wo = nullptr;     // [H, H]
   void* w1 = nullptr;     // [I, H]
   void* w2 = nullptr;     // [H, I]
+  void* wqkv_f = nullptr; // bf16, deferred LayerNorm: gamma_in o Wqkv   (gamma_in: the LayerNorm feeding this layer)
+  void* w1_f = nullptr;   // bf16, deferred LayerNorm: ln1g o W1
 };
 struct LayerParams {      // f32, shared by both precisions
   float *bqkv, *bo, *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
+  // deferred LayerNorm (see fold_layernorm): column sums / folded biases of wqkv_f and w1_f, residual biases
+  float *cq1 = nullptr, *cq2 = nullptr, *cf1 = nullptr, *cf2 = nullptr, *bo_res = nullptr, *b2_res = nullptr;
 };
 
 }  // namespace manner
@@ -55,7 +63,7 @@ struct manner_hip_encoder {
   // a layer late; in lockstep the two would just run the same kernels together).  Bit-identical results,
   // +4 % measured.  MANNER_HIP_STREAMS=1 disables
   int n_streams = 2;
-  bool fuse_ln = false;               // experimental, opt-in: MANNER_HIP_FUSE_LN=1
+  bool defer_ln = false;              // bf16 deferred-LayerNorm schedule available (folded weights packed); MANNER_HIP_DEFER_LN=0 disables
   static constexpr int MAX_STREAMS = 4;
   hipStream_t side[MAX_STREAMS] = {};      // side[0] unused (the caller's stream)
   hipEvent_t join_ev[MAX_STREAMS] = {};
@@ -114,7 +122,7 @@ struct Workspace {
   float* pre;
   void *x, *qkv, *ctx, *ffn;
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
-  void* ln_sync;                     // row statistics + arrival counters of the fused GEMM+LayerNorm
+  void *mr_in, *mr_mid, *part;       // deferred LayerNorm: {mean, rstd} per row (layer input / after attention), partial sums
 };
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
@@ -134,7 +142,9 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   const size_t n_pad = (size_t)round_up(max_news, 256);
   p = take(n_pad * H * es); if (ws) ws->xcls = p;
   p = take(n_pad * H * es); if (ws) ws->qcls = p;
-  p = take(gemm_ln_sync_bytes(m_cap, (int)H)); if (ws) ws->ln_sync = p;
+  p = take((size_t)m_cap * 8); if (ws) ws->mr_in = p;
+  p = take((size_t)m_cap * 8); if (ws) ws->mr_mid = p;
+  p = take((size_t)m_cap * (H / 64) * 8); if (ws) ws->part = p;
   return off;
 }
 
@@ -150,30 +160,56 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, e->status, s))) return rc;
   }
   const int pos_offset = c.arch == MANNER_HIP_ARCH_ROBERTA ? c.pad_id + 1 : 0;
+#define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
+  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  if (dt == DT_BF16 && e->defer_ln) {
+    // ---- deferred-LayerNorm schedule: ws.x holds the pre-LayerNorm sums, mr_in / mr_mid their row statistics
+    PROF_STEP(MANNER_HIP_PROF_EMBED, embed_raw(ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, H, c.ln_eps, pos_offset,
+                                               c.vocab, c.max_pos, ws.x, ws.mr_in, e->status, s))
+    const int groups = H / 64;
+    for (int l = 0; l < c.layers; ++l) {
+      const LayerWeights& w = e->w[prec][l];
+      const LayerParams& p = e->params[l];
+      const float* g_in = l == 0 ? e->embg : e->params[l - 1].ln2g;     // the LayerNorm that feeds this layer
+      const float* b_in = l == 0 ? e->embb : e->params[l - 1].ln2b;
+      if (l + 1 == c.layers) {
+        // last layer: K|V for every token, everything else on the compact [CLS] rows (plain weights)
+        const int64_t n_bound = round_up(n_news, 256);
+        const int32_t* n_total = ws.m_total + 1;
+        const char* wkv = static_cast<const char*>(w.wqkv_f) + (size_t)H * H * 2;
+        PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, wkv, p.cq2 + H, p.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
+        PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ws.xcls, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, out, n_bound, n_total, s))
+        break;
+      }
+      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, w.wqkv_f, p.cq2, p.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
+      if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, p.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
+    }
+    return MANNER_HIP_OK;
+  }
   {
     ProfScope ps(e, s, MANNER_HIP_PROF_EMBED);
     if ((rc = embed_layernorm(dt, ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, e->embg, e->embb, H, c.ln_eps,
                               pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
       return rc;
   }
-#define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
-  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
-  // The fused GEMM+LayerNorm kernel synchronises the column-tile workgroups of a panel; it needs the
-  // 256-wide tiling (H % 256 == 0) and is not run on two streams at once (two resident-grid kernels
-  // waiting on workgroups of each other could starve).  Measured +0..3 % only (a chain of dependent global
-  // round trips per tile idles the CU), so it stays opt-in: MANNER_HIP_FUSE_LN=1.
-  const bool fuse_ln = dt == DT_BF16 && H % 256 == 0 && e->fuse_ln && (e->profiling || e->n_streams == 1);
   for (int l = 0; l + 1 < c.layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
-    if (fuse_ln) {   // bf16: residual + LayerNorm inside the GEMM epilogue, in place on the residual stream x
-      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_ln(ws.ctx, w.wo, p.bo, ws.x, p.ln1g, p.ln1b, c.ln_eps, ws.ln_sync, m_bound, H, H, ws.m_total, e->status, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_ln(ws.ffn, w.w2, p.b2, ws.x, p.ln2g, p.ln2b, c.ln_eps, ws.ln_sync, m_bound, H, I, ws.m_total, e->status, s))
-      continue;
-    }
     PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
     if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
@@ -279,8 +315,9 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
       const int v = atoi(ev);
       e->n_streams = v < 1 ? 1 : (v > manner_hip_encoder::MAX_STREAMS ? manner_hip_encoder::MAX_STREAMS : v);
     }
-    if (const char* ev = getenv("MANNER_HIP_FUSE_LN")) e->fuse_ln = atoi(ev) != 0;
-    if (e->fuse_ln) e->n_streams = 1;   // the fused kernel's workgroups wait on each other: never two such grids at once
+    // deferred LayerNorm needs every full-size GEMM on the 256x256 kernel: H, 3H, 2H and I multiples of 256
+    e->defer_ln = (precisions & (1u << MANNER_HIP_PREC_BF16)) && H % 256 == 0 && I % 256 == 0;
+    if (const char* ev = getenv("MANNER_HIP_DEFER_LN")) e->defer_ln = e->defer_ln && atoi(ev) != 0;
     for (int i = 0; i < e->n_streams && !rc; ++i) {
       if ((i > 0 && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) ||
           hipEventCreateWithFlags(&e->join_ev[i], hipEventDisableTiming) != hipSuccess ||
@@ -315,6 +352,23 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
         guard(pack_matrix(p, wl[MANNER_HIP_WL_AO_W], HH, W.wo, 0, s));
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF1_W], HI, W.w1, 0, s));
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF2_W], HI, W.w2, 0, s));
+      }
+      if (e->defer_ln && !rc) {
+        // fold the LayerNorm that feeds each GEMM into its weight: the embedding LayerNorm (layer 0) or the
+        // previous layer's output LayerNorm for Q|K|V, this layer's attention-output LayerNorm for FFN1
+        LayerWeights& W = e->w[MANNER_HIP_PREC_BF16][l];
+        const float* g_in = l == 0 ? e->embg : e->params[l - 1].ln2g;
+        const float* b_in = l == 0 ? e->embb : e->params[l - 1].ln2b;
+        if (!guard(dev_alloc(e, 3 * HH * 2, &W.wqkv_f)) || !guard(dev_alloc(e, HI * 2, &W.w1_f))) break;
+        if (!guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.cq1)) || !guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.cq2))) break;
+        if (!guard(dev_alloc(e, (size_t)I * 4, (void**)&P.cf1)) || !guard(dev_alloc(e, (size_t)I * 4, (void**)&P.cf2))) break;
+        if (!guard(dev_alloc(e, (size_t)H * 4, (void**)&P.bo_res)) || !guard(dev_alloc(e, (size_t)H * 4, (void**)&P.b2_res))) break;
+        for (int j = 0; j < 3; ++j)
+          guard(fold_layernorm(wl[MANNER_HIP_WL_Q_W + 2 * j], wl[MANNER_HIP_WL_Q_B + 2 * j], g_in, b_in, H, H,
+                               static_cast<bf16_t*>(W.wqkv_f) + j * HH, P.cq1 + j * H, P.cq2 + j * H, s));
+        guard(fold_layernorm(wl[MANNER_HIP_WL_FF1_W], wl[MANNER_HIP_WL_FF1_B], P.ln1g, P.ln1b, I, H, W.w1_f, P.cf1, P.cf2, s));
+        guard(add_vectors(P.bo, b_in, P.bo_res, H, s));
+        guard(add_vectors(P.b2, P.ln1b, P.b2_res, H, s));
       }
     }
     if (rc) break;

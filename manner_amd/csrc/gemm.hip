@@ -48,6 +48,25 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x|/sqrt2)
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
+// GeLU for the 256x256 bf16 kernel's epilogue, transcendental-free so that the compiler packs it two lanes-elements
+// per instruction (v_pk_fma_f32):  gelu(x) = x/2 + |x| * P(min(|x|, 4.25)),  P ~ erf(t/sqrt2)/2 a degree-8 minimax
+// fit (LP on 3001 nodes, P(4.25) = 1/2 exactly so x > 4.25 gives x and x < -4.25 gives 0).  Max |error| 7.4e-5
+// evaluated in f32 — below the bf16 rounding step (2^-9 relative) of any output above 0.02; the f32 parity
+// mode keeps erff.
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float a = fabsf(x);
+  const float t = fminf(a, 4.25f);
+  float p = -2.944768248e-05f;
+  p = fmaf(p, t, 4.707596855e-04f);
+  p = fmaf(p, t, -2.366253315e-03f);
+  p = fmaf(p, t, -2.697367422e-04f);
+  p = fmaf(p, t, 4.205343857e-02f);
+  p = fmaf(p, t, -1.310204100e-01f);
+  p = fmaf(p, t, 4.837078524e-02f);
+  p = fmaf(p, t, 3.822678287e-01f);
+  p = fmaf(p, t, 1.922160747e-03f);
+  return fmaf(a, p, 0.5f * x);
+}
 template <typename TIn> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return gelu_erf_fast(x); }
@@ -433,20 +452,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
 //    live in the stage the last K-step just finished with; the next tile's first barrier separates
 //    them from its DMA(1), and
 //    the next tile starts with a COUNTED vmcnt that leaves exactly the epilogue's stores in flight.
-struct LnFuse {                       // EPI_BIAS_RES_LN only
-  const float* gamma;
-  const float* beta;
-  unsigned long long* stats;          // [m_bound][N/256] per-tile {sum, sum of squares} packed as two f32
-  int* counters;                      // [m_bound / 256] arrivals of a panel's column tiles
-  int* status;
-  float eps;
+// Deferred LayerNorm (bf16 path): the residual stream holds the PRE-LayerNorm sums `raw` (bf16) plus, per row,
+// {mean, rstd}; LayerNorm itself never runs as a kernel.
+//   consumer GEMM (EPI_NORM / EPI_NORM_GELU), A = raw, W' = gamma o W folded at pack time:
+//       LN(raw) W^T + b  =  rstd * (raw W'^T - mean * c1) + c2,   c1[n] = sum_k W'[n,k],  c2[n] = b[n] + sum_k beta[k] W[n,k]
+//   producer GEMM (EPI_NRES), in place on the residual stream:  raw' = acc + bias + LN(raw), the residual rebuilt in
+//       f32 from raw and its row statistics; each wave also emits the {sum, sum of squares} of its 64 output
+//       columns per row (`part`), reduced to the next {mean, rstd} by dln_finalize (rowops.hip) — fixed order,
+//       no atomics, so results do not depend on scheduling.
+struct DlnAux {
+  const float* vec;       // EPI_NORM*: c1 [N];  EPI_NRES: gamma [N] of the LayerNorm that produced the residual
+  const float2* mr;       // {mean, rstd} per row of the deferred operand (EPI_NORM*: of X;  EPI_NRES: of R)
+  float2* part;           // EPI_NRES: [m_bound][N/64] partial {sum, sum of squares} of the rows written
 };
 
 template <typename TOut, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const bf16_t* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
-    int n_tiles, LnFuse ln) {
+    int n_tiles, DlnAux dln) {
   typedef bf16_t TIn;
   constexpr int EPC = 8, BK = 64;
   // 2 weight stages [0, 64 KiB) + 3 activation stages [64, 160 KiB): the activation tile's first touch
@@ -609,9 +633,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step 1's activations may still fly
     } else if (ABL == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (EPI == EPI_BIAS_RES_LN) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the fused-LN epilogue ends with 16 row stores
-    } else if (sizeof(TOut) == 2) {
+    } else if (sizeof(TOut) == 2) {                       // every bf16 epilogue ends with its 16 row stores
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // residual variant: the last half slab's 4 stores
@@ -634,114 +656,71 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     const int xfree = xs;              // activation stage of the last step: free for the epilogue slabs
     xs = xs == 2 ? 0 : xs + 1;
 
-    if constexpr (EPI == EPI_BIAS_RES_LN) {
-      // ---- fused residual + LayerNorm epilogue (K4/K6 tails, modeling_bert.py:289-293, 347-351), all in
-      // the MFMA register layout (lane = token 16b + l15, features 16a + 4lq .. +3):
-      //   v = acc + bias + residual                      (in place in the accumulators)
-      //   row {sum, sum of squares} over the wave's 64 columns: in-lane + 2 shuffles, over the tile's
-      //   256 columns through LDS, written to this tile's slot stats[m][nt] with write-through stores
-      //   arrive on the panel counter, bounded wait for the panel's other column tiles (every
-      //   workgroup publishes BEFORE it waits and the persistent grid is resident: waits cannot cycle)
-      //   read all N/256 slots in fixed order (deterministic, unlike float atomics)
-      //   y = (v - mean) * rstd * gamma + beta -> bf16 slab -> whole 128-byte row segments.
+    if constexpr (EPI == EPI_NRES) {
+      // ---- residual epilogue of the deferred-LayerNorm path (K4/K6 tails, modeling_bert.py:289-293, 347-351), in
+      // the MFMA register layout (lane = token 16b + l15, features 16a + 4lq .. +3), in place on R == Y:
+      //   v = acc + (bias + beta) + ((raw - mean) * rstd) * gamma        (f32; `bias` already holds bias + beta)
+      //   per row {sum, sum of squares} over the wave's 64 columns -> part[m][4 nt + wn]
+      //   v -> bf16 slab -> whole 128-byte row segments.
       int el = lane, ew = wave;
       asm volatile("" : "+v"(el), "+s"(ew));
       const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
       char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;       // 32 rows x 64 bf16, XOR-swizzled chunks
-      float2* part = reinterpret_cast<float2*>(lds + last * G_OP_BYTES);   // [8 waves][128 rows] {s1, s2}
       const int nbase = nt * G_BN + wn * 64;
       const int mrow0 = mt * G_BM + wm * 128;
+      const int pstride = N >> 6;
       {
-        f32x4 bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
-        // all 32 residual loads of the tile in flight before the first use (the fragment registers of
-        // the K-loop are dead here); issued per token block they would expose the memory latency 8 times
-        bf16x4 res[8][4];
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-          const int m = min(mrow0 + 16 * bb + l15, M - 1);
-#pragma unroll
-          for (int a = 0; a < 4; ++a) res[bb][a] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + 16 * a + 4 * lq);
-        }
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-          float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = acc[a][bb][e] + bv[a][e] + (float)res[bb][a][e];
-              acc[a][bb][e] = x;
-              p1 += x;
-              p2 = fmaf(x, x, p2);
-            }
-          p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
-          p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
-          if (lq == 0) part[ew * 128 + 16 * bb + l15] = float2{p1, p2};
-        }
-      }
-      __syncthreads();
-      if (el < 32) {                                                // 4 waves of a row group: 32 rows each
-        const int row = 32 * wn + el;
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) { const float2 p = part[(wm * 4 + w4) * 128 + row]; a1 += p.x; a2 += p.y; }
-        const int m = mrow0 + row;
-        if (m < M) {
-          const unsigned long long raw = (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32);
-          __hip_atomic_store(ln.stats + (size_t)m * n_tiles + nt, raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's write-through stores are done
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ln.counters + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(ln.counters + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > 400000) { atomicOr(ln.status, 4); break; }    // bounded (~0.1 s): never hang the GPU
-        }
-      }
-      __syncthreads();
-      {
-        float2* mr = part + ew * 128;                               // mean / rstd of the wave's 128 rows
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = 2 * el + i;
-          const int m = min(mrow0 + row, M - 1);
-          float s1 = 0.f, s2 = 0.f;
-          for (int j = 0; j < n_tiles; ++j) {                       // fixed order: bitwise reproducible
-            const unsigned long long raw = __hip_atomic_load(ln.stats + (size_t)m * n_tiles + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += __uint_as_float((unsigned)raw);
-            s2 += __uint_as_float((unsigned)(raw >> 32));
-          }
-          const float mean = s1 / (float)N;
-          const float var = fmaxf(s2 / (float)N - mean * mean, 0.f);
-          mr[row] = float2{mean, 1.0f / sqrtf(var + ln.eps)};
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        f32x4 g4[4], b4[4];
+        f32x4 bv[4], g4[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          g4[a] = *reinterpret_cast<const f32x4*>(ln.gamma + nbase + 16 * a + 4 * lq);
-          b4[a] = *reinterpret_cast<const f32x4*>(ln.beta + nbase + 16 * a + 4 * lq);
+          bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+          g4[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
         }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                 // two halves of 4 token blocks: 32 + 8 load registers live
+          bf16x4 res[4][4];
+          float2 ms[4];
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4) {
+            const int m = min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1);
+            ms[b4] = dln.mr[m];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) res[b4][a] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + 16 * a + 4 * lq);
+          }
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4) {
+            const int bb = 4 * hb + b4;
+            const float rs = ms[b4].y, nm = -ms[b4].x * ms[b4].y;
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float r = fmaf((float)res[b4][a][e], rs, nm);
+                const float x = fmaf(r, g4[a][e], acc[a][bb][e] + bv[a][e]);
+                acc[a][bb][e] = x;
+                p1 += x;
+                p2 = fmaf(x, x, p2);
+              }
+            p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
+            p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
+            const int m = mrow0 + 16 * bb + l15;
+            if (lq == 0 && m < M) dln.part[(size_t)m * pstride + 4 * nt + wn] = float2{p1, p2};
+          }
+        }
+      }
+      {
         const int row0 = el >> 3, sl = el & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int b2 = 0; b2 < 2; ++b2) {
             const int row = 16 * b2 + l15;
-            const float2 ms = mr[32 * j + row];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-              float o[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (acc[a][2 * j + b2][e] - ms.x) * ms.y * g4[a][e] + b4[a][e];
               const int c = (16 * a + 4 * lq) / 8;
-              store4<bf16_t>(reinterpret_cast<bf16_t*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)), o[0], o[1], o[2], o[3]);
+              store4<bf16_t>(reinterpret_cast<bf16_t*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)),
+                             acc[a][2 * j + b2][0], acc[a][2 * j + b2][1], acc[a][2 * j + b2][2], acc[a][2 * j + b2][3]);
             }
           }
           __builtin_amdgcn_wave_barrier();
@@ -777,6 +756,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     f32x4 bv[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+    constexpr bool NORM = EPI == EPI_NORM || EPI == EPI_NORM_GELU;   // deferred LayerNorm of the A operand
+    f32x4 cv[NORM ? 4 : 1];
+    float2 ms[NORM ? 8 : 1];
+    if constexpr (NORM) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cv[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
+#pragma unroll
+      for (int bb = 0; bb < 8; ++bb) ms[bb] = dln.mr[min(mt * G_BM + wm * 128 + 16 * bb + l15, M - 1)];
+    }
     constexpr int SLAB_ROWS = 4096 / OUT_ROW;          // 32 tokens (bf16) / 16 tokens (f32) per slab
     constexpr int MB = SLAB_ROWS / 16;                 // MFMA token blocks per slab
     constexpr int SQ = SLAB_ROWS / ROWS_PER_INST;      // row-contiguous 16-byte instructions per slab (4)
@@ -790,10 +778,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           const int nl = 16 * a + 4 * lq;
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[a][MB * j + b2][e] + bv[a][e];
-          if (EPI == EPI_BIAS_GELU) {
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (NORM) v[e] = fmaf(ms[MB * j + b2].y, fmaf(-ms[MB * j + b2].x, cv[a][e], acc[a][MB * j + b2][e]), bv[a][e]);
+            else v[e] = acc[a][MB * j + b2][e] + bv[a][e];
+          }
+          if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_poly(v[e]);
           }
           const int c = nl / OPC;
           const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
@@ -853,13 +844,13 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
   TOut* y = static_cast<TOut*>(Y);
   switch (epi) {
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_RES:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, LnFuse{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     default:
       return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
@@ -909,30 +900,32 @@ static int device_cus() {
   return n_cus;
 }
 
-size_t gemm_ln_sync_bytes(int64_t m_bound, int N) { return (size_t)(m_bound / G_BM) * 4 + 256 + (size_t)m_bound * (N / G_BN) * 8; }
-
-int gemm_tn_ln(const void* X, const void* W, const float* bias, void* Y, const float* gamma, const float* beta,
-               float eps, void* sync, int64_t m_bound, int N, int K, const int* m_total, int32_t* status,
-               hipStream_t stream) {
-  if (N % G_BN || (K * 2) % ROW_BYTES || m_bound % G_BM || !sync)
-    return fail(MANNER_HIP_E_INVALID, "gemm_ln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
+    return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
   const int n_tiles = N / G_BN;
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
-  // persistent grid, a whole number of panels per round: a panel's column tiles always run in the
-  // same round on neighbouring slots
-  int64_t grid = (device_cus() / n_tiles) * n_tiles;
-  if (grid <= 0) grid = n_tiles;
-  if (tiles < grid) grid = tiles;
-  // only the arrival counters need zeroing; every stats slot is written before it is read
-  const size_t cbytes = (size_t)round_up((m_bound / G_BM) * 4, 256);
-  MANNER_HIP_TRY(hipMemsetAsync(sync, 0, cbytes, stream));
-  LnFuse ln;
-  ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.status = status;
-  ln.counters = static_cast<int*>(sync);
-  ln.stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(sync) + cbytes);
-  hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_BIAS_RES_LN>), dim3((unsigned)grid), dim3(512), 0, stream,
-                     static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(W), bias, static_cast<const bf16_t*>(Y),
-                     static_cast<bf16_t*>(Y), N, K, m_total, n_tiles, ln);
+  const int64_t cus = device_cus();
+  dim3 g((unsigned)(tiles < cus ? tiles : cus)), b(512);
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part)};
+  const bf16_t* x = static_cast<const bf16_t*>(X);
+  const bf16_t* w = static_cast<const bf16_t*>(W);
+  bf16_t* y = static_cast<bf16_t*>(Y);
+  switch (epi) {
+    case EPI_NORM:
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NORM>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+      break;
+    case EPI_NORM_GELU:
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NORM_GELU>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+      break;
+    case EPI_NRES:   // in place: the residual is the output buffer
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NRES>), g, b, 0, stream, x, w, bias, y, y, N, K, m_total, n_tiles, aux);
+      break;
+    default:
+      return fail(MANNER_HIP_E_INVALID, "gemm_dln: epilogue %d", (int)epi);
+  }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -34,11 +34,11 @@ struct HeadFlag {          // flag iterator functor: 1 where a new key value sta
 size_t cub_bytes_for(int64_t n) {
   size_t a = 0, b = 0, c = 0;
   uint32_t* p = nullptr;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
-  hipcub::DeviceScan::ExclusiveSum(nullptr, b, p, p, (int)n);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, p, p, (int)n);
   hipcub::CountingInputIterator<uint32_t> idx(0);
   hipcub::TransformInputIterator<uint32_t, HeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(idx, HeadFlag{p});
-  hipcub::DeviceSelect::Flagged(nullptr, c, idx, flags, p, p, (int)n);
+  (void)hipcub::DeviceSelect::Flagged(nullptr, c, idx, flags, p, p, (int)n);
   return align256(a > b ? (a > c ? a : c) : (b > c ? b : c));
 }
 

@@ -163,6 +163,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   wave_layernorm_store<TOut>(v, H, eps, gamma, beta, x + (size_t)row * H, lane);
 }
 
+// ---- deferred LayerNorm (bf16 path): K1 without the normalisation.  The row is rounded to bf16 first and the
+// statistics are those of the rounded values — exactly what the consuming GEMM reads.
+__global__ __launch_bounds__(256) void embed_raw_kernel(
+    const int64_t* __restrict__ ids, int64_t lp, const int32_t* __restrict__ cu, const float* __restrict__ word,
+    const float* __restrict__ pos, const float* __restrict__ type0, int H, float eps, int pos_offset, int vocab,
+    int max_pos, bf16_t* __restrict__ raw, float2* __restrict__ mr, int32_t* __restrict__ status) {
+  const int64_t n = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int start = cu[n], len = cu[n + 1] - start;
+  for (int t = wave; t < len; t += 4) {
+    int64_t id = ids[n * lp + t];
+    int p = t + pos_offset;
+    if (id < 0 || id >= vocab || p >= max_pos) {
+      if (lane == 0) atomicOr(status, 2);
+      id = 0; p = 0;
+    }
+    const float* wr = word + (size_t)id * H;
+    const float* pr = pos + (size_t)p * H;
+    f32x4 v[VEC_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC_PER_LANE; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wr + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(type0 + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(pr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (float)(bf16_t)((a[e] + b[e]) + d[e]);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        store_vec<bf16_t>(raw + (size_t)(start + t) * H + c, v[i]);
+      }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC_PER_LANE; ++i)
+      if ((i * 64 + lane) * 4 < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    if (lane == 0) mr[start + t] = float2{mean, rstd};
+  }
+}
+
+__global__ __launch_bounds__(256) void dln_finalize_kernel(const float2* __restrict__ part, int groups, float inv_h, float eps,
+                                                           float2* __restrict__ mr, const int* __restrict__ m_total) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= *m_total) return;
+  const float2* p = part + (size_t)m * groups;
+  float s1 = 0.f, s2 = 0.f;
+  for (int g = 0; g < groups; ++g) { const float2 v = p[g]; s1 += v.x; s2 += v.y; }
+  const float mean = s1 * inv_h;
+  const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
+  mr[m] = float2{mean, 1.0f / sqrtf(var + eps)};
+}
+
+__global__ __launch_bounds__(256) void gather_cls_ln_kernel(const bf16_t* __restrict__ raw, const float2* __restrict__ mr,
+                                                            const int32_t* __restrict__ cu, int H, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ dst) {
+  const int64_t n = blockIdx.x;
+  const int64_t row = cu[n];
+  const float2 ms = mr[row];
+  const bf16_t* src = raw + (size_t)row * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[n * H + c] = (bf16_t)(((float)src[c] - ms.x) * ms.y * gamma[c] + beta[c]);
+}
+
+__global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// one wave per output row n of the folded weight
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
+                                                      bf16_t* __restrict__ wf, float* __restrict__ c1, float* __restrict__ c2) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float x = w[(size_t)n * K + k];
+    const bf16_t f = (bf16_t)(gamma[k] * x);
+    wf[(size_t)n * K + k] = f;
+    s1 += (float)f;
+    s2 = fmaf(beta[k], x, s2);
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { c1[n] = s1; c2[n] = bias[n] + s2; }
+}
+
 // ---- K7: out[n] = x[cu[n]] (the [CLS] row), as f32
 template <typename TIn>
 __global__ __launch_bounds__(256) void gather_cls_kernel(const TIn* __restrict__ x, const int32_t* __restrict__ cu,
@@ -223,6 +314,46 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<bf16_t*>(x), m_total);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<float*>(x), m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
+              const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
+              void* raw, void* mr, int32_t* status, hipStream_t stream) {
+  if (H % 4 || H > MAX_H) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported (<= %d, %%4)", H, MAX_H);
+  hipLaunchKernelGGL(embed_raw_kernel, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
+                     eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(raw), static_cast<float2*>(mr), status);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
+                 hipStream_t stream) {
+  hipLaunchKernelGGL(dln_finalize_kernel, dim3((unsigned)((m_bound + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const float2*>(part), groups, 1.0f / (float)H, eps, static_cast<float2*>(mr), m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
+                  const float* beta, void* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_cls_ln_kernel, dim3((unsigned)n_news), dim3(256), 0, stream, static_cast<const bf16_t*>(raw),
+                     static_cast<const float2*>(mr), cu, H, gamma, beta, static_cast<bf16_t*>(dst));
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int fold_layernorm(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
+                   float* c1, float* c2, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, w, bias, gamma, beta, N, K,
+                     static_cast<bf16_t*>(wf), c1, c2);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

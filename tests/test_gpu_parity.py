@@ -171,8 +171,8 @@ def test_encode_cls_is_graph_capturable():
 
 def test_optional_paths_agree_with_default(monkeypatch):
     """Execution modes read from the environment at encoder creation: one stream vs the default two
-    phase-shifted streams run the same kernels (bit-identical); the opt-in fused GEMM+LayerNorm epilogue
-    uses a one-pass variance and must stay within bf16 noise of the default path."""
+    phase-shifted streams run the same kernels (bit-identical); the classic LayerNorm-kernel schedule
+    (MANNER_HIP_DEFER_LN=0) must stay within bf16 noise of the default deferred-LayerNorm schedule."""
     cfg = PRESETS["bert-base-uncased"]
     w = make_plm_weights(cfg, seed=42, std=0.02)
     ids, mask = synth_news_tokens(3000, cfg, seed=21, profile="title_abstract")
@@ -186,19 +186,20 @@ def test_optional_paths_agree_with_default(monkeypatch):
     assert torch.equal(ref, out2)
     two.close()
     monkeypatch.delenv("MANNER_HIP_STREAMS")
-    monkeypatch.setenv("MANNER_HIP_FUSE_LN", "1")
-    fused = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
-    out3 = fused.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
-    fused.status()                                   # raises if a panel wait had expired
-    out3b = fused.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
-    assert torch.equal(out3, out3b)                  # deterministic (fixed-order slot sums, no float atomics)
+    monkeypatch.setenv("MANNER_HIP_DEFER_LN", "0")   # classic schedule: f32 pre-LayerNorm buffer + LayerNorm kernels
+    classic = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
+    out3 = classic.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    classic.status()
+    refb = base.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    assert torch.equal(ref, refb)                    # deferred LayerNorm is deterministic (fixed-order partial sums)
     d = (out3 - ref).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(out3, ref, dim=1).min().item()
-    print(f"fused-LN vs default bf16: max-abs {d:.3e}, min cosine {cos:.6f}")
-    assert d < 0.1 and cos > 0.9995
-    fused.close()
+    print(f"deferred vs classic LayerNorm schedule, bf16: max-abs {d:.3e}, min cosine {cos:.6f}")
+    assert d < 0.2 and cos > 0.9995                  # two bf16 roundings of the same f32 result, each ~5e-2 from it
+    classic.close()
 
 
+@pytest.mark.gpu
 def test_encoder_rejects_bad_mask():
     enc, cfg = _encoder("tiny-bert", 7, 0.05)
     ids, mask = synth_news_tokens(4, cfg, seed=1, lengths=np.array([5, 6, 7, 8]))
