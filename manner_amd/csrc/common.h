@@ -54,7 +54,7 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
 //   EPI_NORM / EPI_NORM_GELU : Y = [gelu]( rstd * (X W'^T - mean * vec) + bias ),  X = raw, W' = gamma-folded weight,
 //                              vec = c1 (column sums of W'), bias = c2 (see fold_layernorm)
 //   EPI_NRES (in place on Y) : Y = X W^T + bias + ((Y - mean) * rstd) * vec,  vec = gamma, bias = b + beta;
-//                              also writes part[m][N/64] = per-wave {sum, sum of squares} of the new rows.
+//                              also writes part[N/64][m_bound] = per-wave {sum, sum of squares} of the new rows.
 int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
 
@@ -72,7 +72,7 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
 int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
               const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
               void* raw, void* mr, int32_t* status, hipStream_t stream);
-// mr[m] = {mean, rstd} from the groups partial sums of row m (fixed summation order)
+// mr[m] = {mean, rstd} from the `groups` partial sums part[g][m] of row m (fixed summation order)
 int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
                  hipStream_t stream);
 // dst[n] = bf16(LN(raw[cu[n]])) — the [CLS] rows of the last layer, normalised on the way

@@ -458,12 +458,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
 //       LN(raw) W^T + b  =  rstd * (raw W'^T - mean * c1) + c2,   c1[n] = sum_k W'[n,k],  c2[n] = b[n] + sum_k beta[k] W[n,k]
 //   producer GEMM (EPI_NRES), in place on the residual stream:  raw' = acc + bias + LN(raw), the residual rebuilt in
 //       f32 from raw and its row statistics; each wave also emits the {sum, sum of squares} of its 64 output
-//       columns per row (`part`), reduced to the next {mean, rstd} by dln_finalize (rowops.hip) — fixed order,
+//       columns per row (`part`, group-major), reduced to the next {mean, rstd} by dln_finalize (rowops.hip) — fixed order,
 //       no atomics, so results do not depend on scheduling.
 struct DlnAux {
   const float* vec;       // EPI_NORM*: c1 [N];  EPI_NRES: gamma [N] of the LayerNorm that produced the residual
   const float2* mr;       // {mean, rstd} per row of the deferred operand (EPI_NORM*: of X;  EPI_NRES: of R)
-  float2* part;           // EPI_NRES: [m_bound][N/64] partial {sum, sum of squares} of the rows written
+  float2* part;           // EPI_NRES: [N/64][m_bound] partial {sum, sum of squares} of the rows written (group-major:
+                          // a wave's 16 rows per store instruction are one contiguous 128-byte line)
+  int64_t part_stride;    // m_bound
 };
 
 template <typename TOut, int EPI, int ABL = 0>
@@ -668,25 +670,58 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;       // 32 rows x 64 bf16, XOR-swizzled chunks
       const int nbase = nt * G_BN + wn * 64;
       const int mrow0 = mt * G_BM + wm * 128;
-      const int pstride = N >> 6;
-      {
+      if (ABL == 1) {                                  // lab: main loop only
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) asm volatile("" ::"v"(acc[a][bb]));
+      } else {
         f32x4 bv[4], g4[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
           g4[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
         }
+        // The residual is fetched as whole 128-byte row segments (16 B per lane, the same coalesced shape as the
+        // output stores) and turned into the MFMA layout through two wave-private 4 KiB LDS slabs: 8-byte loads
+        // straight in the MFMA layout touch 16 rows per instruction and cost ~10 us per tile in the address path.
+        char* rslab0 = slab;                                          // 32 rows each, XOR-swizzled 16-byte chunks
+        char* rslab1 = lds + last * G_OP_BYTES + ew * 4096;           // the weight stage of the last K-step is free too
+        const int rrow0 = el >> 3, rsl = el & 7;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {                 // two halves of 4 token blocks: 32 + 8 load registers live
+        for (int hb = 0; hb < 2; ++hb) {                 // two halves of 4 token blocks (64 rows = two slabs); keeping
+          f32x4 rawres[2][4];                            // more loads in flight (all 16, or half 1 under half 0's
+          float2 ms[4];                                  // arithmetic) measured 15 % slower per tile
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = 8 * q + rrow0;
+              const int m = min(mrow0 + 64 * hb + 32 * sb + row, M - 1);
+              rawres[sb][q] = ABL == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R + (size_t)m * N + nbase + 8 * (rsl ^ (row & 7)));
+            }
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = 8 * q + rrow0;
+              *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
+            }
+          __builtin_amdgcn_wave_barrier();
           bf16x4 res[4][4];
-          float2 ms[4];
 #pragma unroll
           for (int b4 = 0; b4 < 4; ++b4) {
-            const int m = min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1);
-            ms[b4] = dln.mr[m];
+            const int row = 16 * (b4 & 1) + l15;
+            const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) res[b4][a] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + 16 * a + 4 * lq);
+            for (int a = 0; a < 4; ++a) {
+              const int c = (16 * a + 4 * lq) / 8;
+              res[b4][a] = *reinterpret_cast<const bf16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+            }
           }
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int b4 = 0; b4 < 4; ++b4) {
             const int bb = 4 * hb + b4;
@@ -705,11 +740,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
             p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
             p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
             const int m = mrow0 + 16 * bb + l15;
-            if (lq == 0 && m < M) dln.part[(size_t)m * pstride + 4 * nt + wn] = float2{p1, p2};
+            if (ABL == 4) asm volatile("" ::"v"(p1), "v"(p2));
+            else if (ABL != 2 && lq == 0 && m < M) dln.part[(size_t)(4 * nt + wn) * dln.part_stride + m] = float2{p1, p2};
           }
         }
       }
-      {
+      if (ABL != 1) {
         const int row0 = el >> 3, sl = el & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -909,7 +945,7 @@ int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, c
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
   dim3 g((unsigned)(tiles < cus ? tiles : cus)), b(512);
-  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part)};
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound};
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* w = static_cast<const bf16_t*>(W);
   bf16_t* y = static_cast<bf16_t*>(Y);

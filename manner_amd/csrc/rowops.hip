@@ -209,13 +209,12 @@ __global__ __launch_bounds__(256) void embed_raw_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void dln_finalize_kernel(const float2* __restrict__ part, int groups, float inv_h, float eps,
-                                                           float2* __restrict__ mr, const int* __restrict__ m_total) {
+__global__ __launch_bounds__(256) void dln_finalize_kernel(const float2* __restrict__ part, int groups, int64_t stride, float inv_h,
+                                                           float eps, float2* __restrict__ mr, const int* __restrict__ m_total) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= *m_total) return;
-  const float2* p = part + (size_t)m * groups;
   float s1 = 0.f, s2 = 0.f;
-  for (int g = 0; g < groups; ++g) { const float2 v = p[g]; s1 += v.x; s2 += v.y; }
+  for (int g = 0; g < groups; ++g) { const float2 v = part[(size_t)g * stride + m]; s1 += v.x; s2 += v.y; }   // group-major
   const float mean = s1 * inv_h;
   const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
   mr[m] = float2{mean, 1.0f / sqrtf(var + eps)};
@@ -331,7 +330,7 @@ int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int3
 int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
                  hipStream_t stream) {
   hipLaunchKernelGGL(dln_finalize_kernel, dim3((unsigned)((m_bound + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const float2*>(part), groups, 1.0f / (float)H, eps, static_cast<float2*>(mr), m_total);
+                     static_cast<const float2*>(part), groups, m_bound, 1.0f / (float)H, eps, static_cast<float2*>(mr), m_total);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

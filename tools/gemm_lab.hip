@@ -98,62 +98,42 @@ int main(int argc, char** argv) {
       printf("mfma_peak 16x16x32 blocks=%d: %.1f us  %.0f TF\n", blocks, ms * 1e3, fl / ms / 1e9);
     }
   }
-  for (auto& s : shapes) {
+  // the production 256x256 kernel, every epilogue it runs in the bf16 encoder; abl1 = main loop only
+  float2* mr; float2* part; float* vec;
+  CK(hipMalloc(&mr, (size_t)M * 8)); CK(hipMalloc(&part, (size_t)M * 16 * 8)); CK(hipMalloc(&vec, 3072 * 4));
+  {
+    std::vector<float2> hm(M, float2{0.01f, 1.0f});
+    CK(hipMemcpy(mr, hm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+    std::vector<float> hv(3072, 1.0f);
+    CK(hipMemcpy(vec, hv.data(), 3072 * 4, hipMemcpyHostToDevice));
+  }
+  struct Case { const char* name; int N, K; Epilogue epi; };
+  Case cases[] = {{"qkv  NORM", 2304, 768, EPI_NORM}, {"qkv  BIAS", 2304, 768, EPI_BIAS}, {"out  NRES", 768, 768, EPI_NRES},
+                  {"out  BIAS", 768, 768, EPI_BIAS}, {"ffn1 NORM_GELU", 3072, 768, EPI_NORM_GELU}, {"ffn1 BIAS", 3072, 768, EPI_BIAS},
+                  {"ffn2 NRES", 768, 3072, EPI_NRES}, {"ffn2 BIAS", 768, 3072, EPI_BIAS}};
+  for (auto& s : cases) {
     const int n_tiles = s.N / G_BN;
-    dim3 g((M / G_BM) * n_tiles), b(512);
+    const int tiles = (M / G_BM) * n_tiles;
+    dim3 g(tiles < 256 ? tiles : 256), b(512);
     const double fl = 2.0 * M * s.N * s.K;
+    DlnAux aux{vec, mr, part, M};
+    bf16_t* y = (bf16_t*)Y;
     auto run = [&](int abl) {
-#define LAUNCH(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_big_kernel<bf16_t, TO, EPI, ABL>), g, b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles)
-#define BY_ABL(TO, EPI) switch (abl) { case 0: LAUNCH(TO, EPI, 0); break; case 1: LAUNCH(TO, EPI, 1); break; case 2: LAUNCH(TO, EPI, 2); break; case 3: LAUNCH(TO, EPI, 3); break; }
-      if (s.epi == EPI_BIAS) { BY_ABL(bf16_t, EPI_BIAS) }
-      else if (s.epi == EPI_BIAS_GELU) { BY_ABL(bf16_t, EPI_BIAS_GELU) }
-      else { BY_ABL(float, EPI_BIAS_RES) }
+#define LX(EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI, ABL>), g, b, 0, 0, X, W, bias, EPI == EPI_NRES ? y : R, y, s.N, s.K, mtot, n_tiles, aux)
+#define BYA(EPI) if (abl == 0) LX(EPI, 0); else if (abl == 1) LX(EPI, 1); else if (abl == 2) LX(EPI, 2); else if (abl == 3) LX(EPI, 3); else LX(EPI, 4);
+      switch (s.epi) {
+        case EPI_NORM: BYA(EPI_NORM) break;
+        case EPI_NORM_GELU: BYA(EPI_NORM_GELU) break;
+        case EPI_NRES: BYA(EPI_NRES) break;
+        default: BYA(EPI_BIAS) break;
+      }
     };
-    printf("%-5s M=%d N=%d K=%d:", s.name, M, s.N, s.K);
-    for (int abl = 0; abl < 4; ++abl) {
+    printf("%-15s M=%d N=%d K=%d tiles/CU %.1f:", s.name, M, s.N, s.K, tiles / 256.0);
+    for (int abl = 0; abl < (s.epi == EPI_NRES ? 5 : 2); ++abl) {
       double ms = time_ms([&] { run(abl); }, 20);
-      printf("  abl%d %.1f us %.0f TF", abl, ms * 1e3, fl / ms / 1e9);
-    }
-    {
-      auto runx = [&](int abl) {
-#define LAUNCHX(TO, EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<TO, EPI, ABL>), dim3(g.x < 256 ? g.x : 256), b, 0, 0, X, W, bias, R, (TO*)Y, s.N, s.K, mtot, n_tiles, LnFuse{})
-#define BY_ABLX(TO, EPI) switch (abl) { case 0: LAUNCHX(TO, EPI, 0); break; case 1: LAUNCHX(TO, EPI, 1); break; case 2: LAUNCHX(TO, EPI, 2); break; }
-        if (s.epi == EPI_BIAS) { BY_ABLX(bf16_t, EPI_BIAS) }
-        else if (s.epi == EPI_BIAS_GELU) { BY_ABLX(bf16_t, EPI_BIAS_GELU) }
-        else { BY_ABLX(float, EPI_BIAS_RES) }
-      };
-      for (int abl = 0; abl < 3; ++abl) {
-        double ms = time_ms([&] { runx(abl); }, 20);
-        printf("  | x16_%d %.1f us %.0f TF", abl, ms * 1e3, fl / ms / 1e9);
-      }
-      // x16 vs big: same products, different summation order inside a K-step -> compare numerically
-      const size_t n_out = (size_t)M * s.N;
-      const size_t bytes = n_out * (s.f32out ? 4 : 2);
-      std::vector<char> y1(bytes), y2(bytes);
-      CK(hipMemset(Y, 0, bytes)); run(0); CK(hipDeviceSynchronize());
-      CK(hipMemcpy(y1.data(), Y, bytes, hipMemcpyDeviceToHost));
-      CK(hipMemset(Y, 0, bytes)); runx(0); CK(hipDeviceSynchronize());
-      CK(hipMemcpy(y2.data(), Y, bytes, hipMemcpyDeviceToHost));
-      double maxd = 0, maxv = 0;
-      for (size_t i = 0; i < n_out; i += 7) {
-        float a_ = s.f32out ? ((float*)y1.data())[i] : (float)((bf16_t*)y1.data())[i];
-        float b_ = s.f32out ? ((float*)y2.data())[i] : (float)((bf16_t*)y2.data())[i];
-        maxd = fmax(maxd, fabs((double)a_ - b_)); maxv = fmax(maxv, fabs((double)a_));
-      }
-      printf("  | x16 vs big: max|d| %.3g of %.3g", maxd, maxv);
-    }
-    // v1 128x128
-    {
-      dim3 g1((M / 128) * (s.N / 128)), b1(256);
-      double ms = time_ms([&] {
-        if (s.epi == EPI_BIAS) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t, EPI_BIAS>), g1, b1, 0, 0, X, W, bias, R, (bf16_t*)Y, s.N, s.K, mtot, s.N / 128);
-        else if (s.epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t, EPI_BIAS_GELU>), g1, b1, 0, 0, X, W, bias, R, (bf16_t*)Y, s.N, s.K, mtot, s.N / 128);
-        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float, EPI_BIAS_RES>), g1, b1, 0, 0, X, W, bias, R, (float*)Y, s.N, s.K, mtot, s.N / 128);
-      }, 20);
-      printf("  | v1 %.1f us %.0f TF", ms * 1e3, fl / ms / 1e9);
+      printf("  abl%d %.1f us %.0f TF (%.1f us/tile)", abl, ms * 1e3, fl / ms / 1e9, ms * 1e3 / (tiles / 256.0));
     }
     printf("\n");
   }
-  CK(hipDeviceSynchronize());
   return 0;
 }
