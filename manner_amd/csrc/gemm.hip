@@ -510,8 +510,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int i = 2 * pair + par;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]),
-                                       LDS_PTR(base + i * 1024), 16, 0, 0);
+      if (ABL == 6 && !is_w)
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]), LDS_PTR(base + i * 1024), 16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]),
+                                         LDS_PTR(base + i * 1024), 16, 0, 0);
     }
   };
 
@@ -848,8 +851,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
         }
-        if (m < M)
-          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut)) = raw;
+        if (m < M) {
+          f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
+          // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
+          // that they do not push the weight tiles, re-read by every row panel, out of the XCD's 4 MB L2
+          if (NORM && ABL != 5) __builtin_nontemporal_store(raw, dst);
+          else *dst = raw;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }

@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     bf16_t* y = (bf16_t*)Y;
     auto run = [&](int abl) {
 #define LX(EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI, ABL>), g, b, 0, 0, X, W, bias, EPI == EPI_NRES ? y : R, y, s.N, s.K, mtot, n_tiles, aux)
-#define BYA(EPI) if (abl == 0) LX(EPI, 0); else if (abl == 1) LX(EPI, 1); else if (abl == 2) LX(EPI, 2); else if (abl == 3) LX(EPI, 3); else LX(EPI, 4);
+#define BYA(EPI) if (abl == 0) LX(EPI, 0); else if (abl == 1) LX(EPI, 1); else if (abl == 2) LX(EPI, 2); else if (abl == 3) LX(EPI, 3); else if (abl == 4) LX(EPI, 4); else if (abl == 5) LX(EPI, 5); else LX(EPI, 6);
       switch (s.epi) {
         case EPI_NORM: BYA(EPI_NORM) break;
         case EPI_NORM_GELU: BYA(EPI_NORM_GELU) break;
@@ -129,7 +129,7 @@ int main(int argc, char** argv) {
       }
     };
     printf("%-15s M=%d N=%d K=%d tiles/CU %.1f:", s.name, M, s.N, s.K, tiles / 256.0);
-    for (int abl = 0; abl < (s.epi == EPI_NRES ? 5 : 2); ++abl) {
+    for (int abl = 0; abl < 7; ++abl) {
       double ms = time_ms([&] { run(abl); }, 20);
       printf("  abl%d %.1f us %.0f TF (%.1f us/tile)", abl, ms * 1e3, fl / ms / 1e9, ms * 1e3 / (tiles / 256.0));
     }
