@@ -466,6 +466,7 @@ struct DlnAux {
   float2* part;           // EPI_NRES: [N/64][m_bound] partial {sum, sum of squares} of the rows written (group-major:
                           // a wave's 16 rows per store instruction are one contiguous 128-byte line)
   int64_t part_stride;    // m_bound
+  int col_group;          // column tiles per pass over the rows (0 = all): see the tile order in the kernel
 };
 
 template <typename TOut, int EPI, int ABL = 0>
@@ -484,7 +485,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
   const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   const int M = *m_total;
-  const int valid_tiles = ((M + G_BM - 1) / G_BM) * n_tiles;
+  const int m_tiles = (M + G_BM - 1) / G_BM;
+  const int valid_tiles = m_tiles * n_tiles;
+  // Tile order: column tiles are walked in groups of `gsz`; within a group the order is row-panel-major.  One pass
+  // over the rows then touches only gsz weight tiles (gsz * 256 * K * 2 bytes), which stay resident in the XCD's 4 MB
+  // L2 while activations stream — at the price of reading the activations once per group instead of once.
+  const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? dln.col_group : n_tiles;
+  const int per_group = m_tiles * gsz;
+  auto decode = [&](int tile, int& mt_, int& nt_) {
+    const int g = tile / per_group;
+    const int r = tile - g * per_group;
+    const int width = min(gsz, n_tiles - g * gsz);     // the last group may be narrower
+    mt_ = r / width;
+    nt_ = g * gsz + (r - mt_ * width);
+  };
   int t = slot;
   if (t >= valid_tiles) return;
 
@@ -502,7 +516,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   for (int par = 0; par < 2; ++par)
     voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
   auto tile_src = [&](int tile) -> const TIn* {
-    const int mt_ = tile / n_tiles, nt_ = tile - mt_ * n_tiles;
+    int mt_, nt_;
+    decode(tile, mt_, nt_);
     return is_w ? W + (size_t)(nt_ * G_BN + prow0) * K : X + (size_t)(mt_ * G_BM + prow0) * K;
   };
   auto issue2 = [&](int buf, const TIn* gsrc, int k0, int pair) {
@@ -624,7 +639,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   int xs = 0;                        // activation stage of the current K-step (ring of 3 across tiles)
   bool first = true;
   while (true) {
-    const int mt = t / n_tiles, nt = t - mt * n_tiles;
+    int mt, nt;
+    decode(t, mt, nt);
     const int tn = t + G;
     const bool has_next = tn < valid_tiles;
     const TIn* gnext = tile_src(has_next ? tn : t);
@@ -946,6 +962,8 @@ static int device_cus() {
 
 int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  static const int col_group_env = getenv("MANNER_HIP_COL_GROUP") ? atoi(getenv("MANNER_HIP_COL_GROUP")) : -1;   // A/B switch
+  const int col_group = col_group_env >= 0 ? col_group_env : 0;
   if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
     return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
@@ -953,7 +971,7 @@ int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, c
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
   dim3 g((unsigned)(tiles < cus ? tiles : cus)), b(512);
-  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound};
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group};
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* w = static_cast<const bf16_t*>(W);
   bf16_t* y = static_cast<bf16_t*>(Y);

@@ -116,7 +116,8 @@ int main(int argc, char** argv) {
     const int tiles = (M / G_BM) * n_tiles;
     dim3 g(tiles < 256 ? tiles : 256), b(512);
     const double fl = 2.0 * M * s.N * s.K;
-    DlnAux aux{vec, mr, part, M};
+    int cg = 0;
+    DlnAux aux{vec, mr, part, M, cg};
     bf16_t* y = (bf16_t*)Y;
     auto run = [&](int abl) {
 #define LX(EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI, ABL>), g, b, 0, 0, X, W, bias, EPI == EPI_NRES ? y : R, y, s.N, s.K, mtot, n_tiles, aux)
@@ -129,7 +130,14 @@ int main(int argc, char** argv) {
       }
     };
     printf("%-15s M=%d N=%d K=%d tiles/CU %.1f:", s.name, M, s.N, s.K, tiles / 256.0);
-    for (int abl = 0; abl < 7; ++abl) {
+    for (int c : {0, 2, 3, 4, 6}) {
+      cg = c;
+      aux.col_group = c;
+      double ms = time_ms([&] { run(0); }, 20);
+      printf("  cg%d %.1f us %.0f TF", c, ms * 1e3, fl / ms / 1e9);
+    }
+    cg = 0; aux.col_group = 0;
+    for (int abl = 1; abl < 2; ++abl) {
       double ms = time_ms([&] { run(abl); }, 20);
       printf("  abl%d %.1f us %.0f TF (%.1f us/tile)", abl, ms * 1e3, fl / ms / 1e9, ms * 1e3 / (tiles / 256.0));
     }
