@@ -253,6 +253,20 @@ int manner_hip_collate_aspects(const int32_t* category, const int32_t* sentiment
                                int64_t n_news, const int32_t* rows, int64_t M, int64_t* out_category,
                                int64_t* out_sentiment, float* out_score, manner_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- evaluation loss (val/loss, test/loss)
+ * Replaces the loss of CRModule.model_step — manner/models/cr_module.py:140-171, run by validation_step and test_step
+ * (:211-262) on every batch — per impression, on the ragged scores (no dense [B, Cmax] matrix, no host loops).
+ *   mode 0 (supcon_loss: True, configs/model/cr_module.yaml:4): the reference's SupConLoss on the score matrix
+ *           (manner/models/components/losses.py:12-40): losses[i] = -sum_{j positive}(s_j/T - logsumexp_{j real} s_j/T)
+ *           / (n_pos + FLT_MIN); 0 for an impression without a positive.  The batch value is the reducer's job
+ *           (pytorch_metric_learning default for SupConLoss: mean over the non-zero entries).
+ *   mode 1 (supcon_loss: False): nn.CrossEntropyLoss(scores [B, c_max], y_true [B, c_max]) with probability targets —
+ *           the c_max - c_i zero-padded scores of the dense row take part in the softmax, as in the reference;
+ *           losses[i] = -sum_j y_ij log_softmax(row_i)_j, batch value = mean.  temperature is ignored (pass 1).
+ * scores / labels f32 [cand_off[B]], cand_off int64 [B+1], losses f32 [B]. */
+int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t mode,
+                         float temperature, int64_t c_max, float* losses, manner_hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ SIGNATURES = {
     "manner_hip_aspect_metrics": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_auc_workspace_bytes": (_SZ, [_I64]),
     "manner_hip_auc": (C.c_int, [_P, _P, _I64, _I32, _P, _SZ, _P, _P, _P]),
+    "manner_hip_eval_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P]),
     "manner_hip_collate_segments": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "manner_hip_collate_text": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_collate_entities": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),

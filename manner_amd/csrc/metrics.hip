@@ -117,6 +117,41 @@ __global__ void auc_final_kernel(const unsigned long long* acc, const uint32_t* 
   if (counts) { counts[0] = (int64_t)u2; counts[1] = (int64_t)pos; counts[2] = (int64_t)neg; }
 }
 
+// ---- evaluation loss of CRModule.model_step (cr_module.py:140-171), one wave per impression, ragged scores.
+// mode 0: SupConLoss on the score matrix (losses.py:12-40): -mean_{pos} (s_j/T - logsumexp_{real j} s_j/T)
+// mode 1: nn.CrossEntropyLoss(scores[B,Cmax], y_true[B,Cmax]) with probability targets: the zero-padded entries of the
+//         dense row take part in the softmax (c_max - c_i scores of 0.0), as they do in the reference.
+__global__ __launch_bounds__(256) void eval_loss_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                                       const int64_t* __restrict__ off, int64_t B, int mode, float inv_t,
+                                                       int64_t c_max, float tiny, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  const int64_t c0 = off[i], c1 = off[i + 1];
+  const int64_t pad = mode == 1 ? c_max - (c1 - c0) : 0;
+  float mx = pad > 0 ? 0.f : -INFINITY;
+  for (int64_t j = c0 + lane; j < c1; j += 64) mx = fmaxf(mx, scores[j] * inv_t);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.f, sp = 0.f, np = 0.f;
+  for (int64_t j = c0 + lane; j < c1; j += 64) {
+    const float v = scores[j] * inv_t - mx;          // contraction is off in this kernel: the row maximum gives exactly 0
+    se += expf(v);
+    const float y = labels[j];
+    if (mode == 1) { sp = fmaf(y, v, sp); np += y; }
+    else if (y > 0.5f) { sp += v; np += 1.f; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sp += __shfl_xor(sp, o, 64); np += __shfl_xor(np, o, 64); }
+  if (lane == 0) {
+    if (pad > 0) se += (float)pad * expf(-mx);
+    const float lse = logf(se);
+    // sum_pos (v - lse) = sp - np * lse;  SupCon divides by (n_pos + tiny): 0 without a positive
+    out[i] = mode == 1 ? -(sp - np * lse) : -(sp - np * lse) / (np + tiny);
+  }
+}
+
 }  // namespace
 }  // namespace manner
 
@@ -155,6 +190,17 @@ int manner_hip_auc(const float* scores, const float* labels, int64_t n, int32_t 
   MANNER_HIP_TRY(hipcub::DeviceSelect::Flagged(w.cub, cb, idx, flags, w.head_pos, w.scalars + 1, (int)n, stream));
   hipLaunchKernelGGL(auc_groups_kernel, dim3(grid), dim3(256), 0, stream, w.head_pos, w.cneg, w.scalars, n, w.acc);
   hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, stream, w.acc, w.scalars, n, auc, counts);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t mode,
+                         float temperature, int64_t c_max, float* losses, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!scores || !labels || !cand_off || !losses || B < 0 || mode < 0 || mode > 1 || !(temperature > 0.f) || (mode == 1 && c_max < 1))
+    return fail(MANNER_HIP_E_INVALID, "eval_loss: bad argument");
+  hipLaunchKernelGGL(eval_loss_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, labels, cand_off, B,
+                     (int)mode, 1.0f / temperature, c_max, 1.17549435e-38f, losses);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

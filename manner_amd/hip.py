@@ -377,3 +377,29 @@ def collate_aspects(category: Tensor, sentiment: Tensor, sentiment_score: Tensor
                                                           category.numel(), _ptr(rows), m, _ptr(ocat), _ptr(osent), _ptr(oscore),
                                                           _stream()))
     return ocat, osent, oscore
+
+
+def eval_loss(scores: Tensor, labels: Tensor, cand_off: Tensor, supcon: bool = True, temperature: float = 0.1,
+              c_max: Optional[int] = None, reduce: bool = True):
+    """Loss of ``CRModule.model_step`` (cr_module.py:140-171) from the ragged scores: SupCon on the score matrix
+    (``supcon=True``, losses.py:12-40; batch value = mean of the non-zero per-impression losses, the
+    pytorch_metric_learning default reducer for SupConLoss) or CrossEntropyLoss with probability targets over the
+    zero-padded row of width ``c_max`` (default: the batch maximum; batch value = mean)."""
+    scores = _dev(scores, torch.float32, "scores").contiguous()
+    labels = _dev(labels, torch.float32, "labels").contiguous()
+    cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
+    nb = cand_off.numel() - 1
+    if not supcon and c_max is None:
+        c_max = int((cand_off[1:] - cand_off[:-1]).max())
+    losses = torch.empty((nb,), dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().manner_hip_eval_loss(_ptr(scores), _ptr(labels), _ptr(cand_off), nb, 0 if supcon else 1,
+                                                    C.c_float(temperature if supcon else 1.0), int(c_max or 1), _ptr(losses), _stream()))
+    if not reduce:
+        return losses
+    if not supcon:
+        return losses.mean()
+    if supcon and (not bool((labels > 0.5).any()) or not bool((labels <= 0.5).any())):
+        return losses.sum() * 0                       # losses.py:24-25, 40: no positive or no negative pair in the batch
+    nz = losses > 0
+    return torch.where(nz.any(), (losses * nz).sum() / nz.sum().clamp(min=1), losses.sum() * 0)

@@ -416,3 +416,45 @@ def collate(news: dict, batch_rows: Sequence[dict], max_history_length: int, pad
             "x_hist": side(hist), "x_cand": side(cand),
             "labels": torch.tensor([l for r in batch_rows for l in r["labels"]], dtype=torch.float32),
             "users": torch.tensor([int(r["user"]) for r in batch_rows], dtype=torch.int64)}
+
+
+# ---------------------------------------------------------------------------------------------- evaluation loss
+def model_step_loss(scores: Tensor, labels: Tensor, offsets: Sequence[int], supcon: bool, temperature: float = 0.1):
+    """The loss of CRModule.model_step restated on dense matrices exactly as the reference builds them
+    (cr_module.py:140-171): to_dense_batch of the labels, positive / negative index lists (the negatives are the first
+    c_i - n_pos zero-label columns, i.e. the real negatives), then the reference's SupConLoss on the SCORE matrix
+    (manner/models/components/losses.py:12-40) or nn.CrossEntropyLoss with probability targets.
+    pytorch_metric_learning is not installed: its pieces are restated — mat-based pair loss masks
+    (pos_mask[a1, p] = 1, neg_mask[a2, n] = 1), lmu.logsumexp with keep_mask (masked entries -> -inf, rows without any
+    kept entry -> 0), c_f.small_val = finfo.tiny, default reducer of SupConLoss = AvgNonZeroReducer (mean of the
+    per-row losses that are > 0; 0 if none).  Returns (batch loss, per-impression losses)."""
+    sizes = [offsets[i + 1] - offsets[i] for i in range(len(offsets) - 1)]
+    seg = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    mat, mask = to_dense_batch(scores.reshape(-1, 1), seg)
+    mat = mat.squeeze(-1)
+    y_true, _ = to_dense_batch(labels.reshape(-1, 1), seg)
+    y_true = y_true.squeeze(-1)
+    if not supcon:
+        per = -(y_true * F.log_softmax(mat, dim=1)).sum(1)
+        return F.cross_entropy(mat, y_true), per
+    pos_mask, neg_mask = torch.zeros_like(mat), torch.zeros_like(mat)
+    n_pairs = [0, 0]
+    for i in range(mat.shape[0]):
+        pos = torch.where(y_true[i])[0]                                                     # cr_module.py:146
+        neg = torch.where(~y_true[i].bool())[0][: int(mask[i].sum()) - len(pos)]            # :152-157
+        pos_mask[i, pos] = 1
+        neg_mask[i, neg] = 1
+        n_pairs[0] += len(pos)
+        n_pairs[1] += len(neg)
+    zero = torch.zeros(mat.shape[0])
+    if all(n <= 1 for n in n_pairs) or not (pos_mask.bool().any() and neg_mask.bool().any()):   # losses.py:14-15, 21, 40
+        return torch.tensor(0.0), zero
+    m = mat / temperature
+    m = m - m.max(dim=1, keepdim=True)[0]
+    keep = (pos_mask + neg_mask).bool()
+    den = torch.logsumexp(m.masked_fill(~keep, float("-inf")), dim=1, keepdim=True)
+    den = den.masked_fill(~keep.any(dim=1, keepdim=True), 0)
+    log_prob = m - den
+    per = -((pos_mask * log_prob).sum(1) / (pos_mask.sum(1) + torch.finfo(m.dtype).tiny))
+    nz = per > 0
+    return (per[nz].mean() if bool(nz.any()) else per.sum() * 0), per

@@ -529,3 +529,24 @@ def test_device_collate_matches_oracle(tmp_path):
     check([5, 2, 40, 11, 11, 0])
     last = check(range(len(rows) - 1, len(rows)))
     assert last["x_hist"]["entities"].shape == (2, 0) and last["x_cand"]["text"]["input_ids"].shape[1] % 2 == 1
+
+
+@pytest.mark.parametrize("supcon", [True, False])
+def test_eval_loss_matches_oracle(supcon):
+    """val/test loss of CRModule.model_step from the ragged scores == the reference's dense construction (oracle)."""
+    g = np.random.Generator(np.random.PCG64(17))
+    sizes = g.integers(1, 90, 300)
+    sizes[:3] = (1, 2, 300)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    scores = (3.0 * g.standard_normal(off[-1])).astype(np.float32)
+    labels = (g.random(off[-1]) < 0.15).astype(np.float32)
+    labels[off[5]:off[6]] = 0.0                      # an impression without a positive
+    labels[off[7]:off[8]] = 1.0                      # and one without a negative
+    want, per = O.model_step_loss(torch.from_numpy(scores), torch.from_numpy(labels), off.tolist(), supcon, temperature=0.36)
+    got_per = hip.eval_loss(_cuda(scores), _cuda(labels), _cuda(off), supcon=supcon, temperature=0.36, reduce=False)
+    got = hip.eval_loss(_cuda(scores), _cuda(labels), _cuda(off), supcon=supcon, temperature=0.36)
+    assert torch.allclose(got_per.cpu(), per, rtol=2e-5, atol=2e-5), (got_per.cpu() - per).abs().max()
+    assert abs(float(got) - float(want)) < 2e-5 * max(1.0, abs(float(want)))
+    if supcon:                                       # batch-level early exits of the reference loss
+        z = hip.eval_loss(_cuda(scores[:5]), _cuda(np.zeros(5, np.float32)), _cuda(np.array([0, 2, 5])), supcon=True)
+        assert float(z) == 0.0 and float(O.model_step_loss(torch.from_numpy(scores[:5]), torch.zeros(5), [0, 2, 5], True)[0]) == 0.0
