@@ -112,6 +112,18 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
                           int32_t precision, float* out, void* workspace, size_t workspace_bytes,
                           manner_hip_stream_t stream);
 
+/* Hidden states after the first n_layers encoder layers — HF's hidden_states[n_layers] of the model built at
+ * manner/models/components/news_encoder.py:20 (n_layers = 0: embedding output; = layers: last_hidden_state).
+ * n_layers = 8 is the frozen / trainable boundary of the shipped configs (frozen_layers [0..7],
+ * configs/model/cr_module.yaml:10; news_encoder.py:24-27): these activations do not change across training epochs and can
+ * be cached per news.  Arguments as manner_hip_encode_cls; out [n_news, padded_len, H] of
+ * out_dtype (0 = f32, 1 = bf16).  Rows of padded positions are written as zeros: HF computes throw-away values there
+ * which never reach a real token (keys are masked) — feed the tensor with the same attention_mask. */
+int manner_hip_encode_hidden(manner_hip_encoder_t enc, const int64_t* input_ids, const int64_t* attention_mask,
+                             const int32_t* host_lengths, int64_t n_news, int64_t padded_len, int32_t precision,
+                             int32_t n_layers, int32_t out_dtype, void* out, void* workspace, size_t workspace_bytes,
+                             manner_hip_stream_t stream);
+
 /* Blocking: synchronises `stream` and returns MANNER_HIP_E_INPUT if any encode_cls call on this
  * handle since the last status call saw an invalid mask (non-prefix, empty or longer than
  * MANNER_HIP_MAX_LEN); clears the flag. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "manner_hip_encoder_destroy": (C.c_int, [_P]),
     "manner_hip_encoder_workspace_bytes": (_SZ, [_P, _I64, _I64, _I32]),
     "manner_hip_encode_cls": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P]),
+    "manner_hip_encode_hidden": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "manner_hip_encoder_status": (C.c_int, [_P, _P]),
     "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
     "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

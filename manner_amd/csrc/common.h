@@ -81,6 +81,9 @@ int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_
 // pack time: wf[n,k] = bf16(gamma[k] w[n,k]); c1[n] = sum_k wf[n,k]; c2[n] = bias[n] + sum_k beta[k] w[n,k]
 int fold_layernorm(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
                    float* c1, float* c2, hipStream_t stream);
+// out[n, t, :] = x[cu[n]+t] (normalised with mr/gamma/beta when mr != NULL) for t < len(n), zeros for padded positions
+int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const int32_t* cu, int64_t n_news, int64_t lp, int H,
+                   const float* gamma, const float* beta, void* out, hipStream_t stream);
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);

@@ -148,9 +148,11 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   return off;
 }
 
+// `hidden_layers` < 0: the [CLS] path (out = f32 [n_news, H]).  Otherwise the first `hidden_layers` layers run in
+// full and `out` receives their hidden states in the padded [n_news, lp, H] layout (dtype `hidden_dt`).
 int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t lp,
-                 int64_t m_bound, int prec, float* out, const Workspace& ws, hipStream_t s,
-                 hipEvent_t phase_mark = nullptr) {
+                 int64_t m_bound, int prec, void* out, const Workspace& ws, hipStream_t s,
+                 hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32) {
   const manner_hip_encoder_config& c = e->cfg;
   const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
   const int H = c.hidden, I = c.intermediate;
@@ -172,7 +174,8 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
       const LayerParams& p = e->params[l];
       const float* g_in = l == 0 ? e->embg : e->params[l - 1].ln2g;     // the LayerNorm that feeds this layer
       const float* b_in = l == 0 ? e->embb : e->params[l - 1].ln2b;
-      if (l + 1 == c.layers) {
+      if (l == hidden_layers) break;
+      if (hidden_layers < 0 && l + 1 == c.layers) {
         // last layer: K|V for every token, everything else on the compact [CLS] rows (plain weights)
         const int64_t n_bound = round_up(n_news, 256);
         const int32_t* n_total = ws.m_total + 1;
@@ -185,7 +188,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
         PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
         PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
         PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, out, n_bound, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, static_cast<float*>(out), n_bound, n_total, s))
         break;
       }
       PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, w.wqkv_f, p.cq2, p.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
@@ -197,6 +200,11 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
     }
+    if (hidden_layers >= 0) {   // the residual stream is still un-normalised: apply the LayerNorm that closes layer hidden_layers-1
+      const float* g = hidden_layers == 0 ? e->embg : e->params[hidden_layers - 1].ln2g;
+      const float* b = hidden_layers == 0 ? e->embb : e->params[hidden_layers - 1].ln2b;
+      PROF_STEP(MANNER_HIP_PROF_GATHER, scatter_hidden(dt, hidden_dt, ws.x, ws.mr_in, ws.cu, n_news, lp, H, g, b, out, s))
+    }
     return MANNER_HIP_OK;
   }
   {
@@ -205,7 +213,8 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
                               pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
       return rc;
   }
-  for (int l = 0; l + 1 < c.layers; ++l) {
+  const int full_layers = hidden_layers >= 0 ? hidden_layers : c.layers - 1;
+  for (int l = 0; l < full_layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
@@ -216,6 +225,10 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
+  }
+  if (hidden_layers >= 0) {
+    PROF_STEP(MANNER_HIP_PROF_GATHER, scatter_hidden(dt, hidden_dt, ws.x, nullptr, ws.cu, n_news, lp, H, nullptr, nullptr, out, s))
+    return MANNER_HIP_OK;
   }
   // Last layer: the reference keeps only last_hidden_state[:, 0, :] (news_encoder.py:30-34), so K and V
   // are needed for every token but Q, the output projection, both LayerNorms and the FFN only for the
@@ -235,7 +248,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
     PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
     PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, out, n_bound, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, static_cast<float*>(out), n_bound, n_total, s))
   }
   return MANNER_HIP_OK;
 }
@@ -384,9 +397,10 @@ size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_
   return enc->n_streams * carve(enc, max_news, round_up(max_tokens, 256), precision, nullptr, nullptr);
 }
 
-int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
-                          int64_t n_news, int64_t padded_len, int32_t precision, float* out, void* workspace,
-                          size_t workspace_bytes, manner_hip_stream_t stream) {
+// shared driver of encode_cls / encode_hidden: chunking, stream fork/join
+static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
+                       int64_t n_news, int64_t padded_len, int32_t precision, void* out, void* workspace,
+                       size_t workspace_bytes, manner_hip_stream_t stream, int hidden_layers, DType hidden_dt) {
   if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_cls: null handle");
   if (n_news == 0) return MANNER_HIP_OK;
   if (!ids || !mask || !out || !workspace || n_news < 0) return fail(MANNER_HIP_E_INVALID, "encode_cls: null pointer");
@@ -442,8 +456,10 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
       MANNER_HIP_TRY(hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0));
       forked = lane;
     }
+    const size_t news_bytes = hidden_layers < 0 ? (size_t)H * 4 : (size_t)padded_len * H * (hidden_dt == DT_F32 ? 4 : 2);
     int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
-                          out + n0 * H, ws[lane], s, (ns > 1 && chunk < ns - 1) ? enc->phase_ev[lane] : nullptr);
+                          static_cast<char*>(out) + n0 * news_bytes, ws[lane], s,
+                          (ns > 1 && chunk < ns - 1) ? enc->phase_ev[lane] : nullptr, hidden_layers, hidden_dt);
     if (rc) return rc;
     n0 += cnt;
     ++chunk;
@@ -453,6 +469,22 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
     MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev[i], 0));
   }
   return MANNER_HIP_OK;
+}
+
+int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
+                          int64_t n_news, int64_t padded_len, int32_t precision, float* out, void* workspace,
+                          size_t workspace_bytes, manner_hip_stream_t stream) {
+  return encode_impl(enc, ids, mask, host_lengths, n_news, padded_len, precision, out, workspace, workspace_bytes, stream, -1, DT_F32);
+}
+
+int manner_hip_encode_hidden(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
+                             int64_t n_news, int64_t padded_len, int32_t precision, int32_t n_layers, int32_t out_dtype,
+                             void* out, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_hidden: null handle");
+  if (n_layers < 0 || n_layers > enc->cfg.layers) return fail(MANNER_HIP_E_INVALID, "encode_hidden: n_layers %d outside [0, %d]", n_layers, enc->cfg.layers);
+  if (out_dtype != 0 && out_dtype != 1) return fail(MANNER_HIP_E_INVALID, "encode_hidden: out_dtype %d (0 = f32, 1 = bf16)", out_dtype);
+  return encode_impl(enc, ids, mask, host_lengths, n_news, padded_len, precision, out, workspace, workspace_bytes, stream, n_layers,
+                     out_dtype == 0 ? DT_F32 : DT_BF16);
 }
 
 int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stream) {

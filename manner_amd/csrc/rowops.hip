@@ -253,6 +253,39 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ 
   if (lane == 0) { c1[n] = s1; c2[n] = bias[n] + s2; }
 }
 
+// ---- hidden states back in the reference's padded layout: out[n, t, :] = (LN of) x[cu[n] + t] for t < len, 0 beyond
+template <typename TIn, typename TOut, bool NORM>
+__global__ __launch_bounds__(256) void scatter_hidden_kernel(const TIn* __restrict__ x, const float2* __restrict__ mr,
+                                                             const int32_t* __restrict__ cu, int64_t lp, int H,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             TOut* __restrict__ out) {
+  const int64_t n = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int start = cu[n], len = cu[n + 1] - start;
+  for (int t = wave; t < lp; t += 4) {
+    TOut* dst = out + ((size_t)n * lp + t) * H;
+    if (t >= len) {
+      for (int c = lane * 4; c < H; c += 256) store_vec<TOut>(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
+      continue;
+    }
+    const TIn* src = x + (size_t)(start + t) * H;
+    float2 ms = {0.f, 1.f};
+    if (NORM) ms = mr[start + t];
+    for (int c = lane * 4; c < H; c += 256) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)src[c + e];
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - ms.x) * ms.y * g[e] + b[e];
+      }
+      store_vec<TOut>(dst + c, v);
+    }
+  }
+}
+
 // ---- K7: out[n] = x[cu[n]] (the [CLS] row), as f32
 template <typename TIn>
 __global__ __launch_bounds__(256) void gather_cls_kernel(const TIn* __restrict__ x, const int32_t* __restrict__ cu,
@@ -339,6 +372,23 @@ int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_
                   const float* beta, void* dst, hipStream_t stream) {
   hipLaunchKernelGGL(gather_cls_ln_kernel, dim3((unsigned)n_news), dim3(256), 0, stream, static_cast<const bf16_t*>(raw),
                      static_cast<const float2*>(mr), cu, H, gamma, beta, static_cast<bf16_t*>(dst));
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const int32_t* cu, int64_t n_news, int64_t lp, int H,
+                   const float* gamma, const float* beta, void* out, hipStream_t stream) {
+  if (H % 4) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported", H);
+  dim3 g((unsigned)n_news), b(256);
+  const float2* m = static_cast<const float2*>(mr);
+#define SCATTER(TI, TO, NORM) hipLaunchKernelGGL((scatter_hidden_kernel<TI, TO, NORM>), g, b, 0, stream, static_cast<const TI*>(x), m, cu, lp, H, gamma, beta, static_cast<TO*>(out))
+  if (in == DT_BF16) {
+    if (mr) { if (out_dt == DT_F32) SCATTER(bf16_t, float, true); else SCATTER(bf16_t, bf16_t, true); }
+    else { if (out_dt == DT_F32) SCATTER(bf16_t, float, false); else SCATTER(bf16_t, bf16_t, false); }
+  } else {
+    if (out_dt == DT_F32) SCATTER(float, float, false); else SCATTER(float, bf16_t, false);
+  }
+#undef SCATTER
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

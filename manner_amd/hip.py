@@ -133,6 +133,37 @@ class HipEncoder:
                 _ptr(out), _ptr(ws), ws.numel(), _stream()))
         return out
 
+    def encode_hidden(self, ids: Tensor, mask: Tensor, n_layers: int, precision: str = "bf16",
+                      out_dtype: torch.dtype = torch.float32, host_lengths: Optional[np.ndarray] = None,
+                      max_chunk_tokens: int = 65536) -> Tensor:
+        """HF ``hidden_states[n_layers]`` as [N, Lp, H] (zeros at padded positions): the cacheable output of the
+        frozen layers (``frozen_layers: [0..7]`` -> ``n_layers=8``) for a training loop that only updates the rest."""
+        ids, mask = _dev(ids, torch.int64, "input_ids"), _dev(mask, torch.int64, "attention_mask")
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError(f"input_ids {tuple(ids.shape)} / attention_mask {tuple(mask.shape)} must be equal 2-D")
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("out_dtype must be float32 or bfloat16")
+        ids, mask = ids.contiguous(), mask.contiguous()
+        n, lp = ids.shape
+        prec = _lib.PRECISIONS[precision]
+        out = torch.empty((n, lp, self.cfg.hidden), dtype=out_dtype, device=ids.device)
+        if n == 0:
+            return out
+        hl = None
+        if host_lengths is not None:
+            hl = np.ascontiguousarray(host_lengths, dtype=np.int32)
+            assert hl.shape == (n,)
+            tokens = min(int(hl.sum()), max_chunk_tokens)
+        else:
+            tokens = min(n * lp, max_chunk_tokens)
+        tokens = max(tokens, lp, 256)
+        with torch.cuda.device(ids.device):
+            ws = self._workspace(min(n, tokens), tokens, prec)
+            _lib.check(_lib.load().manner_hip_encode_hidden(
+                self._handle, _ptr(ids), _ptr(mask), C.c_void_p(hl.ctypes.data if hl is not None else 0), n, lp, prec,
+                int(n_layers), 0 if out_dtype == torch.float32 else 1, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+        return out
+
     def profile(self, enable: bool) -> None:
         """Bracket every launch of encode_cls with HIP events on the launch stream (opt-in)."""
         _lib.check(_lib.load().manner_hip_encoder_profile(self._handle, int(enable)))

@@ -133,6 +133,25 @@ class MannerTextEncoder(nn.Module):
         return self._encoder(ids.device).encode_cls(ids, mask, precision=self.precision)
 
 
+    def frozen_hidden_states(self, tokenized_text, n_layers: Optional[int] = None,
+                             dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+        """HF ``hidden_states[n_layers]`` [N, Lp, H] computed by the HIP encoder without autograd — by default up to
+        the first trainable layer (the constructor's ``frozen_layers`` must then be a prefix 0..k-1, as in
+        configs/model/cr_module.yaml:10).  These activations are constant across epochs, so a training loop can cache
+        them per news and run only layers k.. in PyTorch with gradients."""
+        if n_layers is None:
+            frozen = sorted({int(n.split("layer.")[1].split(".")[0]) for n, p in self.plm_model.named_parameters()
+                             if "layer." in n and not p.requires_grad})
+            if frozen != list(range(len(frozen))):
+                raise ValueError(f"frozen layers {frozen} are not a prefix 0..k-1; pass n_layers explicitly")
+            n_layers = len(frozen)
+        ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
+        if not ids.is_cuda:
+            raise RuntimeError("MannerTextEncoder.frozen_hidden_states needs GPU tensors — no CPU fallback")
+        with torch.no_grad():
+            return self._encoder(ids.device).encode_hidden(ids, mask, n_layers, precision=self.precision, out_dtype=dtype)
+
+
 class MannerEntityEncoder(nn.Module):
     """reference news_encoder.py:40-72.
 

@@ -91,6 +91,25 @@ def gen_encoder(name, preset, n, lp, seed, std, lengths=None):
     return keys
 
 
+def gen_hidden(name, preset, n, lp, seed, std, lengths, layers_out):
+    """hidden_states[k] of the reference's text encoder (the tensor HF hands from layer k-1 to layer k; k = 8 is the
+    frozen / trainable boundary of configs/model/cr_module.yaml:10), real tokens only, packed news after news."""
+    cfg = PRESETS[preset]
+    w = make_plm_weights(cfg, seed=seed, std=std)
+    ids, mask = synth_news_tokens(n, cfg, seed=seed, max_len=lp, lengths=lengths)
+    with tempfile.TemporaryDirectory() as tmp:
+        enc = reference_news_encoder(hf_model_dir(cfg, w, tmp), cfg.hidden)
+        hs = enc.text_encoder.plm_model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                                        output_hidden_states=True).hidden_states
+    keep = torch.from_numpy(mask).bool()
+    packed = {f"h{k}": hs[k][keep].numpy() for k in layers_out}
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), ids=ids, mask=mask, **packed,
+                        meta=json.dumps({"source": "HF hidden_states of the reference MannerTextEncoder.plm_model "
+                                                   "(news_encoder.py:20), transformers " + __import__("transformers").__version__,
+                                         "preset": preset, "seed": seed, "std": std, "layers": list(layers_out)}))
+    print(name, {k: v.shape for k, v in packed.items()})
+
+
 def gen_components(seed=42):
     g = np.random.Generator(np.random.PCG64(seed))
     d, q = 768, 200
@@ -197,6 +216,12 @@ def gen_pipeline(seed=42):
 
 
 if __name__ == "__main__":
+    if "--hidden-only" in sys.argv:
+        gen_hidden("hidden_tiny_bert", "tiny-bert", n=6, lp=24, seed=42, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),
+                   layers_out=(0, 1, 2))
+        gen_hidden("hidden_bert_base", "bert-base-uncased", n=4, lp=32, seed=42, std=0.02, lengths=np.array([5, 17, 31, 32]),
+                   layers_out=(8, 12))
+        sys.exit(0)
     keys = {}
     keys["tiny-bert"] = gen_encoder("enc_tiny_bert", "tiny-bert", n=12, lp=40, seed=42, std=0.05)
     gen_encoder("enc_tiny_roberta", "tiny-roberta", n=12, lp=40, seed=43, std=0.05)
@@ -208,5 +233,9 @@ if __name__ == "__main__":
     keys["user_encoder"] = gen_components()
     keys["tiny-bert-entities"] = gen_entities()
     gen_pipeline()
+    gen_hidden("hidden_tiny_bert", "tiny-bert", n=6, lp=24, seed=42, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),
+               layers_out=(0, 1, 2))
+    gen_hidden("hidden_bert_base", "bert-base-uncased", n=4, lp=32, seed=42, std=0.02, lengths=np.array([5, 17, 31, 32]),
+               layers_out=(8, 12))
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0)

@@ -550,3 +550,28 @@ def test_eval_loss_matches_oracle(supcon):
     if supcon:                                       # batch-level early exits of the reference loss
         z = hip.eval_loss(_cuda(scores[:5]), _cuda(np.zeros(5, np.float32)), _cuda(np.array([0, 2, 5])), supcon=True)
         assert float(z) == 0.0 and float(O.model_step_loss(torch.from_numpy(scores[:5]), torch.zeros(5), [0, 2, 5], True)[0]) == 0.0
+
+
+@pytest.mark.parametrize("name", ["hidden_tiny_bert", "hidden_bert_base"])
+def test_encode_hidden_matches_reference(golden_dir, name):
+    """Frozen-prefix hidden states (SURVEY §8f rank 3 enabler): HF hidden_states[k] of the reference within 1e-4 in fp32
+    mode (bf16: stated tolerance), zeros at padded positions, chunked == unchunked."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    enc, _ = _encoder(meta["preset"], meta["seed"], meta["std"])
+    ids, mask = _cuda(z["ids"]), _cuda(z["mask"])
+    keep = torch.from_numpy(z["mask"]).bool()
+    for k in meta["layers"]:
+        ref = z[f"h{k}"]
+        h = enc.encode_hidden(ids, mask, k, precision="fp32").cpu()
+        assert h.shape == (z["ids"].shape[0], z["ids"].shape[1], enc.cfg.hidden)
+        assert float(h[~keep].abs().max()) == 0.0 if (~keep).any() else True
+        err = np.abs(h[keep].numpy() - ref).max()
+        assert err < FP32_TOL, (k, err)
+        hb = enc.encode_hidden(ids, mask, k, precision="bf16", out_dtype=torch.bfloat16).float().cpu()
+        errb = np.abs(hb[keep].numpy() - ref).max()
+        print(f"{name} hidden_states[{k}]: fp32 err {err:.2e}, bf16 err {errb:.2e}")
+        assert errb < 0.12 and float(hb[~keep].abs().max() if (~keep).any() else 0.0) == 0.0
+        h2 = enc.encode_hidden(ids, mask, k, precision="fp32", host_lengths=z["mask"].sum(1), max_chunk_tokens=256).cpu()
+        assert torch.equal(h, h2)
+    enc.status()

@@ -184,3 +184,17 @@ def test_binary_auroc_against_sklearn_and_brute_force():
     auc_raw, _ = O.binary_auroc(s, y, sigmoid_rule=False)
     assert (p, q) == (3, 3) and u2 == 2 * (1 + 1 + 1 + 1 + 1) + 2 and abs(auc_raw - 5 / 9) < 1e-12 and auc_sig == u2 / 18
     assert O.binary_auroc(torch.tensor([0.3, 0.6]), torch.tensor([1.0, 1.0]))[0] == 0.0
+
+
+@pytest.mark.parametrize("name", ["hidden_tiny_bert", "hidden_bert_base"])
+def test_hidden_states_match_reference(golden_dir, name):
+    """Oracle hidden_states[k] (embedding output, the frozen/trainable boundary, last_hidden_state) vs HF's, taken
+    from the reference's own text encoder (real tokens only)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+    keep = torch.from_numpy(z["mask"]).bool()
+    for k in meta["layers"]:
+        h = O.encode_tokens(z["ids"], z["mask"], w, cfg, layers=k)[keep].numpy()
+        assert np.abs(h - z[f"h{k}"]).max() < 2e-5, k
