@@ -99,6 +99,15 @@ def test_roberta_large_shape_matches_oracle():
     outb = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens).cpu().numpy()
     cos = (outb * ref).sum(1) / np.linalg.norm(outb, axis=1) / np.linalg.norm(ref, axis=1)
     assert np.abs(outb - ref).max() < 0.1 and cos.min() > 0.999
+    # degenerate shapes on the 256x256 / deferred-LayerNorm schedule: a single news of 2, 3 and 128 tokens, and chunks
+    # that end in the middle of a 256-row tile
+    for l1 in (2, 3, 128):
+        i1, m1 = synth_news_tokens(1, cfg, seed=9, lengths=np.array([l1]))
+        r1 = O.encode_cls(i1, m1, w, cfg).numpy()
+        o1 = enc.encode_cls(_cuda(i1), _cuda(m1), precision="bf16").cpu().numpy()
+        assert np.abs(o1 - r1).max() < 0.1, l1
+    outc = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=1000).cpu().numpy()
+    assert np.array_equal(outb, outc)
     enc.status()
 
 
