@@ -27,6 +27,7 @@ template <int NKT>
 __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                int tok0, int L, int H, int head, char* vl) {
   const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
+  char* ol = vl + NKT * 32 * 128;                 // output slab behind the V image
   const size_t ld = 3 * (size_t)H;
   const bf16_t* Qb = qkv + (size_t)tok0 * ld + head * 64;
   const bf16_t* Kb = Qb + H;
@@ -136,19 +137,30 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
         }
       }
     }
-    const int q = 32 * qb + rr;
-    if (q < L) {
+    // O^T -> ctx rows through a wave-private 4 KiB slab (32 queries x 128 B, XOR-swizzled 16-byte chunks): the lane
+    // that owns query rr writes its 8-byte runs, then every store instruction covers 8 whole 128-byte row segments
+    // (straight from the accumulator layout each row would be touched by 8 instructions, 16 bytes at a time)
+    {
       const float inv = 1.0f / l;
-      bf16_t* dst = ctx + (size_t)(tok0 + q) * H + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int d0 = 32 * dt + 8 * g + 4 * h;
-          *reinterpret_cast<bf16x4*>(dst + d0) =
+          const int c = 4 * dt + g;
+          *reinterpret_cast<bf16x4*>(ol + rr * 128 + ((c ^ (rr & 7)) << 4) + 8 * h) =
               bf16x4{(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv),
                      (bf16_t)(o[dt][4 * g + 2] * inv), (bf16_t)(o[dt][4 * g + 3] * inv)};
         }
+      __builtin_amdgcn_wave_barrier();
+      const int r8 = lane >> 3, sl = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + r8;
+        const int q = 32 * qb + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 128 + (sl << 4));
+        if (q < L) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + head * 64 + 8 * (sl ^ (row & 7))) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -334,7 +346,12 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
   const int64_t pairs = n_news * heads;
   if (dt == DT_BF16) {
     const int nkt = (max_len + 31) / 32;
-    const int lds_per_wave = nkt * 32 * 128;
+    const int lds_per_wave = nkt * 32 * 128 + 4096;   // V image + the 32-query output slab
+    static bool lds_raised = false;                   // 4 waves x 20 KiB exceeds the 64 KiB default of dynamic LDS
+    if (!lds_raised) {
+      MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 32 * 128 + 4096)));
+      lds_raised = true;
+    }
     hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
                        static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
   } else {
