@@ -4,17 +4,21 @@
 // "keys of the same news only"; head_dim is 64 and a news has at most 128 tokens (<= 4 key tiles).
 //
 // bf16 path — one 64-lane wave per (news, head), no workgroup barriers:
+//   memory    every global access is a 16-byte piece of a whole 128-byte row segment (8 lanes per row): K tiles and
+//             Q blocks go registers -> wave-private 4 KiB LDS slab (chunk-swizzled) -> MFMA fragments, V goes by
+//             LDS-DMA straight into its row-major image, O^T leaves through the same slab.  Stores straight from the
+//             accumulator layout (16 bytes per row per instruction) cost 20 us of a 97 us launch; with the slab the
+//             kernel moves its 403 MB at 5.5 TB/s.
 //   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K rows as the A operand: a lane then owns ONE query
 //                 (column) and 16 keys per 32-key tile, so max / sum are in-lane reductions plus
 //                 one exchange with lane^32; softmax runs ONLINE over the key tiles so that only one
-//                 S^T tile is live and the registers it frees hold the Q fragments of every query
-//                 block (one load phase per wave instead of one exposed round trip per block);
+//                 S^T tile is live; the next query block's rows are requested while the current one computes;
 //   O^T = V^T P^T the S^T accumulators, converted pairwise to bf16, ARE the B operand of the second
 //                 product (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
 //                 operand"), k-order permuted: element j of lane half h is key 16s+8(j>>2)+4h+(j&3);
 //                 V sits row-major in a wave-private LDS image and is read key-permuted and
 //                 transposed with ds_read_b64_tr_b16.  O^T keeps the query on the lane, so the
-//                 1/sum scaling is lane-local and stores are 8-byte runs along the ctx row.
+//                 1/sum scaling is lane-local.
 // f32 path — exact-f32 VALU kernel for the parity mode, one workgroup per (news, head).
 #include <math.h>
 
@@ -33,35 +37,48 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
   const bf16_t* Kb = Qb + H;
   const bf16_t* Vb = Qb + 2 * H;
 
-  // V -> LDS [32*NKT][64] bf16 row-major; rows >= L replicate row L-1 (finite, weighted by P = 0)
+  // Every global access is a 16-byte piece of a whole 128-byte row segment (lane = (row lane>>3, chunk lane&7));
+  // the MFMA-layout fragments are then read back from LDS.  Loads straight in the fragment layout touch each row in
+  // four instructions, 32 bytes at a time, and were what bounded the kernel.
+  const int r8 = lane >> 3, c8 = lane & 7;
+  // all loads of the pair in flight first: K tiles and the first Q block to registers, V by LDS-DMA straight into its
+  // row-major image (lane-linear destination = 8 rows x 128 B per instruction; no registers)
+  f32x4 kt_[NKT][4], qt_[4];
 #pragma unroll
-  for (int r0 = 0; r0 < 32 * NKT; r0 += 8) {
-    const int row = r0 + (lane >> 3);
-    const int sr = min(row, L - 1);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vb + (size_t)sr * ld + (lane & 7) * 8);
-    *reinterpret_cast<bf16x8*>(vl + row * 128 + (lane & 7) * 16) = v;
-  }
-  // K fragments (A operand): lane (rr, h) holds K[key = 32kt + rr][d = 16ks + 8h .. +7]
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(32 * kt + 8 * i + r8, L - 1);      // rows >= L replicate row L-1 (finite; masked / weighted by 0)
+      kt_[kt][i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)row * ld + 8 * (c8 ^ (((8 * i + r8) >> 1) & 7)));
+    }
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(32 * kt + 8 * i + r8, L - 1);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(Vb + (size_t)row * ld + 8 * c8), LDS_PTR(vl + (32 * kt + 8 * i) * 128), 16, 0, 0);
+    }
+  auto load_q = [&](int qb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(32 * qb + 8 * i + r8, L - 1);
+      qt_[i] = *reinterpret_cast<const f32x4*>(Qb + (size_t)row * ld + 8 * (c8 ^ (((8 * i + r8) >> 1) & 7)));
+    }
+  };
+  load_q(0);
+  // K: one 32-key tile at a time through the 4 KiB slab, chunk-swizzled -> fragments: lane (rr, h) holds
+  // K[key = 32kt + rr][d = 16ks + 8h .. +7], i.e. chunk 2ks + h of row rr
   bf16x8 kf[NKT][4];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    const int key = min(32 * kt + rr, L - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ol + (8 * i + r8) * 128 + (c8 << 4)) = kt_[kt][i];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      kf[kt][ks] = *reinterpret_cast<const bf16x8*>(Kb + (size_t)key * ld + (2 * ks + h) * 8);
+      kf[kt][ks] = *reinterpret_cast<const bf16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
+    __builtin_amdgcn_wave_barrier();
   }
-  // Q fragments of EVERY 32-query block, requested together with K and V: the wave has one load phase
-  // instead of one exposed memory round trip per query block
-  bf16x8 qf[NKT][4];
-#pragma unroll
-  for (int qb = 0; qb < NKT; ++qb) {
-    const int qrow = min(32 * qb + rr, L - 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[qb][ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ld + (2 * ks + h) * 8);
-  }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own V image is in LDS
 
   // per-lane address of the transposed V reads: 16-lane group g, lane i = 4q + p of the group
   // supplies row q, columns 4p..4p+3 of the group's 4x16 block
@@ -71,6 +88,18 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
   for (int qb = 0; qb < NKT; ++qb) {
     if (32 * qb >= L) break;
+    // Q block: rows -> output slab (free between blocks), chunk-swizzled -> fragments; the next block's rows are
+    // requested before this block's arithmetic starts
+    bf16x8 qfb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ol + (8 * i + r8) * 128 + (c8 << 4)) = qt_[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qfb[ks] = *reinterpret_cast<const bf16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
+    __builtin_amdgcn_wave_barrier();
+    if (qb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the V image (LDS-DMA is not tracked by the compiler)
+    if (qb + 1 < NKT && 32 * (qb + 1) < L) load_q(qb + 1);
     // online softmax over the 32-key tiles (one S^T tile = 16 registers live at a time): running max m of
     // the RAW scores, running sum l, O^T rescaled by exp(m_old - m_new) only when some row's max moved.
     // The kernel is issue-bound on this VALU work, so it is kept minimal: scale (1/8) and log2(e) are
@@ -88,7 +117,7 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qb][ks], st, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qfb[ks], st, 0, 0, 0);
       if (kt == NKT - 1) {                             // L > 32 (NKT - 1): earlier tiles hold real keys only
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -137,7 +166,7 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
         }
       }
     }
-    // O^T -> ctx rows through a wave-private 4 KiB slab (32 queries x 128 B, XOR-swizzled 16-byte chunks): the lane
+    // O^T -> ctx rows through a wave-private 4 KiB slab (32 queries x 128 B, 16-byte chunks XOR-swizzled with (row>>1)&7: two 128-byte rows share a 64-bank span): the lane
     // that owns query rr writes its 8-byte runs, then every store instruction covers 8 whole 128-byte row segments
     // (straight from the accumulator layout each row would be touched by 8 instructions, 16 bytes at a time)
     {
@@ -147,18 +176,17 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = 4 * dt + g;
-          *reinterpret_cast<bf16x4*>(ol + rr * 128 + ((c ^ (rr & 7)) << 4) + 8 * h) =
+          *reinterpret_cast<bf16x4*>(ol + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4) + 8 * h) =
               bf16x4{(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv),
                      (bf16_t)(o[dt][4 * g + 2] * inv), (bf16_t)(o[dt][4 * g + 3] * inv)};
         }
       __builtin_amdgcn_wave_barrier();
-      const int r8 = lane >> 3, sl = lane & 7;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = 8 * i + r8;
         const int q = 32 * qb + row;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 128 + (sl << 4));
-        if (q < L) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + head * 64 + 8 * (sl ^ (row & 7))) = v;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 128 + (c8 << 4));
+        if (q < L) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + head * 64 + 8 * (c8 ^ ((row >> 1) & 7))) = v;
       }
       __builtin_amdgcn_wave_barrier();
     }
