@@ -219,6 +219,9 @@ def table_mode(args, cfg, enc, pool, rank, world, dev):
             "scorer_pairs_per_s": total_c / sc_s, "scorer_GBps_algorithmic": hbm_bytes / sc_s / 1e9 / world,
             "scorer_frac_of_8TBps": hbm_bytes / sc_s / 1e9 / world / HBM_PEAK_GBS,
             "allgather_ms": 1e3 * ag_s, "allgather_bytes_per_rank": (n_news - (hi - lo)) * cfg.hidden * 4 if world > 1 else 0,
+            # bytes every rank RECEIVES over xGMI / time, against 7 links x 153 GB/s per GPU
+            "allgather_GBps_per_rank": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9) if world > 1 and ag_s > 0 else None,
+            "allgather_frac_of_xgmi": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9 / (7 * 153.0)) if world > 1 and ag_s > 0 else None,
             "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item()}
 
 
