@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 from manner_amd import hip, hotpath  # noqa: E402
 from manner_amd.config import PRESETS  # noqa: E402
-from manner_amd.synth import MIND_SMALL, shard_range, synth_impressions, synth_news_tokens  # noqa: E402
+from manner_amd.synth import (MIND_SMALL, shard_range, synth_impression_blocks, synth_impressions,  # noqa: E402
+                              synth_news_tokens)
 from manner_amd.weights import make_plm_weights  # noqa: E402
 
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md chip table
@@ -257,9 +258,10 @@ def main():
     pool_len = pool_mask_np.sum(1)
     pool_ids, pool_mask = torch.from_numpy(pool_ids_np).to(dev), torch.from_numpy(pool_mask_np).to(dev)
     n_steps = args.warmup + args.steps
-    # disjoint impressions per rank: one global list, contiguous block per rank
-    imp_all = synth_impressions(world * n_steps * args.impressions, n_news, seed=42)
-    lo_r, _ = shard_range(world * n_steps * args.impressions, rank, world)
+    # one independent 256-impression draw per (rank, step): step s of rank r is the same batch for every --steps and
+    # --gpus, so the figure does not depend on how many steps were asked for beyond averaging over more batches
+    imp_all = synth_impression_blocks([rank * 1_000_000 + s for s in range(n_steps)], args.impressions, n_news, seed=42)
+    lo_r = 0
     batches = [StepBatch(imp_all, lo_r + s * args.impressions, lo_r + (s + 1) * args.impressions, pool_ids, pool_mask,
                          pool_len, dev) for s in range(n_steps)]
     max_news = max(b.ids.shape[0] for b in batches)

@@ -9,7 +9,7 @@ uses sorted segment ids, ``segment_ids`` converts).
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Sequence, Optional
 
 import numpy as np
 
@@ -78,6 +78,20 @@ def synth_impressions(n_imp: int, n_news: int, seed: int = 42, max_hist: int = 5
     labels[cand_off[:-1] + (g.random(n_imp) * c).astype(np.int64)] = 1.0
     return {"hist_idx": hist_idx, "hist_off": hist_off, "cand_idx": cand_idx, "cand_off": cand_off,
             "labels": labels}
+
+
+def synth_impression_blocks(block_ids: Sequence[int], block: int, n_news: int, seed: int = 42) -> Dict[str, np.ndarray]:
+    """Concatenation of independent ``block``-impression draws, one per id: block ``b`` is the same whatever the
+    other ids are, so a benchmark's step s of rank r sees the same batch for every step count and world size."""
+    parts = [synth_impressions(block, n_news, seed=seed + 7919 * (int(b) + 1)) for b in block_ids]
+    out = {k: np.concatenate([p[k] for p in parts]) for k in ("hist_idx", "cand_idx", "labels")}
+    for k in ("hist_off", "cand_off"):
+        off, base = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            off.append(p[k][1:] + base)
+            base += int(p[k][-1])
+        out[k] = np.concatenate(off)
+    return out
 
 
 def segment_ids(offsets: np.ndarray) -> np.ndarray:
