@@ -241,3 +241,16 @@ def test_parse_behaviors_both_wire_formats(tmp_path):
             assert got.labels[got.cand_off[i]:got.cand_off[i + 1]].tolist() == [float(x) for x in frame["labels"][i]]
     with pytest.raises(KeyError):
         parse_behaviors(["user\thistory\tcandidates\tlabels", "1\t['N1']\t['N999999']\t[1]"], nid2row, 50)
+
+
+def test_impression_blocks_are_prefix_stable():
+    """bench.py draws one block per (rank, step): asking for more steps must not change the earlier batches."""
+    from manner_amd.synth import synth_impression_blocks
+    a = synth_impression_blocks([0, 1], 64, 5000, seed=42)
+    b = synth_impression_blocks([0, 1, 2, 1_000_000], 64, 5000, seed=42)
+    n_h, n_c = int(a["hist_off"][-1]), int(a["cand_off"][-1])
+    assert np.array_equal(a["hist_idx"], b["hist_idx"][:n_h]) and np.array_equal(a["cand_idx"], b["cand_idx"][:n_c])
+    assert np.array_equal(a["hist_off"], b["hist_off"][:129]) and np.array_equal(a["labels"], b["labels"][:n_c])
+    assert b["hist_off"].shape == (257,) and b["cand_off"][-1] == b["cand_idx"].shape[0] == b["labels"].shape[0]
+    for i in range(256):                                       # >= 1 positive per impression survives the concatenation
+        assert b["labels"][b["cand_off"][i]:b["cand_off"][i + 1]].max() == 1.0
