@@ -28,6 +28,9 @@ class EncoderConfig:
     type_vocab: int = 2
     ln_eps: float = 1e-12
     pad_id: int = 0
+    # parameter naming of the HF checkpoint: "bert" (BertModel / RobertaModel) or "distilbert" (DistilBertModel: same
+    # post-LayerNorm block, no token-type embedding, no pooler, q_lin/k_lin/... names) — see weights.canonical_weights
+    naming: str = "bert"
 
     @property
     def head_dim(self) -> int:
@@ -61,6 +64,10 @@ PRESETS = {
     # shapes and the 4-vector LayerNorm of configs[4] without 355 M parameters
     "mini-roberta-large": EncoderConfig(arch=ARCH_ROBERTA, hidden=1024, layers=2, heads=16, intermediate=4096,
                                         vocab=4096, max_pos=130, type_vocab=1, ln_eps=1e-5, pad_id=1),
+    # the multilingual experiments of the reference use distilbert-base-multilingual-cased
+    "distilbert-base-multilingual-cased": EncoderConfig(layers=6, vocab=119547, type_vocab=1, naming="distilbert"),
+    "tiny-distilbert": EncoderConfig(hidden=128, layers=2, heads=2, intermediate=512, vocab=2048, max_pos=128,
+                                     type_vocab=1, naming="distilbert"),
     "tiny-roberta": EncoderConfig(arch=ARCH_ROBERTA, hidden=128, layers=2, heads=2,
                                   intermediate=512, vocab=2048, max_pos=130, type_vocab=1,
                                   ln_eps=1e-5, pad_id=1),
@@ -74,8 +81,14 @@ def from_hf_config(path: str) -> EncoderConfig:
     with open(path) as f:
         c = json.load(f)
     mt = c.get("model_type", "bert")
+    if mt == "distilbert":
+        if c.get("activation", "gelu") != "gelu":
+            raise ValueError("the HIP encoder implements exact erf GeLU only")
+        return EncoderConfig(arch=ARCH_BERT, hidden=c["dim"], layers=c["n_layers"], heads=c["n_heads"],
+                             intermediate=c["hidden_dim"], vocab=c["vocab_size"], max_pos=c["max_position_embeddings"],
+                             type_vocab=1, ln_eps=1e-12, pad_id=c.get("pad_token_id", 0), naming="distilbert")
     if mt not in ("bert", "roberta", "xlm-roberta"):
-        raise ValueError(f"unsupported PLM model_type {mt!r}: the HIP encoder implements BERT/RoBERTa")
+        raise ValueError(f"unsupported PLM model_type {mt!r}: the HIP encoder implements BERT / RoBERTa / DistilBERT")
     if c.get("hidden_act", "gelu") != "gelu":
         raise ValueError("the HIP encoder implements exact erf GeLU only")
     if c.get("position_embedding_type", "absolute") != "absolute":

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from .config import EncoderConfig
-from .weights import plm_param_shapes
+from .weights import canonical_weights, plm_param_shapes
 
 Tensor = torch.Tensor
 
@@ -59,7 +59,8 @@ class HipEncoder:
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("HipEncoder needs a GPU device — there is no CPU fallback")
-        shapes = dict(plm_param_shapes(cfg))
+        weights = canonical_weights(cfg, weights)           # DistilBERT names -> BERT names (+ zero token-type row)
+        shapes = dict(plm_param_shapes(cfg if cfg.naming == "bert" else EncoderConfig(**{**cfg.to_dict(), "naming": "bert"})))
         names = weight_table_order(cfg)
         keep = []
         with torch.cuda.device(self.device):

@@ -39,7 +39,7 @@ class HipPLM(nn.Module):
         self.cfg = cfg
         for name, shape in plm_param_shapes(cfg, with_pooler=True):
             t = torch.empty(shape, dtype=torch.float32)
-            if name.endswith("LayerNorm.weight"):
+            if name.endswith(("LayerNorm.weight", "layer_norm.weight")):
                 t.fill_(1.0)
             elif name.endswith(".bias"):
                 t.zero_()
@@ -70,7 +70,7 @@ class HipPLM(nn.Module):
             own = model.state_dict()
             fixed = {}
             for k, v in sd.items():
-                for pre in ("bert.", "roberta.", ""):
+                for pre in ("bert.", "roberta.", "distilbert.", ""):
                     if k.startswith(pre) and k[len(pre):] in own:
                         fixed[k[len(pre):]] = v
                         break

@@ -21,8 +21,53 @@ import numpy as np
 from .config import EncoderConfig
 
 
+_DISTIL_TO_BERT = (("attention.q_lin.", "attention.self.query."), ("attention.k_lin.", "attention.self.key."),
+                   ("attention.v_lin.", "attention.self.value."), ("attention.out_lin.", "attention.output.dense."),
+                   ("sa_layer_norm.", "attention.output.LayerNorm."), ("ffn.lin1.", "intermediate.dense."),
+                   ("ffn.lin2.", "output.dense."), ("output_layer_norm.", "output.LayerNorm."))
+
+
+def canonical_weights(cfg: EncoderConfig, weights):
+    """The encoder and the oracle speak BertModel parameter names.  A DistilBertModel state dict (same post-LayerNorm
+    block: transformers/models/distilbert/modeling_distilbert.py) is renamed and given an all-zero token-type row."""
+    if cfg.naming != "distilbert":
+        return weights
+    out = {}
+    for k, v in weights.items():
+        if k.startswith("transformer.layer."):
+            k = "encoder.layer." + k[len("transformer.layer."):]
+            for a, b in _DISTIL_TO_BERT:
+                if a in k:
+                    k = k.replace(a, b)
+                    break
+        out[k] = v
+    ref = out["embeddings.LayerNorm.bias"]
+    out["embeddings.token_type_embeddings.weight"] = ref.new_zeros((1, cfg.hidden)) if hasattr(ref, "new_zeros") \
+        else np.zeros((1, cfg.hidden), np.float32)
+    return out
+
+
 def plm_param_shapes(cfg: EncoderConfig, with_pooler: bool = True) -> Iterator[Tuple[str, Tuple[int, ...]]]:
     h, i = cfg.hidden, cfg.intermediate
+    if cfg.naming == "distilbert":
+        yield "embeddings.word_embeddings.weight", (cfg.vocab, h)
+        yield "embeddings.position_embeddings.weight", (cfg.max_pos, h)
+        yield "embeddings.LayerNorm.weight", (h,)
+        yield "embeddings.LayerNorm.bias", (h,)
+        for l in range(cfg.layers):
+            p = f"transformer.layer.{l}."
+            for n in ("q_lin", "k_lin", "v_lin", "out_lin"):
+                yield p + f"attention.{n}.weight", (h, h)
+                yield p + f"attention.{n}.bias", (h,)
+            yield p + "sa_layer_norm.weight", (h,)
+            yield p + "sa_layer_norm.bias", (h,)
+            yield p + "ffn.lin1.weight", (i, h)
+            yield p + "ffn.lin1.bias", (i,)
+            yield p + "ffn.lin2.weight", (h, i)
+            yield p + "ffn.lin2.bias", (h,)
+            yield p + "output_layer_norm.weight", (h,)
+            yield p + "output_layer_norm.bias", (h,)
+        return
     yield "embeddings.word_embeddings.weight", (cfg.vocab, h)
     yield "embeddings.position_embeddings.weight", (cfg.max_pos, h)
     yield "embeddings.token_type_embeddings.weight", (cfg.type_vocab, h)
@@ -65,7 +110,7 @@ def make_plm_weights(cfg: EncoderConfig, seed: int = 42, std: float = 0.02,
     out: Dict[str, np.ndarray] = {}
     for name, shape in plm_param_shapes(cfg, with_pooler):
         g = _stream(seed, name)
-        if name.endswith("LayerNorm.weight"):
+        if name.endswith(("LayerNorm.weight", "layer_norm.weight")):
             w = 1.0 + 0.05 * g.standard_normal(shape, dtype=np.float32)
         elif name.endswith(".bias"):
             w = 0.02 * g.standard_normal(shape, dtype=np.float32)

@@ -42,6 +42,33 @@ def _t(x) -> Tensor:
 
 # --------------------------------------------------------------------------- encoder (K1-K7)
 
+_DISTIL = (("attention.q_lin.", "attention.self.query."), ("attention.k_lin.", "attention.self.key."),
+           ("attention.v_lin.", "attention.self.value."), ("attention.out_lin.", "attention.output.dense."),
+           ("sa_layer_norm.", "attention.output.LayerNorm."), ("ffn.lin1.", "intermediate.dense."),
+           ("ffn.lin2.", "output.dense."), ("output_layer_norm.", "output.LayerNorm."))
+
+
+def bert_named(w: Dict[str, Tensor], cfg) -> Dict[str, Tensor]:
+    """DistilBertModel (transformers/models/distilbert/modeling_distilbert.py) is the BertModel block without
+    token-type embeddings and pooler: Embeddings.forward = LN(word + position) (:90-118), TransformerBlock.forward =
+    sa_layer_norm(attn + x), output_layer_norm(ffn + .) (:270-300), q scaled by 1/sqrt(d_head) before the scores
+    (:180-190: same product).  Its state dict is renamed to BertModel names with an all-zero token-type row, so the
+    functions below serve both."""
+    if getattr(cfg, "naming", "bert") != "distilbert":
+        return w
+    out = {}
+    for k, v in w.items():
+        if k.startswith("transformer.layer."):
+            k = "encoder.layer." + k[len("transformer.layer."):]
+            for a, b in _DISTIL:
+                if a in k:
+                    k = k.replace(a, b)
+                    break
+        out[k] = v
+    out["embeddings.token_type_embeddings.weight"] = torch.zeros((1, cfg.hidden))
+    return out
+
+
 def position_ids(ids: Tensor, arch: int, pad_id: int) -> Tensor:
     """BERT: arange(L) (transformers/models/bert/modeling_bert.py:65,83-84).
     RoBERTa: cumsum(ids != pad) * (ids != pad) + pad
@@ -93,7 +120,7 @@ def encode_tokens(ids: Tensor, mask: Tensor, w: Dict[str, Tensor], cfg,
                   layers: Optional[int] = None) -> Tensor:
     """last_hidden_state [N,L,H] of BertModel.forward (modeling_bert.py:623-686) in eval mode."""
     ids, mask = _t(ids).long(), _t(mask)
-    w = {k: _t(v) for k, v in w.items()}
+    w = bert_named({k: _t(v) for k, v in w.items()}, cfg)
     x = embeddings(ids, w, cfg)
     # additive padding mask over keys (create_bidirectional_mask, modeling_bert.py:704-708)
     add_mask = torch.zeros(mask.shape, dtype=torch.float32)

@@ -48,7 +48,12 @@ def hf_model_dir(cfg, weights, tmp):
               num_attention_heads=cfg.heads, intermediate_size=cfg.intermediate,
               max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
               layer_norm_eps=cfg.ln_eps, pad_token_id=cfg.pad_id, hidden_act="gelu")
-    if cfg.arch == ARCH_BERT:
+    if cfg.naming == "distilbert":
+        from transformers import DistilBertConfig, DistilBertModel
+        model = DistilBertModel(DistilBertConfig(vocab_size=cfg.vocab, dim=cfg.hidden, n_layers=cfg.layers, n_heads=cfg.heads,
+                                                 hidden_dim=cfg.intermediate, max_position_embeddings=cfg.max_pos,
+                                                 pad_token_id=cfg.pad_id, activation="gelu"))
+    elif cfg.arch == ARCH_BERT:
         model = BertModel(BertConfig(**kw))
     else:
         model = RobertaModel(RobertaConfig(**kw))
@@ -85,8 +90,8 @@ def gen_encoder(name, preset, n, lp, seed, std, lengths=None):
                          "preset": preset, "seed": seed, "std": std,
                          "sha256": {k: tensor_sha256(w[k]) for k in
                                     ("embeddings.word_embeddings.weight",
-                                     "encoder.layer.0.attention.self.query.weight",
-                                     "encoder.layer.%d.output.dense.bias" % (cfg.layers - 1))}}))
+                                     [n for n in w if n.endswith((".query.weight", ".q_lin.weight"))][0],
+                                     [n for n in w if n.endswith((".output.dense.bias", ".ffn.lin2.bias"))][-1])}}))
     print(name, out.shape, float(np.abs(out).mean()))
     return keys
 
@@ -216,6 +221,12 @@ def gen_pipeline(seed=42):
 
 
 if __name__ == "__main__":
+    if "--distilbert-only" in sys.argv:
+        keys = json.load(open(os.path.join(HERE, "state_dict_keys.json")))
+        keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)
+        with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+            json.dump(keys, f, indent=0)
+        sys.exit(0)
     if "--hidden-only" in sys.argv:
         gen_hidden("hidden_tiny_bert", "tiny-bert", n=6, lp=24, seed=42, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),
                    layers_out=(0, 1, 2))
@@ -230,6 +241,7 @@ if __name__ == "__main__":
     keys["bert-base-uncased"] = gen_encoder("enc_bert_base", "bert-base-uncased", n=16, lp=96, seed=42,
                                             std=0.02, lengths=lens)
     gen_encoder("enc_bert_base_spread", "bert-base-uncased", n=16, lp=96, seed=44, std=0.05, lengths=lens)
+    keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)
     keys["user_encoder"] = gen_components()
     keys["tiny-bert-entities"] = gen_entities()
     gen_pipeline()

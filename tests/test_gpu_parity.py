@@ -40,7 +40,7 @@ def _encoder(preset, seed, std):
     return _ENC[key]
 
 
-GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_bert_base", "enc_bert_base_spread"]
+GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_ENC)

@@ -254,3 +254,30 @@ def test_impression_blocks_are_prefix_stable():
     assert b["hist_off"].shape == (257,) and b["cand_off"][-1] == b["cand_idx"].shape[0] == b["labels"].shape[0]
     for i in range(256):                                       # >= 1 positive per impression survives the concatenation
         assert b["labels"][b["cand_off"][i]:b["cand_off"][i + 1]].max() == 1.0
+
+
+def test_distilbert_directory_loading_and_keys(tmp_path, golden_dir):
+    """distilbert-base-multilingual-cased is the PLM of the reference's multilingual configs: a local
+    DistilBertModel directory loads under its own parameter names, and those are the reference checkpoint's keys."""
+    from safetensors.torch import save_file
+    from manner_amd.models.components.news_encoder import HipPLM, MannerTextEncoder
+    from manner_amd.weights import canonical_weights, make_plm_weights
+    cfg = PRESETS["tiny-distilbert"]
+    w = make_plm_weights(cfg, seed=45, std=0.05)
+    (tmp_path / "config.json").write_text(json.dumps({
+        "model_type": "distilbert", "dim": cfg.hidden, "n_layers": cfg.layers, "n_heads": cfg.heads,
+        "hidden_dim": cfg.intermediate, "vocab_size": cfg.vocab, "max_position_embeddings": cfg.max_pos,
+        "pad_token_id": 0, "activation": "gelu"}))
+    save_file({"distilbert." + k: torch.from_numpy(v) for k, v in w.items()}, str(tmp_path / "model.safetensors"))
+    m = HipPLM.from_pretrained(str(tmp_path))
+    assert m.cfg == cfg
+    sd = m.state_dict()
+    assert set(sd) == set(w) and all(np.array_equal(sd[k].numpy(), v) for k, v in w.items())
+    with open(os.path.join(golden_dir, "state_dict_keys.json")) as f:
+        ref_keys = json.load(f)["tiny-distilbert"]
+    enc = MannerTextEncoder(str(tmp_path), frozen_layers=[0], dropout_probability=0.2)
+    assert sorted("text_encoder." + k for k in enc.state_dict()) == ref_keys
+    frozen = [n for n, p in enc.plm_model.named_parameters() if not p.requires_grad]
+    assert frozen and all("layer.0." in n for n in frozen)                      # news_encoder.py:24-27 name test
+    c = canonical_weights(cfg, w)
+    assert "encoder.layer.1.attention.self.query.weight" in c and c["embeddings.token_type_embeddings.weight"].shape == (1, cfg.hidden)

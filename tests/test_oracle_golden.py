@@ -17,7 +17,7 @@ def _load(golden_dir, name):
     return z, json.loads(str(z["meta"]))
 
 
-@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_bert_base", "enc_bert_base_spread"])
+@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread"])
 def test_encoder_matches_reference(golden_dir, name):
     z, meta = _load(golden_dir, name)
     cfg = PRESETS[meta["preset"]]
@@ -79,7 +79,7 @@ def test_state_dict_keys_match_reference(golden_dir):
     """Our weight naming is the reference checkpoint naming."""
     with open(os.path.join(golden_dir, "state_dict_keys.json")) as f:
         keys = json.load(f)
-    for preset in ("tiny-bert", "bert-base-uncased"):
+    for preset in ("tiny-bert", "bert-base-uncased", "tiny-distilbert"):
         ours = sorted("text_encoder.plm_model." + n for n, _ in plm_param_shapes(PRESETS[preset]))
         assert ours == keys[preset]
     assert keys["user_encoder"] == sorted(
