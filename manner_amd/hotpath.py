@@ -124,3 +124,41 @@ def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights:
         scores = hip.zscore_fuse(torch.stack(planes), [w for w in weights if w != 0], imp["cand_off"])
     topk, ndcg, mrr = hip.rank_ndcg(scores, labels, imp["cand_off"], k, with_mrr=True)
     return {"scores": scores, "topk": topk, "ndcg": ndcg, "mrr": mrr}
+
+
+# ------------------------------------------------------------------------------------- epoch-end metrics
+
+def epoch_end_metrics(scores: Tensor, labels: Tensor, cand_off: Tensor, *, cand_categories: Optional[Tensor] = None,
+                       cand_sentiments: Optional[Tensor] = None, hist_categories: Optional[Tensor] = None,
+                       hist_sentiments: Optional[Tensor] = None, hist_off: Optional[Tensor] = None,
+                       num_categ_classes: int = 19, num_sent_classes: int = 4, with_auc_mrr: bool = True,
+                       prefix: str = "test/") -> Dict[str, Tensor]:
+    """What ``on_test_epoch_end`` logs, from the ragged epoch tensors and entirely on the device:
+
+    * CRModule (cr_module.py:78-87, 264-273): ``auc``, ``mrr``, ``ndcg@5``, ``ndcg@10``;
+    * EnsembleModule (ensemble_module.py:50-84, 214-252): ``ndcg@5/10`` plus, when the aspect tensors are given,
+      ``categ_div@5/10``, ``sent_div@5/10`` (manner/metrics/functional.py:8-28) and ``categ_pers@5/10``,
+      ``sent_pers@5/10`` (:31-62).
+    Retrieval metrics are means over impressions; AUC is one curve over all pairs (hip.auc).  Keys carry ``prefix``.
+    """
+    out: Dict[str, Tensor] = {}
+    tops = {}
+    for k in (5, 10):
+        topk, ndcg, mrr = hip.rank_ndcg(scores, labels, cand_off, k, with_mrr=True)
+        tops[k] = topk
+        out[f"{prefix}ndcg@{k}"] = ndcg.mean()
+        if k == 10 and with_auc_mrr:
+            out[f"{prefix}mrr"] = mrr.mean()
+    if with_auc_mrr:
+        out[f"{prefix}auc"] = hip.auc(scores, labels)
+    for name, cand, hist, classes in (("categ", cand_categories, hist_categories, num_categ_classes),
+                                      ("sent", cand_sentiments, hist_sentiments, num_sent_classes)):
+        if cand is None:
+            continue
+        for k in (5, 10):
+            div, pers = hip.aspect_metrics(tops[k], cand.to(torch.int32), cand_off, classes,
+                                           None if hist is None else hist.to(torch.int32), hist_off)
+            out[f"{prefix}{name}_div@{k}"] = div.mean()
+            if pers is not None:
+                out[f"{prefix}{name}_pers@{k}"] = pers.mean()
+    return out

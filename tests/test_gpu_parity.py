@@ -584,3 +584,28 @@ def test_encode_hidden_matches_reference(golden_dir, name):
         h2 = enc.encode_hidden(ids, mask, k, precision="fp32", host_lengths=z["mask"].sum(1), max_chunk_tokens=256).cpu()
         assert torch.equal(h, h2)
     enc.status()
+
+
+def test_epoch_metrics_match_oracle():
+    """The metric dict of on_test_epoch_end (CRModule + EnsembleModule collections) from one device call."""
+    g = np.random.Generator(np.random.PCG64(23))
+    nb = 200
+    c = g.integers(2, 60, nb); h = g.integers(1, 50, nb)
+    co = np.concatenate([[0], np.cumsum(c)]).astype(np.int64); ho = np.concatenate([[0], np.cumsum(h)]).astype(np.int64)
+    scores = g.standard_normal(co[-1]).astype(np.float32)
+    labels = (g.random(co[-1]) < 0.1).astype(np.float32)
+    labels[co[:-1]] = 1.0
+    ccat = g.integers(1, 19, co[-1]); csen = g.integers(0, 4, co[-1]); hcat = g.integers(1, 19, ho[-1]); hsen = g.integers(0, 4, ho[-1])
+    got = hotpath.epoch_end_metrics(_cuda(scores), _cuda(labels), _cuda(co), cand_categories=_cuda(ccat), cand_sentiments=_cuda(csen),
+                                     hist_categories=_cuda(hcat), hist_sentiments=_cuda(hsen), hist_off=_cuda(ho))
+    ts, tl = torch.from_numpy(scores), torch.from_numpy(labels)
+    want = {"test/auc": O.binary_auroc(ts, tl)[0], "test/mrr": O.mrr(ts, tl, co.tolist())[0]}
+    for k in (5, 10):
+        want[f"test/ndcg@{k}"] = O.ndcg_at_k(ts, tl, co.tolist(), k)[0]
+        for name, cc, hh, ncls in (("categ", ccat, hcat, 19), ("sent", csen, hsen, 4)):
+            want[f"test/{name}_div@{k}"] = float(O.diversity_at_k(ts, torch.from_numpy(cc), co.tolist(), ncls, k).mean())
+            want[f"test/{name}_pers@{k}"] = float(O.personalization_at_k(ts, torch.from_numpy(cc), torch.from_numpy(hh), co.tolist(),
+                                                                         ho.tolist(), ncls, k).mean())
+    assert set(got) == set(want)
+    for key, v in want.items():
+        assert abs(float(got[key]) - v) < 2e-5, (key, float(got[key]), v)
