@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--impressions", type=int, default=256, help="impressions per step per GPU")
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     p.add_argument("--profile", default="title_abstract", choices=["title", "title_abstract"],
                    help="token-length profile of the news pool (SURVEY.md §8d)")
     p.add_argument("--model", default="bert-base-uncased")
@@ -251,7 +251,7 @@ def main():
     log("generating seeded weights")
     weights = make_plm_weights(cfg, seed=42, std=args.std)
     log("packing weights into the HIP encoder")
-    enc = hip.HipEncoder(cfg, weights, precisions=("bf16", "fp32"), device=dev)
+    enc = hip.HipEncoder(cfg, weights, precisions=("bf16", "fp32") + (("bf16x3",) if args.precision == "bf16x3" else ()), device=dev)
     n_news = MIND_SMALL["n_news"]
     log("synthesising news pool + impressions")
     pool_ids_np, pool_mask_np = synth_news_tokens(n_news, cfg, seed=42, max_len=96, profile=args.profile)

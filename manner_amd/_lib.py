@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
 PREC_F32, PREC_BF16 = 0, 1
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+PREC_BF16X3 = 2
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 W_EMB_COUNT, WL_COUNT = 5, 16
 MAX_LEN = 128
 PROF_CLASSES = ["lengths", "embed_ln", "gemm_qkv", "attention", "gemm_out", "layernorm", "gemm_ffn1", "gemm_ffn2",

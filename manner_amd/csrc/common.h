@@ -38,7 +38,8 @@ int fail(int code, const char* fmt, ...);   // records the thread-local error te
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
-enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5 };
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5,
+                EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */ };
 enum DType { DT_F32 = 0, DT_BF16 = 1 };
 
 // Y[m, n] = epi( sum_k X[m, k] * W[n, k] + bias[n] )  for m < *m_total (device scalar).
@@ -84,6 +85,8 @@ int fold_layernorm(const float* w, const float* bias, const float* gamma, const 
 // out[n, t, :] = x[cu[n]+t] (normalised with mr/gamma/beta when mr != NULL) for t < len(n), zeros for padded positions
 int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const int32_t* cu, int64_t n_news, int64_t lp, int H,
                    const float* gamma, const float* beta, void* out, hipStream_t stream);
+// bf16x3: out [rows, 3K] bf16 = [hi | hi | lo] of x [rows, K] f32 (activations) or [hi | lo | hi] (weights); rows >= *m_total skipped
+int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream);
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);

@@ -55,7 +55,7 @@ struct manner_hip_encoder {
   uint32_t precisions = 0;
   float *word = nullptr, *pos = nullptr, *type0 = nullptr, *embg = nullptr, *embb = nullptr;
   std::vector<manner::LayerParams> params;
-  std::vector<manner::LayerWeights> w[2];   // [MANNER_HIP_PREC_*]
+  std::vector<manner::LayerWeights> w[3];   // [MANNER_HIP_PREC_*]; BF16X3: bf16 [out, 3*in] split weights
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
@@ -123,12 +123,14 @@ struct Workspace {
   void *x, *qkv, *ctx, *ffn;
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
   void *mr_in, *mr_mid, *part;       // deferred LayerNorm: {mean, rstd} per row (layer input / after attention), partial sums
+  void* a3;                          // BF16X3: split copy [M, 3*max(H, I)] bf16 of the current GEMM's f32 A operand
 };
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
   const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
   const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
   size_t off = 0;
+  if (ws) ws->a3 = nullptr;
   auto take = [&](size_t bytes) { size_t o = off; off += (size_t)round_up((int64_t)bytes, 256); return base ? base + o : nullptr; };
   char* p;
   p = take((size_t)max_news * 4); if (ws) ws->lens = (int32_t*)p;
@@ -145,6 +147,7 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   p = take((size_t)m_cap * 8); if (ws) ws->mr_in = p;
   p = take((size_t)m_cap * 8); if (ws) ws->mr_mid = p;
   p = take((size_t)m_cap * (H / 64) * 8); if (ws) ws->part = p;
+  if (prec == MANNER_HIP_PREC_BF16X3) { p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p; }
   return off;
 }
 
@@ -154,7 +157,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
                  int64_t m_bound, int prec, void* out, const Workspace& ws, hipStream_t s,
                  hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32) {
   const manner_hip_encoder_config& c = e->cfg;
-  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
+  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;   // activation dtype (BF16X3 keeps f32 activations)
   const int H = c.hidden, I = c.intermediate;
   int rc;
   {
@@ -213,17 +216,27 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
                               pos_offset, c.vocab, c.max_pos, ws.x, e->status, s)))
       return rc;
   }
+  // BF16X3: f32 activations everywhere; each GEMM first splits its A operand into [hi | hi | lo] bf16 (ws.a3) and
+  // runs on the bf16 MFMA against the [hi | lo | hi] split weight, depth 3K, f32 residual / output
+  const bool x3 = prec == MANNER_HIP_PREC_BF16X3;
+  auto gemm = [&](DType out_dt, Epilogue epi, const void* A, const void* Wm, const float* bias, const void* res, void* Y,
+                  int64_t mb, int N, int K, const int* mt) -> int {
+    if (!x3) return gemm_tn(dt, out_dt, epi, A, Wm, bias, res, Y, mb, N, K, mt, s);
+    int r = split3_rows(false, static_cast<const float*>(A), ws.a3, K, mb, mt, s);
+    if (r) return r;
+    return gemm_tn(DT_BF16, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, mb, N, 3 * K, mt, s);
+  };
   const int full_layers = hidden_layers >= 0 ? hidden_layers : c.layers - 1;
   for (int l = 0; l < full_layers; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
-    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
-    PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm(DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
     if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
-    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
-    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm(dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm(DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
   }
   if (hidden_layers >= 0) {
@@ -239,15 +252,15 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     const LayerParams& p = e->params[c.layers - 1];
     const int64_t n_bound = round_up(n_news, 256);
     const int32_t* n_total = ws.m_total + 1;
-    const char* wkv = static_cast<const char*>(w.wqkv) + (size_t)H * H * es;
-    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(dt, dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
+    const char* wkv = static_cast<const char*>(w.wqkv) + (size_t)H * (x3 ? (size_t)3 * H * 2 : (size_t)H * es);
+    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_rows(dt, ws.x, ws.cu, n_news, H, ws.xcls, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total))
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total))
     PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total))
     PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, static_cast<float*>(out), n_bound, n_total, s))
   }
   return MANNER_HIP_OK;
@@ -305,7 +318,8 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
   if (I <= 0 || I % 128 || L <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: intermediate=%d layers=%d unsupported", I, L);
   if (cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->type_vocab <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: bad table sizes");
   if (n_weights != MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT) return fail(MANNER_HIP_E_INVALID, "encoder_create: expected %d weight pointers, got %d", MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT, n_weights);
-  if (!(precisions & 3u) || (precisions & ~3u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
+  if (!(precisions & 7u) || (precisions & ~7u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
+  if ((precisions & (1u << MANNER_HIP_PREC_BF16X3)) && (H % 256 || I % 256)) return fail(MANNER_HIP_E_INVALID, "encoder_create: BF16X3 needs hidden and intermediate sizes that are multiples of 256 (H=%d I=%d)", H, I);
   for (int i = 0; i < n_weights; ++i)
     if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "encoder_create: weight pointer %d is null", i);
 
@@ -339,7 +353,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     }
     if (rc) break;
     e->params.resize(L);
-    for (int p = 0; p < 2; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
+    for (int p = 0; p < 3; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
     for (int l = 0; l < L && !rc; ++l) {
       const float* const* wl = weights + MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT;
       LayerParams& P = e->params[l];
@@ -365,6 +379,16 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
         guard(pack_matrix(p, wl[MANNER_HIP_WL_AO_W], HH, W.wo, 0, s));
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF1_W], HI, W.w1, 0, s));
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF2_W], HI, W.w2, 0, s));
+      }
+      if ((precisions & (1u << MANNER_HIP_PREC_BF16X3)) && !rc) {       // [out, 3 in] bf16 split weights
+        LayerWeights& W = e->w[MANNER_HIP_PREC_BF16X3][l];
+        if (!guard(dev_alloc(e, 3 * HH * 6, &W.wqkv)) || !guard(dev_alloc(e, HH * 6, &W.wo)) ||
+            !guard(dev_alloc(e, HI * 6, &W.w1)) || !guard(dev_alloc(e, HI * 6, &W.w2))) break;
+        for (int j = 0; j < 3; ++j)
+          guard(split3_rows(true, wl[MANNER_HIP_WL_Q_W + 2 * j], static_cast<bf16_t*>(W.wqkv) + (size_t)j * HH * 3, H, H, nullptr, s));
+        guard(split3_rows(true, wl[MANNER_HIP_WL_AO_W], W.wo, H, H, nullptr, s));
+        guard(split3_rows(true, wl[MANNER_HIP_WL_FF1_W], W.w1, H, I, nullptr, s));
+        guard(split3_rows(true, wl[MANNER_HIP_WL_FF2_W], W.w2, I, H, nullptr, s));
       }
       if (e->defer_ln && !rc) {
         // fold the LayerNorm that feeds each GEMM into its weight: the embedding LayerNorm (layer 0) or the
@@ -393,7 +417,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
 }
 
 size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens, int32_t precision) {
-  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 1) return 0;
+  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 2) return 0;
   return enc->n_streams * carve(enc, max_news, round_up(max_tokens, 256), precision, nullptr, nullptr);
 }
 
@@ -404,7 +428,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_cls: null handle");
   if (n_news == 0) return MANNER_HIP_OK;
   if (!ids || !mask || !out || !workspace || n_news < 0) return fail(MANNER_HIP_E_INVALID, "encode_cls: null pointer");
-  if (precision < 0 || precision > 1 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
+  if (precision < 0 || precision > 2 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
   if (padded_len < 1 || padded_len > MANNER_HIP_MAX_LEN) return fail(MANNER_HIP_E_INVALID, "encode_cls: padded_len %lld outside [1, %d]", (long long)padded_len, MANNER_HIP_MAX_LEN);
   if ((uintptr_t)workspace % 256) return fail(MANNER_HIP_E_INVALID, "encode_cls: workspace must be 256-byte aligned");
   const int H = enc->cfg.hidden;
@@ -413,7 +437,8 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   const int ns = enc->profiling ? 1 : enc->n_streams;   // per-kernel timing wants un-overlapped launches
   const size_t ws_each = (workspace_bytes / enc->n_streams) / 256 * 256;   // same chunk size with or without profiling
   const size_t es = precision == MANNER_HIP_PREC_BF16 ? 2 : 4;
-  const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es;
+  const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es +
+                         (precision == MANNER_HIP_PREC_BF16X3 ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) : 0);
   int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;
   int64_t n_cap = 0;
   while (m_cap >= 256) {

@@ -839,7 +839,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           }
           if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_poly(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);   // f32 out: parity-grade erf
           }
           const int c = nl / OPC;
           const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
@@ -848,12 +848,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       }
       __builtin_amdgcn_wave_barrier();
       bf16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
-      if (EPI == EPI_BIAS_RES && ABL != 1) {          // TOut == float: the slab's residual loads in one batch
+      f32x4 resf[EPI == EPI_BIAS_RES_F32 ? SQ : 1];
+      if ((EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_F32) && ABL != 1) {   // TOut == float: the slab's residual loads in one batch
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
           const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
-          res[q] = *reinterpret_cast<const bf16x4*>(R + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+          const size_t idx = (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC;
+          if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const bf16x4*>(R + idx);
+          else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
         }
       }
 #pragma unroll
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
         }
+        if (EPI == EPI_BIAS_RES_F32) raw += resf[q];
         if (m < M) {
           f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
           // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
@@ -912,6 +916,12 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
     case EPI_BIAS_RES:
       hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
+    case EPI_BIAS_RES_F32:
+      if constexpr (sizeof(TOut) == 4) {
+        hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+        break;
+      }
+      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 writes f32");
     default:
       return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
@@ -998,7 +1008,9 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   const int esz = in == DT_BF16 ? 2 : 4;
   if (N % BN || (K * esz) % ROW_BYTES || m_bound % BM)
     return fail(MANNER_HIP_E_INVALID, "gemm shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
-  if (epi == EPI_BIAS_RES && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
+  if ((epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_F32) && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
+  if (epi == EPI_BIAS_RES_F32 && !(in == DT_BF16 && out == DT_F32 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
+    return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 needs bf16 operands, f32 output and 256-tileable shapes");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
     static const bool use_x32 = getenv("MANNER_HIP_GEMM_X32") != nullptr;   // A/B: bf16 on the 32x32x16 shape

@@ -286,6 +286,26 @@ __global__ __launch_bounds__(256) void scatter_hidden_kernel(const TIn* __restri
   }
 }
 
+// ---- bf16x3 operand splits.  Activations: out[m] = [hi(x[m]) | hi(x[m]) | lo(x[m])], weights: [hi | lo | hi] with
+// hi = bf16(v), lo = bf16(v - hi): the depth-3K dot product of the two is hi.hi + hi.lo + lo.hi.
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int K,
+                                                     int64_t rows, const int* __restrict__ m_total) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows || (m_total && row >= *m_total)) return;
+  const float* src = x + (size_t)row * K;
+  bf16_t* dst = out + (size_t)row * 3 * K;
+  for (int c = threadIdx.x * 4; c < K; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = (bf16_t)(v[e] - (float)hi[e]); }
+    *reinterpret_cast<bf16x4*>(dst + c) = hi;
+    *reinterpret_cast<bf16x4*>(dst + K + c) = WEIGHT ? lo : hi;
+    *reinterpret_cast<bf16x4*>(dst + 2 * K + c) = WEIGHT ? hi : lo;
+  }
+}
+
 // ---- K7: out[n] = x[cu[n]] (the [CLS] row), as f32
 template <typename TIn>
 __global__ __launch_bounds__(256) void gather_cls_kernel(const TIn* __restrict__ x, const int32_t* __restrict__ cu,
@@ -389,6 +409,14 @@ int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const 
     if (out_dt == DT_F32) SCATTER(float, float, false); else SCATTER(float, bf16_t, false);
   }
 #undef SCATTER
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream) {
+  if (K % 4) return fail(MANNER_HIP_E_INVALID, "split3: K=%d", K);
+  if (weight) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)rows), dim3(256), 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
+  else hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)rows), dim3(256), 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -609,3 +609,26 @@ def test_epoch_metrics_match_oracle():
     assert set(got) == set(want)
     for key, v in want.items():
         assert abs(float(got[key]) - v) < 2e-5, (key, float(got[key]), v)
+
+
+@pytest.mark.parametrize("name", ["enc_bert_base", "enc_bert_base_spread"])
+def test_encoder_bf16x3_close_to_the_fp32_bar(golden_dir, name):
+    """BF16X3: f32 activations, every GEMM on the bf16 MFMA over hi/lo-split operands (depth 3K): 16-bit operand
+    mantissas.  Stated tolerance 2.5e-4 against the reference's CLS embeddings (measured 3.3e-5 with HF-init weights,
+    1.1e-4 with the spread weights — the f32-MFMA mode stays THE 1e-4 parity mode), chunk-invariant, hidden states too."""
+    z, meta = _load(golden_dir, name)
+    cfg = PRESETS[meta["preset"]]
+    enc = hip.HipEncoder(cfg, make_plm_weights(cfg, seed=meta["seed"], std=meta["std"]), precisions=("bf16x3", "fp32"), device=DEV)
+    ids, mask = _cuda(z["ids"]), _cuda(z["mask"])
+    out = enc.encode_cls(ids, mask, precision="bf16x3", host_lengths=z["mask"].sum(1)).cpu().numpy()
+    enc.status()
+    err = np.abs(out - z["out"]).max()
+    ref32 = enc.encode_cls(ids, mask, precision="fp32").cpu().numpy()
+    print(f"{name}: bf16x3 max-abs err vs reference {err:.3e} (f32-MFMA mode {np.abs(ref32 - z['out']).max():.3e})")
+    assert err < 2.5e-4
+    out2 = enc.encode_cls(ids, mask, precision="bf16x3", host_lengths=z["mask"].sum(1), max_chunk_tokens=256).cpu().numpy()
+    assert np.array_equal(out, out2)
+    h = enc.encode_hidden(ids, mask, 8, precision="bf16x3").cpu()
+    h32 = enc.encode_hidden(ids, mask, 8, precision="fp32").cpu()
+    assert float((h - h32).abs().max()) < 2.5e-4
+    enc.close()
