@@ -87,7 +87,8 @@ class HipPLM(nn.Module):
 class MannerTextEncoder(nn.Module):
     """reference news_encoder.py:11-37."""
 
-    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate) or "fp32" (f32 MFMA parity mode)
+    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate), "fp32" (f32 MFMA parity mode) or "bf16x3"
+    #: (f32 activations, split-operand bf16 GEMMs: 2x the fp32 mode, within 2.5e-4)
     precision: str = os.environ.get("MANNER_HIP_PRECISION", "bf16")
 
     def __init__(self, plm_model: str, frozen_layers: List[int], dropout_probability: float) -> None:
@@ -109,12 +110,13 @@ class MannerTextEncoder(nn.Module):
 
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
         params = dict(self.plm_model.named_parameters())
-        key = (str(device), tuple((p.data_ptr(), p._version) for p in params.values()))
+        key = (str(device), self.precision == "bf16x3", tuple((p.data_ptr(), p._version) for p in params.values()))
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
                 self._hip.close()
+            precisions = ("bf16", "fp32") + (("bf16x3",) if self.precision == "bf16x3" else ())
             self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
-                                       precisions=("bf16", "fp32"), device=device)
+                                       precisions=precisions, device=device)
             self._hip_key = key
         return self._hip
 
