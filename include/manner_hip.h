@@ -42,7 +42,7 @@ enum { MANNER_HIP_ARCH_BERT = 0, MANNER_HIP_ARCH_ROBERTA = 1 };
  * chains; the 1e-4 parity mode).  BF16: bf16 operands, f32 accumulation, f32 LayerNorm/softmax.
  * BF16X3: f32 activations and f32 attention / LayerNorm / erf-GeLU as in F32, but every GEMM runs on the bf16 MFMA
  * over split operands — x = hi + lo, W = hi + lo (bf16 each), x W^T ~ hi.hi + hi.lo + lo.hi as ONE bf16 GEMM of
- * depth 3K: 16-bit operand mantissas, f32 accumulation.  2x the F32 mode's speed at 3e-5 .. 1.1e-4 of the reference
+ * depth 3K: 16-bit operand mantissas, f32 accumulation.  2.3x the F32 mode's speed at 3e-5 .. 1.1e-4 of the reference
  * (stated tolerance 2.5e-4; F32 remains THE 1e-4 parity mode).  Needs H and I multiples of 256. */
 enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1, MANNER_HIP_PREC_BF16X3 = 2 };
 

@@ -19,8 +19,10 @@
 //                 V sits row-major in a wave-private LDS image and is read key-permuted and
 //                 transposed with ds_read_b64_tr_b16.  O^T keeps the query on the lane, so the
 //                 1/sum scaling is lane-local.
-// f32 path — exact-f32 VALU kernel for the parity mode, one workgroup per (news, head).
+// f32 path — exact-f32 kernel for the parity modes on the f32 matrix pipe (attn_wave_f32); the older VALU kernel, one
+// workgroup per (news, head), stays selectable for A/B.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -210,7 +212,147 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   else attn_wave_bf16<4>(qkv, ctx, tok0, L, H, head, vl);
 }
 
-// exact-f32 attention: one workgroup (128 threads, one per query) per (news, head)
+// ---- exact-f32 attention on the f32 matrix pipe: the structure of attn_wave_bf16 with v_mfma_f32_32x32x2_f32 (exact f32
+// products, f32 accumulation): S^T = K Q^T with lane (key rr, half h) holding K[key][32h .. 32h+31] — the MFMA's two
+// k-slots pair feature s with feature 32+s for Q and K alike, which is just another summation order — softmax online
+// over 32-key tiles with expf, and the S^T accumulators as the B operand of O^T = V^T P^T, V^T read row-wise from a
+// row-major f32 LDS image (two key rows per ds_read_b32).  All global traffic in whole 256-byte row segments.
+template <int NKT>
+__device__ __forceinline__ void attn_wave_f32(const float* __restrict__ qkv, float* __restrict__ ctx, int tok0, int L, int H,
+                                              int head, char* vl) {
+  const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
+  char* ol = vl + NKT * 32 * 256;                 // 8 KiB slab (32 rows x 256 B) behind the V image
+  const size_t ld = 3 * (size_t)H;
+  const float* Qb = qkv + (size_t)tok0 * ld + head * 64;
+  const float* Kb = Qb + H;
+  const float* Vb = Qb + 2 * H;
+  const int r4 = lane >> 4, c16 = lane & 15;      // coalesced piece: row r4 of a 4-row group, 16-byte chunk c16 of 16
+  // V by LDS-DMA straight into its row-major image: 4 rows x 256 B per instruction, lane-linear
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(32 * kt + 4 * i + r4, L - 1);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(Vb + (size_t)row * ld + 4 * c16), LDS_PTR(vl + (32 * kt + 4 * i) * 256), 16, 0, 0);
+    }
+  // a 32-row tile of K or Q: coalesced rows -> slab (16-byte chunks XOR-swizzled with row & 15) -> lane (rr, h) takes
+  // the 32 features 32h .. 32h+31 of row rr
+  auto tile_to_frag = [&](const float* base, int row0, float (&frag)[32]) {
+    f32x4 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(row0 + 4 * i + r4, L - 1);
+      t[i] = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + 4 * (c16 ^ ((4 * i + r4) & 15)));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(ol + (4 * i + r4) * 256 + (c16 << 4)) = t[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ol + rr * 256 + (((8 * h + j) ^ (rr & 15)) << 4));
+      frag[4 * j] = v[0]; frag[4 * j + 1] = v[1]; frag[4 * j + 2] = v[2]; frag[4 * j + 3] = v[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  float kf[NKT][32];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) tile_to_frag(Kb, 32 * kt, kf[kt]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the V image has landed (LDS-DMA is not tracked by the compiler)
+#pragma unroll
+  for (int qb = 0; qb < NKT; ++qb) {
+    if (32 * qb >= L) break;
+    float qf[32];
+    tile_to_frag(Qb, 32 * qb, qf);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][s2], qf[s2], st, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        st[e] = key < L ? st[e] * 0.125f : -INFINITY;            // scores / sqrt(64), as the reference scales them
+      }
+      float tmx = st[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) tmx = fmaxf(tmx, st[e]);
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+      const float mn = fmaxf(m, tmx);
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = expf(st[e] - mn); rs += st[e]; }
+      rs += __shfl_xor(rs, 32, 64);
+      const float alpha = kt == 0 ? 0.f : expf(m - mn);
+      l = l * alpha + rs;
+      if (kt > 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+      }
+      m = mn;
+      // O^T += V^T P^T: MFMA step t pairs key 8(t>>2) + (t&3) (k-slot 0) with key + 4 (k-slot 1) — the keys the two
+      // lane halves hold in accumulator element t
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const char* vrow = vl + (32 * kt + 8 * (t >> 2) + (t & 3) + 4 * h) * 256 + rr * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const float vv = *reinterpret_cast<const float*>(vrow + 128 * dt);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[t], o[dt], 0, 0, 0);
+        }
+      }
+    }
+    // O^T -> ctx rows through the slab: lane (query rr, half h) owns features 32dt + 8g + 4h .. +3
+    {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = (32 * dt + 8 * g + 4 * h) >> 2;             // 16-byte chunk 0..15 of the 256-byte row
+          *reinterpret_cast<f32x4*>(ol + rr * 256 + ((c ^ (rr & 15)) << 4)) =
+              f32x4{o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + r4;
+        const int q = 32 * qb + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 256 + (c16 << 4));
+        if (q < L) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + head * 64 + 4 * (c16 ^ (row & 15))) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(128, 1) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                               const int32_t* __restrict__ cu, int64_t n_pairs, int heads,
+                                                               int H, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char vlds[];
+  const int wave = threadIdx.x >> 6;
+  const int64_t pair = (int64_t)blockIdx.x * 2 + wave;
+  if (pair >= n_pairs) return;
+  const int n = (int)(pair / heads), head = (int)(pair - (int64_t)n * heads);
+  const int tok0 = __builtin_amdgcn_readfirstlane(cu[n]);
+  const int L = __builtin_amdgcn_readfirstlane(cu[n + 1]) - tok0;
+  char* vl = vlds + wave * lds_per_wave;
+  if (L <= 32) attn_wave_f32<1>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 64) attn_wave_f32<2>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 96) attn_wave_f32<3>(qkv, ctx, tok0, L, H, head, vl);
+  else attn_wave_f32<4>(qkv, ctx, tok0, L, H, head, vl);
+}
+
+// exact-f32 attention, VALU form (MANNER_HIP_ATTN_F32_VALU=1): one workgroup (128 threads, one per query) per (news, head)
 __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                        const int32_t* __restrict__ cu, int heads, int H) {
   __shared__ __attribute__((aligned(16))) float Ks[MANNER_HIP_MAX_LEN * 64];
@@ -383,8 +525,21 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
     hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
                        static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
   } else {
-    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)pairs), dim3(128), 0, stream, static_cast<const float*>(qkv),
-                       static_cast<float*>(ctx), cu, heads, H);
+    static const bool valu = getenv("MANNER_HIP_ATTN_F32_VALU") != nullptr;       // A/B switch: the older VALU kernel
+    if (valu) {
+      hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)pairs), dim3(128), 0, stream, static_cast<const float*>(qkv),
+                         static_cast<float*>(ctx), cu, heads, H);
+    } else {
+      const int nkt = (max_len + 31) / 32;
+      const int lds_per_wave = nkt * 32 * 256 + 8192;   // f32 V image + the 32-row slab
+      static bool lds_raised = false;
+      if (!lds_raised) {
+        MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
+        lds_raised = true;
+      }
+      hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(128), 2 * lds_per_wave, stream,
+                         static_cast<const float*>(qkv), static_cast<float*>(ctx), cu, pairs, heads, H, lds_per_wave);
+    }
   }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
