@@ -167,7 +167,38 @@ def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
     ms = e0.elapsed_time(e1) / iters
     slots = sum(mb[s]["text"]["input_ids"].numel() for s in ("x_hist", "x_cand"))
     nbytes = 20 * slots + 8 * (mb["batch_hist"].numel() + mb["batch_cand"].numel())
+    # the same kernels on a batch large enough to leave the launch-bound regime: 8192 impressions in one call
+    big = synth_impressions(8192, pool_ids_np.shape[0], seed=77)
+    bbig = ParsedBehaviors(np.zeros(8192, np.int64), big["hist_idx"].astype(np.int32), big["hist_off"].astype(np.int64),
+                           big["cand_idx"].astype(np.int32), big["cand_off"].astype(np.int64), big["labels"].astype(np.float32))
+    cbig = DeviceCollate(store, bbig)
+    mbig = cbig(range(0, 8192))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        mbig = cbig(range(0, 8192))
+    e1.record()
+    torch.cuda.synchronize()
+    ms_big = e0.elapsed_time(e1) / 5
+    slots_big = sum(mbig[s]["text"]["input_ids"].numel() for s in ("x_hist", "x_cand"))
+    bytes_big = 20 * slots_big + 8 * (mbig["batch_hist"].numel() + mbig["batch_cand"].numel())
+    # the text kernel alone (no host-side offset slicing, no allocation of the small tensors)
+    rows_d, lp_big = cbig.cand_rows_d, int(mbig["x_cand"]["text"]["input_ids"].shape[1])
+    hip.collate_text(store.ids_d, store.len_d, rows_d, lp_big, store.pad_id)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        out_ids, _ = hip.collate_text(store.ids_d, store.len_d, rows_d, lp_big, store.pad_id)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_text = e0.elapsed_time(e1) / 5
+    bytes_text = 20 * out_ids.numel()
+    del mbig, cbig, out_ids
     return {"ms_per_batch": ms, "matches_step_inputs": same, "impressions": args.impressions, "token_slots": slots,
+            "large_batch": {"impressions": 8192, "ms": ms_big, "algorithmic_bytes": bytes_big, "GB/s": bytes_big / ms_big / 1e6,
+                            "frac_of_8TBps": bytes_big / ms_big / 1e6 / HBM_PEAK_GBS,
+                            "text_kernel_ms": ms_text, "text_kernel_GB/s": bytes_text / ms_text / 1e6,
+                            "text_kernel_frac_of_8TBps": bytes_text / ms_text / 1e6 / HBM_PEAK_GBS},
             "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "padded_len": [int(mb[s]["text"]["input_ids"].shape[1]) for s in ("x_hist", "x_cand")],
             "note": "wall time of DeviceCollate.__call__ incl. host offset slicing and 10 small kernel launches; "
                     "launch-bound at this batch size, HBM roofline applies to the text kernel only"}
