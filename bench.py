@@ -238,6 +238,22 @@ def table_mode(args, cfg, enc, pool, rank, world, dev):
         res = hotpath.score_impressions([table], dimp, labels=labels, k=10)
         sync(); t3 = time.perf_counter()
         times = {"encode_s": t1 - t0, "allgather_s": t2 - t1, "score_s": t3 - t2, "total_s": t3 - t0}
+    # epoch-end metrics of this rank's block on the device: timed separately, not part of total_s
+    def timed_ms(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    sc_r, off_r = res["scores"], dimp["cand_off"]
+    n_c = int(sc_r.numel())
+    metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
+                  "auc": timed_ms(lambda: hip.auc(sc_r, labels)),
+                  "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
     st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"]], dtype=torch.float64, device=dev)
     nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -254,7 +270,9 @@ def table_mode(args, cfg, enc, pool, rank, world, dev):
             # bytes every rank RECEIVES over xGMI / time, against 7 links x 153 GB/s per GPU
             "allgather_GBps_per_rank": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9) if world > 1 and ag_s > 0 else None,
             "allgather_frac_of_xgmi": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9 / (7 * 153.0)) if world > 1 and ag_s > 0 else None,
-            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item()}
+            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(),
+            "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
+                                 "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}
 
 
 def main():
