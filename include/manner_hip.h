@@ -120,7 +120,8 @@ int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const in
  * manner/models/components/news_encoder.py:20 (n_layers = 0: embedding output; = layers: last_hidden_state).
  * n_layers = 8 is the frozen / trainable boundary of the shipped configs (frozen_layers [0..7],
  * configs/model/cr_module.yaml:10; news_encoder.py:24-27): these activations do not change across training epochs and can
- * be cached per news.  Arguments as manner_hip_encode_cls; out [n_news, padded_len, H] of
+ * be cached per news — provided the embedding tables, which that name test does not freeze, are
+ * not trained either.  Arguments as manner_hip_encode_cls; out [n_news, padded_len, H] of
  * out_dtype (0 = f32, 1 = bf16).  Rows of padded positions are written as zeros: HF computes throw-away values there
  * which never reach a real token (keys are masked) — feed the tensor with the same attention_mask. */
 int manner_hip_encode_hidden(manner_hip_encoder_t enc, const int64_t* input_ids, const int64_t* attention_mask,

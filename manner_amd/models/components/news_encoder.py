@@ -140,7 +140,9 @@ class MannerTextEncoder(nn.Module):
         """HF ``hidden_states[n_layers]`` [N, Lp, H] computed by the HIP encoder without autograd — by default up to
         the first trainable layer (the constructor's ``frozen_layers`` must then be a prefix 0..k-1, as in
         configs/model/cr_module.yaml:10).  These activations are constant across epochs, so a training loop can cache
-        them per news and run only layers k.. in PyTorch with gradients."""
+        them per news and run only layers k.. in PyTorch with gradients.  Note that the
+        reference's name test freezes the encoder layers only — its embedding tables keep training — so a cached
+        prefix reproduces the reference exactly only when the embeddings are frozen as well."""
         if n_layers is None:
             frozen = sorted({int(n.split("layer.")[1].split(".")[0]) for n, p in self.plm_model.named_parameters()
                              if "layer." in n and not p.requires_grad})
