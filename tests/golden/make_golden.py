@@ -221,6 +221,11 @@ def gen_pipeline(seed=42):
 
 
 if __name__ == "__main__":
+    if "--roberta-base-only" in sys.argv:
+        # roberta-base is the PLM of the reference's MIND configs (configs/experiment/cr_module_mind_all_scl_lf.yaml:25)
+        gen_encoder("enc_roberta_base", "roberta-base", n=16, lp=96, seed=46, std=0.02,
+                    lengths=np.array([5, 9, 12, 16, 17, 23, 31, 32, 33, 47, 48, 64, 65, 80, 95, 96]))
+        sys.exit(0)
     if "--distilbert-only" in sys.argv:
         keys = json.load(open(os.path.join(HERE, "state_dict_keys.json")))
         keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)
@@ -241,6 +246,7 @@ if __name__ == "__main__":
     keys["bert-base-uncased"] = gen_encoder("enc_bert_base", "bert-base-uncased", n=16, lp=96, seed=42,
                                             std=0.02, lengths=lens)
     gen_encoder("enc_bert_base_spread", "bert-base-uncased", n=16, lp=96, seed=44, std=0.05, lengths=lens)
+    gen_encoder("enc_roberta_base", "roberta-base", n=16, lp=96, seed=46, std=0.02, lengths=lens)
     keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)
     keys["user_encoder"] = gen_components()
     keys["tiny-bert-entities"] = gen_entities()

@@ -40,7 +40,7 @@ def _encoder(preset, seed, std):
     return _ENC[key]
 
 
-GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread"]
+GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_ENC)
@@ -611,7 +611,7 @@ def test_epoch_metrics_match_oracle():
         assert abs(float(got[key]) - v) < 2e-5, (key, float(got[key]), v)
 
 
-@pytest.mark.parametrize("name", ["enc_bert_base", "enc_bert_base_spread"])
+@pytest.mark.parametrize("name", ["enc_bert_base", "enc_bert_base_spread", "enc_roberta_base"])
 def test_encoder_bf16x3_close_to_the_fp32_bar(golden_dir, name):
     """BF16X3: f32 activations, every GEMM on the bf16 MFMA over hi/lo-split operands (depth 3K): 16-bit operand
     mantissas.  Stated tolerance 2.5e-4 against the reference's CLS embeddings (measured 3.3e-5 with HF-init weights,

@@ -17,7 +17,7 @@ def _load(golden_dir, name):
     return z, json.loads(str(z["meta"]))
 
 
-@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread"])
+@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base"])
 def test_encoder_matches_reference(golden_dir, name):
     z, meta = _load(golden_dir, name)
     cfg = PRESETS[meta["preset"]]
