@@ -632,3 +632,26 @@ def test_encoder_bf16x3_close_to_the_fp32_bar(golden_dir, name):
     h32 = enc.encode_hidden(ids, mask, 8, precision="fp32").cpu()
     assert float((h - h32).abs().max()) < 2.5e-4
     enc.close()
+
+
+def test_deferred_layernorm_chunk_invariance_fuzz():
+    """Random news counts / lengths / chunk sizes on the 256x256 deferred-LayerNorm schedule: every chunking gives the same
+    bits as the single-chunk run (ragged last tiles, rows beyond M, tiles straddling news), and stays near the oracle."""
+    enc, cfg = _encoder("mini-roberta-large", 5, 0.03)
+    w = make_plm_weights(cfg, seed=5, std=0.03)
+    g = np.random.Generator(np.random.PCG64(99))
+    for it in range(10):
+        n = int(g.integers(1, 400))
+        lens = g.integers(2, 129, n)
+        ids, mask = synth_news_tokens(n, cfg, seed=100 + it, lengths=lens)
+        base = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens)
+        for chunk in (int(g.choice([256, 512, 1000, 4096])), int(g.integers(300, 20000))):
+            out = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=chunk)
+            assert torch.equal(base, out), (it, n, chunk)
+        out_nolen = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16")            # padded chunking, device-side lengths
+        assert torch.equal(base, out_nolen), (it, n)
+        if it < 3:
+            ref = O.encode_cls(ids[:24], mask[:24], w, cfg).numpy()
+            assert np.abs(base[:24].cpu().numpy() - ref).max() < 0.1
+    assert torch.isfinite(base).all()
+    enc.status()
