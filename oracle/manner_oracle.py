@@ -26,7 +26,6 @@ are restated line by line; for those the fixtures pin self-consistency only.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
