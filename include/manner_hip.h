@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 1
+#define MANNER_HIP_ABI_VERSION 2
 
 enum {
   MANNER_HIP_OK = 0,
@@ -34,6 +34,17 @@ enum {
   MANNER_HIP_E_WORKSPACE = 2,   /* workspace too small */
   MANNER_HIP_E_RUNTIME = 3,     /* HIP runtime error */
   MANNER_HIP_E_INPUT = 4        /* device-side input validation failed (see encoder_status) */
+};
+
+/* Device-side input validation.  Kernels never fault on bad inputs: they raise one of these bits in a status word
+ * (the encoder handle's own, or the caller-owned int32 `status` argument of the scoring entry points, which may be
+ * NULL) and continue on a safe substitute.  The reference raises a Python exception in each of these cases. */
+enum {
+  MANNER_HIP_STATUS_MASK = 1,     /* attention_mask is not a right-padded 0/1 prefix with 1..MAX_LEN tokens */
+  MANNER_HIP_STATUS_TOKEN = 2,    /* input id / position outside the embedding tables (IndexError in the reference) */
+  MANNER_HIP_STATUS_FUSED = 4,    /* reserved (bounded-wait overflow of a fused kernel) */
+  MANNER_HIP_STATUS_INDEX = 8,    /* news / entity index outside the table (IndexError in the reference) */
+  MANNER_HIP_STATUS_LENGTHS = 16  /* host_lengths disagree with attention_mask (tokens beyond the chunk bound dropped) */
 };
 
 enum { MANNER_HIP_ARCH_BERT = 0, MANNER_HIP_ARCH_ROBERTA = 1 };
@@ -133,6 +144,10 @@ int manner_hip_encode_hidden(manner_hip_encoder_t enc, const int64_t* input_ids,
  * handle since the last status call saw an invalid mask (non-prefix, empty or longer than
  * MANNER_HIP_MAX_LEN); clears the flag. */
 int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stream);
+/* Non-blocking form: enqueues a copy of the flag word into `host_flag` (pinned host int32) followed by its reset,
+ * both on `stream`; the caller reads *host_flag once an event recorded after this call has completed.  This is how
+ * the module mirror surfaces bad inputs of call k at call k+1 without a host synchronisation per forward. */
+int manner_hip_encoder_status_async(manner_hip_encoder_t enc, int32_t* host_flag /*pinned host*/, manner_hip_stream_t stream);
 #define MANNER_HIP_MAX_LEN 128
 
 /* Optional per-kernel timing (the reference delegates profiling to Lightning's `profiler: simple`,
@@ -175,7 +190,7 @@ int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, co
                              int32_t D, int32_t heads, const float* in_proj_w, const float* in_proj_b,
                              const float* out_proj_w, const float* out_proj_b, const float* pool_w,
                              const float* pool_b, const float* pool_q, int32_t Q, float* out, void* workspace,
-                             size_t workspace_bytes, manner_hip_stream_t stream);
+                             size_t workspace_bytes, int32_t* status /*device, nullable*/, manner_hip_stream_t stream);
 int manner_hip_linear(const float* x, const float* weight, const float* bias, int64_t R, int32_t K, int32_t O,
                       float* y, manner_hip_stream_t stream);
 
@@ -192,20 +207,43 @@ int manner_hip_dot(const float* user, const float* cand, int64_t B, int64_t C, i
  * EnsembleModule._submodel_forward — manner/models/ensemble_module.py:116-135:
  * user_i = sum(table[hist_idx[hist_off[i]:hist_off[i+1]]]) / h_i ;
  * out[j] = <user_i, table[cand_idx[j]]> for j in [cand_off[i], cand_off[i+1]).
- * table f32 [n_rows, D]; idx int32; off int64 [B+1]; out f32 [cand_off[B]] (ragged order). */
+ * table f32 [n_rows, D] (D % 4 == 0, D <= 3072); idx int32; off int64 [B+1]; out f32 [cand_off[B]] (ragged order).
+ * An index outside [0, n_rows) raises MANNER_HIP_STATUS_INDEX in *status (device int32, nullable) where the
+ * reference's gather raises IndexError. */
 int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D,
                                  const int32_t* hist_idx, const int64_t* hist_off,
                                  const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
-                                 float* out, manner_hip_stream_t stream);
+                                 float* out, int32_t* status, manner_hip_stream_t stream);
+
+/* Same scorer with the user vectors given: the early-fusion tail of CRModule.forward —
+ * manner/models/cr_module.py:125-129 (user_vector = user_encoder(...), then the click predictor) — on ragged
+ * candidates: out[j] = <user[i, :], table[cand_idx[j]]> for j in [cand_off[i], cand_off[i+1]).  user f32 [B, D]. */
+int manner_hip_score_user(const float* table, int64_t n_rows, int32_t D, const float* user,
+                          const int32_t* cand_idx, const int64_t* cand_off, int64_t B, float* out,
+                          int32_t* status, manner_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- ragged -> dense (K9)
+ * Replaces torch_geometric.utils.to_dense_batch at its call sites — manner/models/cr_module.py:108-110,114,142;
+ * manner/models/ensemble_module.py:116-124,155-163: dense[b, j, :] = x[off[b] + j, :] for j < off[b+1] - off[b],
+ * every other slot of row b = fill[b] (fill == NULL: 0, what to_dense_batch writes); mask[b, j] = 1 on real slots.
+ * x f32 [off[B], D]; dense f32 [B, width, D]; mask uint8 [B, width] (nullable).  `width` comes from the caller
+ * (the collate knows the batch maximum), so nothing is read back to the host; items beyond `width` are dropped.
+ * `fill` carries the value the reference's dense ensemble matrix holds in padded slots (see zscore_fuse). */
+int manner_hip_to_dense(const float* x, const int64_t* off, int64_t B, int64_t width, int32_t D, const float* fill,
+                        float* dense, uint8_t* mask, manner_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- ensemble (K13+K14)
  * Replaces the z-normalisation of EnsembleModule._submodel_forward —
  * manner/models/ensemble_module.py:138-149 — and the fusion of EnsembleModule.forward — :95-109:
  * out = z(scores[0]) + sum_{k>=1, w[k-1] != 0} w[k-1] * z(scores[k]), z per impression with the
  * unbiased std (c_i == 1 gives NaN, as torch.std does).
- * scores: K planes of f32 [total] at stride `plane_stride` elements; weights host f32 [K-1]. */
+ * scores: K planes of f32 [total] at stride `plane_stride` elements; weights host f32 [K-1].
+ * pad_value f32 [B] (nullable): the value the reference's dense [B, Cmax] result holds in the PADDED slots of row i —
+ * its z-score runs over the whole zero-padded row (:145-149), so they become sum_k w_k (0 - mean_ik) / std_ik, not 0.
+ * Feed it to manner_hip_to_dense as `fill` to reproduce the reference's matrix slot for slot. */
 int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K, const float* weights /*host*/,
-                           const int64_t* cand_off, int64_t B, float* out, manner_hip_stream_t stream);
+                           const int64_t* cand_off, int64_t B, float* out, float* pad_value,
+                           manner_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- ranking / nDCG (K15)
  * Replaces what RetrievalNormalizedDCG(top_k=k) computes per impression (constructed at

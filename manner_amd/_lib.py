@@ -13,6 +13,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
+ABI_VERSION = 2
+STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
@@ -39,15 +41,18 @@ SIGNATURES = {
     "manner_hip_encode_cls": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P]),
     "manner_hip_encode_hidden": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "manner_hip_encoder_status": (C.c_int, [_P, _P]),
+    "manner_hip_encoder_status_async": (C.c_int, [_P, _P, _P]),
     "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
     "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_entity_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
-    "manner_hip_entity_encode": (C.c_int, [_P, _I64, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
+    "manner_hip_entity_encode": (C.c_int, [_P, _I64, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P, _P]),
     "manner_hip_linear": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "manner_hip_dot": (C.c_int, [_P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P]),
-    "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P]),
-    "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P]),
+    "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "manner_hip_score_user": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P]),
+    "manner_hip_to_dense": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P]),
+    "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P, _P]),
     "manner_hip_rank_ndcg": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "manner_hip_aspect_metrics": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_auc_workspace_bytes": (_SZ, [_I64]),
@@ -86,7 +91,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.manner_hip_abi_version() != 1:
+        if lib.manner_hip_abi_version() != ABI_VERSION:
             raise RuntimeError("libmanner_hip.so ABI version mismatch; rebuild with `python -m manner_amd.build`")
         _lib = lib
     return _lib

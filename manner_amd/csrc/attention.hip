@@ -517,7 +517,8 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
   if (dt == DT_BF16) {
     const int nkt = (max_len + 31) / 32;
     const int lds_per_wave = nkt * 32 * 128 + 4096;   // V image + the 32-query output slab
-    static bool lds_raised = false;                   // 4 waves x 20 KiB exceeds the 64 KiB default of dynamic LDS
+    static bool lds_raised_dev[MAX_DEVICES] = {};     // 4 waves x 20 KiB exceeds the 64 KiB default of dynamic LDS
+    bool& lds_raised = lds_raised_dev[current_device_slot()];   // the attribute is per device
     if (!lds_raised) {
       MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 32 * 128 + 4096)));
       lds_raised = true;
@@ -532,7 +533,8 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
     } else {
       const int nkt = (max_len + 31) / 32;
       const int lds_per_wave = nkt * 32 * 256 + 8192;   // f32 V image + the 32-row slab
-      static bool lds_raised = false;
+      static bool lds_raised_dev[MAX_DEVICES] = {};
+      bool& lds_raised = lds_raised_dev[current_device_slot()];
       if (!lds_raised) {
         MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
         lds_raised = true;

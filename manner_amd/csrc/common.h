@@ -37,6 +37,16 @@ int fail(int code, const char* fmt, ...);   // records the thread-local error te
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Per-DEVICE one-time state (a process may drive several GPUs through different handles): the current device id,
+// clamped to the cache size.
+constexpr int MAX_DEVICES = 64;
+static inline int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < MAX_DEVICES ? dev : MAX_DEVICES - 1;
+}
+int device_cus();   // compute units of the current device (gemm.hip)
+
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5,
                 EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */ };
@@ -60,8 +70,12 @@ int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, c
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
+// m_bound: rows the chunk's buffers hold; expect_tokens >= 0: what the caller's host_lengths promised.  A mask that
+// yields more tokens than m_bound is truncated there (cu clamped) and, like any disagreement with expect_tokens,
+// raises MANNER_HIP_STATUS_LENGTHS — downstream kernels never index past m_bound.
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens,
-                        int32_t* cu /*[n_news+1]*/, int32_t* m_total /*[2]: tokens, news*/, int32_t* status, hipStream_t stream);
+                        int32_t* cu /*[n_news+1]*/, int32_t* m_total /*[2]: tokens, news*/, int64_t m_bound,
+                        int64_t expect_tokens, int32_t* status, hipStream_t stream);
 int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu,
                     const float* word, const float* pos, const float* type0, const float* gamma,
                     const float* beta, int H, float eps, int pos_offset, int vocab, int max_pos,

@@ -153,16 +153,26 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
 
 // `hidden_layers` < 0: the [CLS] path (out = f32 [n_news, H]).  Otherwise the first `hidden_layers` layers run in
 // full and `out` receives their hidden states in the padded [n_news, lp, H] layout (dtype `hidden_dt`).
+// `phase_mark` (two-stream mode) is recorded on `s` half a layer in — or, when no full layer runs (n_layers = 0, a
+// one-layer model) or the chunk fails, when the function returns: whoever waits on it always waits on an event of
+// THIS call, so a side stream is ordered after everything the caller's stream had queued before it.
+struct PhaseGuard {
+  hipEvent_t ev; hipStream_t s; bool done = false;
+  void mark() { if (ev && !done) { (void)hipEventRecord(ev, s); done = true; } }
+  ~PhaseGuard() { mark(); }
+};
+
 int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t lp,
-                 int64_t m_bound, int prec, void* out, const Workspace& ws, hipStream_t s,
+                 int64_t m_bound, int64_t expect_tokens, int prec, void* out, const Workspace& ws, hipStream_t s,
                  hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32) {
+  PhaseGuard phase{phase_mark, s};
   const manner_hip_encoder_config& c = e->cfg;
   const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;   // activation dtype (BF16X3 keeps f32 activations)
   const int H = c.hidden, I = c.intermediate;
   int rc;
   {
     ProfScope ps(e, s, MANNER_HIP_PROF_LENGTHS);
-    if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, e->status, s))) return rc;
+    if ((rc = lengths_and_offsets(mask, n_news, lp, ws.lens, ws.cu, ws.m_total, m_bound, expect_tokens, e->status, s))) return rc;
   }
   const int pos_offset = c.arch == MANNER_HIP_ARCH_ROBERTA ? c.pad_id + 1 : 0;
 #define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
@@ -198,7 +208,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
       PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
       PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
-      if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
+      if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, p.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
@@ -234,7 +244,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
     PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm(DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.x, ws.pre, m_bound, H, H, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
-    if (l == 0 && phase_mark) (void)hipEventRecord(phase_mark, s);   // two-stream mode: the other stream starts half a layer later
+    if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm(dt, EPI_BIAS_GELU, ws.x, w.w1, p.b1, nullptr, ws.ffn, m_bound, I, H, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm(DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.x, ws.pre, m_bound, H, I, ws.m_total))
     PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows(dt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, ws.x, m_bound, ws.m_total, s))
@@ -452,20 +462,34 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   for (int i = 0; i < ns; ++i) carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace) + i * ws_each, &ws[i]);
   hipStream_t s0 = (hipStream_t)stream;
   int forked = 0;                                       // side streams in use so far
+  // join: the caller's stream waits for every side stream — on EVERY exit path, so that work left on a side stream
+  // by a failing call is still ordered before whatever the caller does next with the workspace
+  auto join = [&]() -> int {
+    for (int i = 1; i <= forked; ++i) {
+      MANNER_HIP_TRY(hipEventRecord(enc->join_ev[i], enc->side[i]));
+      MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev[i], 0));
+    }
+    forked = 0;
+    return MANNER_HIP_OK;
+  };
   int64_t n0 = 0;
   int chunk = 0;
   while (n0 < n_news) {
-    int64_t cnt = 0, m_bound;
+    int64_t cnt = 0, m_bound, expect = -1;
     if (host_lengths) {
       int64_t tok = 0;
       while (n0 + cnt < n_news && cnt < n_cap) {
         const int64_t len = host_lengths[n0 + cnt];
-        if (len < 1 || len > padded_len) return fail(MANNER_HIP_E_INVALID, "encode_cls: host_lengths[%lld]=%lld outside [1, padded_len]", (long long)(n0 + cnt), (long long)len);
+        if (len < 1 || len > padded_len) {
+          (void)join();
+          return fail(MANNER_HIP_E_INVALID, "encode_cls: host_lengths[%lld]=%lld outside [1, padded_len]", (long long)(n0 + cnt), (long long)len);
+        }
         if (tok + len > m_cap) break;
         tok += len;
         ++cnt;
       }
       m_bound = round_up(tok, 256);
+      expect = tok;
     } else {
       cnt = m_cap / padded_len;
       if (cnt > n_cap) cnt = n_cap;
@@ -478,22 +502,21 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
       // stream `lane` starts when the first chunk of stream lane-1 is half a layer in (its phase mark): from
       // then on the streams run out of phase, so the HBM-bound kernels of one (LayerNorm, attention, GEMM
       // epilogues) meet the MFMA-bound main loops of another
-      MANNER_HIP_TRY(hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0));
+      if (hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0) != hipSuccess) {
+        (void)join();
+        return fail(MANNER_HIP_E_RUNTIME, "encode_cls: hipStreamWaitEvent failed");
+      }
       forked = lane;
     }
     const size_t news_bytes = hidden_layers < 0 ? (size_t)H * 4 : (size_t)padded_len * H * (hidden_dt == DT_F32 ? 4 : 2);
-    int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, precision,
+    int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, expect, precision,
                           static_cast<char*>(out) + n0 * news_bytes, ws[lane], s,
                           (ns > 1 && chunk < ns - 1) ? enc->phase_ev[lane] : nullptr, hidden_layers, hidden_dt);
-    if (rc) return rc;
+    if (rc) { (void)join(); return rc; }
     n0 += cnt;
     ++chunk;
   }
-  for (int i = 1; i <= forked; ++i) {                   // join: the caller's stream waits for every side stream
-    MANNER_HIP_TRY(hipEventRecord(enc->join_ev[i], enc->side[i]));
-    MANNER_HIP_TRY(hipStreamWaitEvent(s0, enc->join_ev[i], 0));
-  }
-  return MANNER_HIP_OK;
+  return join();
 }
 
 int manner_hip_encode_cls(manner_hip_encoder_t enc, const int64_t* ids, const int64_t* mask, const int32_t* host_lengths,
@@ -519,9 +542,18 @@ int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stre
   MANNER_HIP_TRY(hipMemcpyAsync(&flag, enc->status, sizeof(flag), hipMemcpyDeviceToHost, s));
   MANNER_HIP_TRY(hipMemsetAsync(enc->status, 0, sizeof(flag), s));
   MANNER_HIP_TRY(hipStreamSynchronize(s));
-  if (flag & 1) return fail(MANNER_HIP_E_INPUT, "attention_mask is not a right-padded 0/1 prefix mask with 1..%d real tokens per news", MANNER_HIP_MAX_LEN);
-  if (flag & 2) return fail(MANNER_HIP_E_INPUT, "input_ids or position index out of range of the embedding tables");
-  if (flag & 4) return fail(MANNER_HIP_E_RUNTIME, "fused GEMM+LayerNorm: a panel's column tiles did not arrive within the bounded wait");
+  if (flag & MANNER_HIP_STATUS_MASK) return fail(MANNER_HIP_E_INPUT, "attention_mask is not a right-padded 0/1 prefix mask with 1..%d real tokens per news", MANNER_HIP_MAX_LEN);
+  if (flag & MANNER_HIP_STATUS_TOKEN) return fail(MANNER_HIP_E_INPUT, "input_ids or position index out of range of the embedding tables");
+  if (flag & MANNER_HIP_STATUS_LENGTHS) return fail(MANNER_HIP_E_INPUT, "host_lengths disagree with the row sums of attention_mask (tokens beyond the chunk bound were dropped)");
+  if (flag) return fail(MANNER_HIP_E_INPUT, "device status word 0x%x", flag);
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_encoder_status_async(manner_hip_encoder_t enc, int32_t* host_flag, manner_hip_stream_t stream) {
+  if (!enc || !host_flag) return fail(MANNER_HIP_E_INVALID, "encoder_status_async: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  MANNER_HIP_TRY(hipMemcpyAsync(host_flag, enc->status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MANNER_HIP_TRY(hipMemsetAsync(enc->status, 0, sizeof(int32_t), s));
   return MANNER_HIP_OK;
 }
 

@@ -17,14 +17,17 @@ constexpr int LIN_ROWS = 8;      // rows per workgroup of the generic linear ker
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ gather,
                                                           int64_t n_src_rows, const float* __restrict__ W,
                                                           const float* __restrict__ b, int64_t R, int K, int O,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float xs[];     // [LIN_ROWS][K]
   const int64_t r0 = (int64_t)blockIdx.x * LIN_ROWS;
   const int nr = (int)min((int64_t)LIN_ROWS, R - r0);
   for (int i = threadIdx.x; i < nr * K; i += 256) {
     const int rr = i / K, k = i - rr * K;
     int64_t src = r0 + rr;
-    if (gather) { src = gather[src]; src = src < 0 ? 0 : (src >= n_src_rows ? n_src_rows - 1 : src); }
+    if (gather) {                                    // nn.Embedding raises IndexError on such an id: flag it, read row 0
+      src = gather[src];
+      if (src < 0 || src >= n_src_rows) { if (status && k == 0) atomicOr(status, MANNER_HIP_STATUS_INDEX); src = 0; }
+    }
     xs[rr * K + k] = x[src * K + k];
   }
   __syncthreads();
@@ -96,11 +99,11 @@ __global__ __launch_bounds__(256) void entity_attn_kernel(const float* __restric
 }
 
 int launch_linear(const float* x, const int64_t* gather, int64_t n_src, const float* W, const float* b, int64_t R, int K,
-                  int O, float* y, hipStream_t s) {
+                  int O, float* y, hipStream_t s, int32_t* status = nullptr) {
   if (R == 0) return MANNER_HIP_OK;
   if (K <= 0 || O <= 0 || K > 4096) return fail(MANNER_HIP_E_INVALID, "linear: K=%d O=%d unsupported (K <= 4096)", K, O);
   hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)((R + LIN_ROWS - 1) / LIN_ROWS)), dim3(256), LIN_ROWS * K * sizeof(float), s,
-                     x, gather, n_src, W, b, R, K, O, y);
+                     x, gather, n_src, W, b, R, K, O, y, status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -127,7 +130,7 @@ int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, co
                              int32_t D, int32_t heads, const float* in_proj_w, const float* in_proj_b,
                              const float* out_proj_w, const float* out_proj_b, const float* pool_w, const float* pool_b,
                              const float* pool_q, int32_t Q, float* out, void* workspace, size_t workspace_bytes,
-                             manner_hip_stream_t stream) {
+                             int32_t* status, manner_hip_stream_t stream) {
   if (N == 0) return MANNER_HIP_OK;
   if (!entity_ids || !table || !in_proj_w || !in_proj_b || !out_proj_w || !out_proj_b || !pool_w || !pool_b || !pool_q || !out || !workspace)
     return fail(MANNER_HIP_E_INVALID, "entity_encode: null pointer");
@@ -142,7 +145,7 @@ int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, co
   float* scratch = proj + (size_t)R * D;                // [R] logits of the additive pooler (+ D spare)
   int rc;
   // embedding lookup fused into the in-projection (rows gathered from the table)
-  if ((rc = launch_linear(table, entity_ids, n_entities, in_proj_w, in_proj_b, R, D, 3 * D, qkv, s))) return rc;
+  if ((rc = launch_linear(table, entity_ids, n_entities, in_proj_w, in_proj_b, R, D, 3 * D, qkv, s, status))) return rc;
   const int dh = D / heads;
   dim3 g((unsigned)(E * heads), (unsigned)((N + 255) / 256)), b(256);
   switch (dh) {

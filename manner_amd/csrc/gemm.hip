@@ -894,13 +894,7 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
   const int n_tiles = N / G_BN;
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
-  static int n_cus = 0;                 // persistent grid: one workgroup per CU (128 KiB LDS each)
-  if (!n_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MANNER_HIP_E_RUNTIME, "hipGetDeviceProperties failed");
-    n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cus = device_cus();       // persistent grid: one workgroup per CU (160 KiB LDS each)
   dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* w = static_cast<const bf16_t*>(W);
@@ -959,13 +953,13 @@ int launch_big(Epilogue epi, const void* X, const void* W, const float* bias, co
 
 }  // namespace
 
-static int device_cus() {
-  static int n_cus = 0;
+int device_cus() {
+  static int cus[MAX_DEVICES] = {};
+  int& n_cus = cus[current_device_slot()];
   if (!n_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+    n_cus = v > 0 ? v : 256;
   }
   return n_cus;
 }

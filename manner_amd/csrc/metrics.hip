@@ -1,46 +1,35 @@
 // Global binary AUC over all (score, label) pairs of an evaluation run: what
 // torchmetrics AUROC(task="binary") computes for the reference (constructed at manner/models/cr_module.py:81,
-// fed with the ragged preds/targets at :267-273).  Integer work end to end: a device radix sort of the
-// order-preserving key of every score, then an exact Mann-Whitney count with ties at one half — the area under
-// the ROC curve drawn through the distinct thresholds.  The sort/scan/compaction primitives are rocPRIM's
-// (through hipCUB); the key, tie-group and reduction kernels are below.
-#include <hipcub/hipcub.hpp>
-
+// fed with the ragged preds/targets at :267-273).  Integer work end to end, every kernel below hand-written
+// (no hipCUB / rocPRIM):
+//   1. order-preserving u32 key of every score; the keys are split by label into a negatives and a positives
+//      array (wave-aggregated appends — their order is irrelevant, see 2 and 3);
+//   2. the NEGATIVES are sorted: LSD radix sort, 8-bit digits, 4 passes of {per-block digit histogram, one
+//      exclusive scan of the [digit][block] counts, stable scatter} — the stable rank of a key inside its block is
+//      (keys of the same digit in earlier waves) + (earlier rounds of its wave) + (lower lanes of its round), the
+//      last from 8 ballots;
+//   3. every POSITIVE key binary-searches the sorted negatives: it beats lb = #(neg < key) of them and ties with
+//      ub - lb, so it adds lb + ub to 2U — the exact Mann-Whitney count with ties at one half, i.e. the area under
+//      the ROC curve drawn through the distinct thresholds.  u64 integer atomics: order-free, deterministic.
 #include "common.h"
 
 namespace manner {
 namespace {
 
+constexpr int RS_ITEMS = 8;                        // keys per lane
+constexpr int RS_TILE = 256 * RS_ITEMS;            // keys per workgroup (4 waves x 64 lanes x 8 rounds)
+
 struct AucWs {            // carved from the caller's workspace
-  uint32_t* key_in;
-  uint32_t* key_out;
-  uint32_t* lab_in;       // 1 = negative (what the prefix scan counts)
-  uint32_t* lab_out;
-  uint32_t* cneg;         // exclusive prefix count of negatives in sorted order, [n]
-  uint32_t* head_pos;     // compacted start index of every tie group, [n]
-  uint32_t* scalars;      // [0] outside-[0,1] flag, [1] number of tie groups, [2] total negatives
+  uint32_t* neg_a;        // negatives' keys (ping)
+  uint32_t* neg_b;        // (pong)
+  uint32_t* pos;          // positives' keys
+  uint32_t* hist;         // [256][blocks] digit counts of one pass
+  uint32_t* scalars;      // [0] outside-[0,1] flag, [1] #negatives, [2] #positives
   unsigned long long* acc;   // [0] 2U
-  void* cub;
-  size_t cub_bytes;
 };
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-
-struct HeadFlag {          // flag iterator functor: 1 where a new key value starts
-  const uint32_t* key;
-  __host__ __device__ uint32_t operator()(uint32_t i) const { return i == 0 || key[i] != key[i - 1]; }
-};
-
-size_t cub_bytes_for(int64_t n) {
-  size_t a = 0, b = 0, c = 0;
-  uint32_t* p = nullptr;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, p, p, (int)n);
-  hipcub::CountingInputIterator<uint32_t> idx(0);
-  hipcub::TransformInputIterator<uint32_t, HeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(idx, HeadFlag{p});
-  (void)hipcub::DeviceSelect::Flagged(nullptr, c, idx, flags, p, p, (int)n);
-  return align256(a > b ? (a > c ? a : c) : (b > c ? b : c));
-}
+int64_t rs_blocks(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
 size_t carve(int64_t n, char* base, AucWs* w) {
   size_t off = 0;
@@ -50,14 +39,12 @@ size_t carve(int64_t n, char* base, AucWs* w) {
     return p;
   };
   const size_t vec = (size_t)n * sizeof(uint32_t);
-  char* k0 = take(vec); char* k1 = take(vec); char* l0 = take(vec); char* l1 = take(vec);
-  char* cn = take(vec); char* hp = take(vec); char* sc = take(64); char* ac = take(64);
-  const size_t cb = cub_bytes_for(n);
-  char* cu = take(cb);
+  char* a = take(vec); char* b = take(vec); char* p = take(vec);
+  char* h = take((size_t)256 * rs_blocks(n) * sizeof(uint32_t));
+  char* sc = take(64); char* ac = take(64);
   if (w) {
-    w->key_in = (uint32_t*)k0; w->key_out = (uint32_t*)k1; w->lab_in = (uint32_t*)l0; w->lab_out = (uint32_t*)l1;
-    w->cneg = (uint32_t*)cn; w->head_pos = (uint32_t*)hp; w->scalars = (uint32_t*)sc;
-    w->acc = (unsigned long long*)ac; w->cub = cu; w->cub_bytes = cb;
+    w->neg_a = (uint32_t*)a; w->neg_b = (uint32_t*)b; w->pos = (uint32_t*)p; w->hist = (uint32_t*)h;
+    w->scalars = (uint32_t*)sc; w->acc = (unsigned long long*)ac;
   }
   return off;
 }
@@ -73,46 +60,147 @@ __global__ __launch_bounds__(256) void auc_range_kernel(const float* __restrict_
   if (__any(out) && (threadIdx.x & 63) == 0) atomicOr(scalars, 1u);
 }
 
-// ascending order-preserving key of a float: flip all bits of negatives, the sign bit of the rest
-__global__ __launch_bounds__(256) void auc_key_kernel(const float* __restrict__ s, const float* __restrict__ lab, int64_t n,
-                                                     int sigmoid_rule, const uint32_t* scalars,
-                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ neg) {
+// ascending order-preserving key of a float (flip all bits of negatives, the sign bit of the rest), appended to the
+// negatives or the positives: one atomic per wave and label, lanes take consecutive slots
+__global__ __launch_bounds__(256) void auc_split_kernel(const float* __restrict__ s, const float* __restrict__ lab, int64_t n,
+                                                       int sigmoid_rule, uint32_t* scalars, uint32_t* __restrict__ neg,
+                                                       uint32_t* __restrict__ pos) {
   const bool squash = sigmoid_rule && scalars[0];
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
-    float v = s[i];
-    if (squash) v = 1.0f / (1.0f + expf(-v));
-    v += 0.0f;                                   // -0 and +0 are one threshold
-    const uint32_t u = __float_as_uint(v);
-    key[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    neg[i] = lab[i] > 0.5f ? 0u : 1u;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = 256ll * gridDim.x;
+  for (int64_t i0 = blockIdx.x * 256ll; i0 < n; i0 += stride) {      // workgroup-uniform trip count
+    const int64_t i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t key = 0;
+    bool is_neg = false;
+    if (valid) {
+      float v = s[i];
+      if (squash) v = 1.0f / (1.0f + expf(-v));
+      v += 0.0f;                                   // -0 and +0 are one threshold
+      const uint32_t u = __float_as_uint(v);
+      key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      is_neg = !(lab[i] > 0.5f);
+    }
+    const unsigned long long mn = __ballot(valid && is_neg), mp = __ballot(valid && !is_neg);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t bn = 0, bp = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(scalars + 1, (uint32_t)__popcll(mn));
+      if (mp) bp = atomicAdd(scalars + 2, (uint32_t)__popcll(mp));
+    }
+    bn = __shfl(bn, 0, 64); bp = __shfl(bp, 0, 64);
+    if (valid) {
+      if (is_neg) neg[bn + __popcll(mn & below)] = key;
+      else pos[bp + __popcll(mp & below)] = key;
+    }
   }
 }
 
-__global__ void auc_total_kernel(const uint32_t* cneg, const uint32_t* lab_sorted, int64_t n, uint32_t* scalars) {
-  scalars[2] = cneg[n - 1] + lab_sorted[n - 1];
+// ---- LSD radix sort of keys[0 .. *count): one pass = hist -> scan -> scatter on digit (key >> shift) & 255.
+// Grids are sized for the upper bound n; workgroups past *count have nothing to do (their counts are 0).
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ count,
+                                                     int shift, uint32_t* __restrict__ hist, int blocks) {
+  __shared__ uint32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t n = *count, base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * blocks + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// one thread per tie group [s, e): its positives each beat the cneg[s] negatives below and tie with the
-// cneg[e] - cneg[s] negatives inside, so the group adds P_g * (cneg[s] + cneg[e]) to 2U.
-__global__ __launch_bounds__(256) void auc_groups_kernel(const uint32_t* __restrict__ head_pos, const uint32_t* __restrict__ cneg,
-                                                        const uint32_t* scalars, int64_t n, unsigned long long* acc) {
-  const uint32_t groups = scalars[1], neg_total = scalars[2];
+// exclusive scan of hist[0 .. len) in place (digit-major, so the result is each (digit, block)'s first output slot)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int64_t len) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (len + 1023) / 1024, lo = t * per, hi = min(len, lo + per);
+  uint32_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += hist[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const uint32_t v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (int64_t i = lo; i < hi; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
+}
+
+// stable scatter.  Wave w of a workgroup owns the contiguous keys [base + w*512, +512) in 8 rounds of 64; the order
+// (wave, round, lane) is the input order, so ranking in that order keeps the pass stable.
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                        const uint32_t* __restrict__ count, int shift,
+                                                        const uint32_t* __restrict__ hist, int blocks) {
+  __shared__ uint32_t run[4][256];                 // per wave: next output slot of each digit
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = *count, base = (int64_t)blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
+  if ((int64_t)blockIdx.x * RS_TILE >= n) return;                   // workgroup-uniform
+  for (int d = lane; d < 256; d += 64) run[wave][d] = 0;
+  __syncthreads();
+  uint32_t key[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    key[r] = i < n ? in[i] : 0u;
+    if (i < n) atomicAdd(&run[wave][(key[r] >> shift) & 255u], 1u);   // this wave's digit counts
+  }
+  __syncthreads();
+  {                                                 // thread d: first slot of digit d for each wave, in wave order
+    const int d = threadIdx.x;
+    uint32_t o = hist[(size_t)d * blocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint32_t c = run[w][d]; run[w][d] = o; o += c; }
+  }
+  __syncthreads();
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t d = (key[r] >> shift) & 255u;
+    unsigned long long same = __ballot(valid);      // lanes of this round holding the same digit
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((d >> bit) & 1u);
+      same &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    if (valid) {
+      const uint32_t slot = run[wave][d] + (uint32_t)__popcll(same & below);
+      out[slot] = key[r];
+    }
+    __builtin_amdgcn_wave_barrier();                // every lane has read run[] before the leaders advance it
+    if (valid && (same & below) == 0) run[wave][d] += (uint32_t)__popcll(same);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// every positive key against the sorted negatives: 2U += #(neg < key) + #(neg <= key)
+__global__ __launch_bounds__(256) void auc_count_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ neg,
+                                                       const uint32_t* __restrict__ scalars, unsigned long long* acc) {
+  const uint32_t n_neg = scalars[1], n_pos = scalars[2];
   unsigned long long part = 0;
-  for (int64_t g = blockIdx.x * 256ll + threadIdx.x; g < groups; g += 256ll * gridDim.x) {
-    const uint32_t s = head_pos[g];
-    const uint32_t e = g + 1 < groups ? head_pos[g + 1] : (uint32_t)n;
-    const uint32_t cs = cneg[s], ce = e < n ? cneg[e] : neg_total;
-    const unsigned long long pos = (unsigned long long)(e - s) - (ce - cs);
-    part += pos * ((unsigned long long)cs + ce);
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n_pos; i += 256ll * gridDim.x) {
+    const uint32_t k = pos[i];
+    uint32_t lo = 0, hi = n_neg;                    // lower bound: first index with neg >= k
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (neg[mid] < k) lo = mid + 1; else hi = mid; }
+    uint32_t lo2 = lo, hi2 = n_neg;                 // upper bound: first index with neg > k
+    while (lo2 < hi2) { const uint32_t mid = lo2 + ((hi2 - lo2) >> 1); if (neg[mid] <= k) lo2 = mid + 1; else hi2 = mid; }
+    part += (unsigned long long)lo + lo2;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   if ((threadIdx.x & 63) == 0 && part) atomicAdd(acc, part);
 }
 
-__global__ void auc_final_kernel(const unsigned long long* acc, const uint32_t* scalars, int64_t n, double* auc,
-                                 int64_t* counts) {
-  const unsigned long long neg = scalars[2], pos = (unsigned long long)n - neg, u2 = acc[0];
+__global__ void auc_final_kernel(const unsigned long long* acc, const uint32_t* scalars, double* auc, int64_t* counts) {
+  const unsigned long long neg = scalars[1], pos = scalars[2], u2 = acc[0];
   if (auc) auc[0] = (pos == 0 || neg == 0) ? 0.0 : (double)u2 / (2.0 * (double)pos * (double)neg);
   if (counts) { counts[0] = (int64_t)u2; counts[1] = (int64_t)pos; counts[2] = (int64_t)neg; }
 }
@@ -176,20 +264,20 @@ int manner_hip_auc(const float* scores, const float* labels, int64_t n, int32_t 
   MANNER_HIP_TRY(hipMemsetAsync(w.acc, 0, 64, stream));
   const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (sigmoid_rule) hipLaunchKernelGGL(auc_range_kernel, dim3(grid), dim3(256), 0, stream, scores, n, w.scalars);
-  hipLaunchKernelGGL(auc_key_kernel, dim3(grid), dim3(256), 0, stream, scores, labels, n, (int)sigmoid_rule, w.scalars,
-                     w.key_in, w.lab_in);
+  hipLaunchKernelGGL(auc_split_kernel, dim3(grid), dim3(256), 0, stream, scores, labels, n, (int)sigmoid_rule, w.scalars,
+                     w.neg_a, w.pos);
   MANNER_LAUNCH_CHECK();
-  size_t cb = w.cub_bytes;
-  MANNER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.key_in, w.key_out, w.lab_in, w.lab_out, (int)n, 0, 32, stream));
-  cb = w.cub_bytes;
-  MANNER_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.cub, cb, w.lab_out, w.cneg, (int)n, stream));
-  hipLaunchKernelGGL(auc_total_kernel, dim3(1), dim3(1), 0, stream, w.cneg, w.lab_out, n, w.scalars);
-  hipcub::CountingInputIterator<uint32_t> idx(0);
-  hipcub::TransformInputIterator<uint32_t, HeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(idx, HeadFlag{w.key_out});
-  cb = w.cub_bytes;
-  MANNER_HIP_TRY(hipcub::DeviceSelect::Flagged(w.cub, cb, idx, flags, w.head_pos, w.scalars + 1, (int)n, stream));
-  hipLaunchKernelGGL(auc_groups_kernel, dim3(grid), dim3(256), 0, stream, w.head_pos, w.cneg, w.scalars, n, w.acc);
-  hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, stream, w.acc, w.scalars, n, auc, counts);
+  const int blocks = (int)rs_blocks(n);
+  uint32_t *src = w.neg_a, *dst = w.neg_b;
+  for (int shift = 0; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(blocks), dim3(256), 0, stream, src, w.scalars + 1, shift, w.hist, blocks);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, stream, w.hist, (int64_t)256 * blocks);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, w.scalars + 1, shift, w.hist, blocks);
+    MANNER_LAUNCH_CHECK();
+    uint32_t* t = src; src = dst; dst = t;
+  }
+  hipLaunchKernelGGL(auc_count_kernel, dim3(grid), dim3(256), 0, stream, w.pos, src, w.scalars, w.acc);
+  hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, stream, w.acc, w.scalars, auc, counts);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void lengths_kernel(const int64_t* __restrict_
 
 // ---- exclusive scan of lens -> cu[0..n], m_total; single workgroup (n is at most a chunk of news)
 __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ lens, int64_t n,
-                                                    int32_t* __restrict__ cu, int32_t* __restrict__ m_total) {
+                                                    int32_t* __restrict__ cu, int32_t* __restrict__ m_total,
+                                                    int m_bound, int expect_tokens, int32_t* __restrict__ status) {
   __shared__ int part[1024];
   const int t = threadIdx.x;
   const int64_t per = (n + 1023) / 1024;
@@ -61,8 +62,14 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
     __syncthreads();
   }
   int run = part[t] - s;
-  for (int64_t i = lo; i < hi; ++i) { cu[i] = run; run += lens[i]; }
-  if (t == 1023) { cu[n] = part[1023]; m_total[0] = part[1023]; m_total[1] = (int32_t)n; }
+  for (int64_t i = lo; i < hi; ++i) { cu[i] = min(run, m_bound); run += lens[i]; }
+  if (t == 1023) {
+    const int total = part[1023];
+    cu[n] = min(total, m_bound);
+    m_total[0] = min(total, m_bound);
+    m_total[1] = (int32_t)n;
+    if (total > m_bound || (expect_tokens >= 0 && total != expect_tokens)) atomicOr(status, MANNER_HIP_STATUS_LENGTHS);
+  }
 }
 
 template <typename TOut>
@@ -333,11 +340,12 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 }  // namespace
 
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens, int32_t* cu,
-                        int32_t* m_total, int32_t* status, hipStream_t stream) {
+                        int32_t* m_total, int64_t m_bound, int64_t expect_tokens, int32_t* status, hipStream_t stream) {
   hipLaunchKernelGGL(lengths_kernel, dim3((unsigned)((n_news + 3) / 4)), dim3(256), 0, stream, mask, n_news,
                      padded_len, lens, status);
   MANNER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, lens, n_news, cu, m_total);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, lens, n_news, cu, m_total,
+                     (int)min(m_bound, (int64_t)0x7fffffff), (int)expect_tokens, status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -34,38 +34,87 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ row, const fl
 // ---------------------------------------------------------------- K9 + K10 + K12 fused
 // one workgroup per impression: user = mean(table[hist]) (cr_module.py:116-123), then one wave per
 // candidate row (click_predictors.py:12).  `user` lives in LDS; table rows are read exactly once.
+// An index outside [0, n_rows) is an IndexError in the reference; here it raises MANNER_HIP_STATUS_INDEX in the
+// caller's status word (the row is then read as row 0 so the kernel stays in bounds).
+__device__ __forceinline__ int64_t checked_row(int64_t r, int64_t n_rows, int32_t* status, int lane) {
+  if (r >= 0 && r < n_rows) return r;
+  if (status && lane == 0) atomicOr(status, MANNER_HIP_STATUS_INDEX);
+  return 0;
+}
+
+// `user_in` != NULL: the user vectors are given ([B, D], e.g. the additive pooler's output — early fusion,
+// cr_module.py:125) and the history lists are not read.
 __global__ __launch_bounds__(256) void score_late_fusion_kernel(
     const float* __restrict__ table, int64_t n_rows, int D, const int32_t* __restrict__ hist_idx,
-    const int64_t* __restrict__ hist_off, const int32_t* __restrict__ cand_idx,
-    const int64_t* __restrict__ cand_off, float* __restrict__ out) {
+    const int64_t* __restrict__ hist_off, const float* __restrict__ user_in, const int32_t* __restrict__ cand_idx,
+    const int64_t* __restrict__ cand_off, float* __restrict__ out, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
   const int64_t b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
-  for (int cb = 0; cb < D; cb += 256) {
-    const int c = cb + lane * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (c < D)
-      for (int64_t j = h0 + wave; j < h1; j += 4) {
-        int64_t r = hist_idx[j];
-        r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
-        acc += *reinterpret_cast<const f32x4*>(table + r * D + c);
-      }
-    if (c < D) *reinterpret_cast<f32x4*>(sm + wave * D + c) = acc;
-  }
-  __syncthreads();
-  const float hn = (float)(h1 - h0);
   float* user = sm + 4 * D;
-  for (int c = threadIdx.x; c < D; c += 256)
-    user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  if (user_in) {
+    for (int c = threadIdx.x * 4; c < D; c += 1024)
+      *reinterpret_cast<f32x4*>(user + c) = *reinterpret_cast<const f32x4*>(user_in + b * D + c);
+  } else {
+    const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
+    for (int cb = 0; cb < D; cb += 256) {
+      const int c = cb + lane * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (c < D)
+        for (int64_t j = h0 + wave; j < h1; j += 4) {
+          const int64_t r = checked_row(hist_idx[j], n_rows, status, lane);
+          acc += *reinterpret_cast<const f32x4*>(table + r * D + c);
+        }
+      if (c < D) *reinterpret_cast<f32x4*>(sm + wave * D + c) = acc;
+    }
+    __syncthreads();
+    const float hn = (float)(h1 - h0);
+    for (int c = threadIdx.x; c < D; c += 256)
+      user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  }
   __syncthreads();
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
   for (int64_t j = c0 + wave; j < c1; j += 4) {
-    int64_t r = cand_idx[j];
-    r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+    const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
     const float d = row_dot(table + r * D, user, D, lane);
     if (lane == 0) out[j] = d;
   }
+}
+
+// ---------------------------------------------------------------- K9 to_dense_batch
+// ragged rows x[off[b] + j] -> dense[b, j, :] for j < min(count_b, width); the other slots get fill[b] (or 0) and
+// mask 0.  One wave per output row for D >= 4 (16-byte pieces), one thread per slot for scalars (D == 1).
+__global__ __launch_bounds__(256) void to_dense_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ off,
+                                                            int64_t B, int64_t width, int D, const float* __restrict__ fill,
+                                                            float* __restrict__ dense, uint8_t* __restrict__ mask) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * width) return;
+  const int64_t b = row / width, j = row - b * width;
+  const int64_t o0 = off[b], cnt = off[b + 1] - o0;
+  const bool real = j < cnt;
+  float* dst = dense + row * D;
+  if (real) {
+    const float* src = x + (o0 + j) * D;
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
+  } else {
+    const float f = fill ? fill[b] : 0.f;
+    const f32x4 fv = {f, f, f, f};
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = fv;
+  }
+  if (mask && lane == 0) mask[row] = real ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void to_dense_scalar_kernel(const float* __restrict__ x, const int64_t* __restrict__ off,
+                                                              int64_t B, int64_t width, int D, const float* __restrict__ fill,
+                                                              float* __restrict__ dense, uint8_t* __restrict__ mask) {
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= B * width) return;
+  const int64_t b = slot / width, j = slot - b * width;
+  const int64_t o0 = off[b], cnt = off[b + 1] - o0;
+  const bool real = j < cnt;
+  const float f = fill ? fill[b] : 0.f;
+  for (int c = 0; c < D; ++c) dense[slot * D + c] = real ? x[(o0 + j) * D + c] : f;
+  if (mask) mask[slot] = real ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- K12 drop-in
@@ -152,12 +201,13 @@ struct FuseWeights { float w[8]; };
 
 __global__ __launch_bounds__(256) void zscore_fuse_kernel(const float* __restrict__ scores, int64_t plane_stride, int K,
                                                           FuseWeights fw, const int64_t* __restrict__ off, int64_t B,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ pad_out) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= B) return;
   const int64_t c0 = off[i], c1 = off[i + 1];
   const float cn = (float)(c1 - c0);
+  float pad = 0.f;                                     // what the reference's dense matrix holds in a padded slot
   for (int k = 0; k < K; ++k) {
     const float wk = k == 0 ? 1.0f : fw.w[k - 1];
     if (k > 0 && wk == 0.0f) continue;                 // ensemble_module.py:100,105: module skipped
@@ -172,7 +222,11 @@ __global__ __launch_bounds__(256) void zscore_fuse_kernel(const float* __restric
       const float z = (s[j] - mean) / sd;
       out[j] = k == 0 ? z : out[j] + wk * z;           // scores += w * z  (:102,:107)
     }
+    // the z-score runs over the whole zero-padded row (:145-149), so a padded slot becomes (0 - mean) / std
+    const float zp = (0.0f - mean) / sd;
+    pad = k == 0 ? zp : pad + wk * zp;
   }
+  if (pad_out && lane == 0) pad_out[i] = pad;
 }
 
 // ---------------------------------------------------------------- K15 ranking + nDCG@k
@@ -287,12 +341,39 @@ extern "C" {
 
 int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D, const int32_t* hist_idx,
                                  const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
-                                 float* out, manner_hip_stream_t stream) {
+                                 float* out, int32_t* status, manner_hip_stream_t stream) {
   if (B == 0) return MANNER_HIP_OK;
   if (!table || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: null pointer");
-  if (D <= 0 || D % 4 || D > 4096 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: D=%d must be a multiple of 4, <= 4096", D);
+  // 5 D floats of dynamic LDS must stay within the 64 KiB a kernel gets without raising its limit
+  if (D <= 0 || D % 4 || D > 3072 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: D=%d must be a multiple of 4, <= 3072", D);
   hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
-                     table, n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out);
+                     table, n_rows, D, hist_idx, hist_off, (const float*)nullptr, cand_idx, cand_off, out, status);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_score_user(const float* table, int64_t n_rows, int32_t D, const float* user, const int32_t* cand_idx,
+                          const int64_t* cand_off, int64_t B, float* out, int32_t* status, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!table || !user || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_user: null pointer");
+  if (D <= 0 || D % 4 || D > 3072 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_user: D=%d must be a multiple of 4, <= 3072", D);
+  hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                     table, n_rows, D, (const int32_t*)nullptr, (const int64_t*)nullptr, user, cand_idx, cand_off, out, status);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_to_dense(const float* x, const int64_t* off, int64_t B, int64_t width, int32_t D, const float* fill,
+                        float* dense, uint8_t* mask, manner_hip_stream_t stream) {
+  if (B * width == 0) return MANNER_HIP_OK;
+  if (!x || !off || !dense || B < 0 || width < 0 || D < 1) return fail(MANNER_HIP_E_INVALID, "to_dense: bad argument");
+  if (B * width > 0x7fffffffll * 4) return fail(MANNER_HIP_E_INVALID, "to_dense: %lld x %lld slots exceed the grid", (long long)B, (long long)width);
+  if (D % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dense % 16 == 0)
+    hipLaunchKernelGGL(to_dense_rows_kernel, dim3((unsigned)((B * width + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, off, B,
+                       width, D, fill, dense, mask);
+  else
+    hipLaunchKernelGGL(to_dense_scalar_kernel, dim3((unsigned)((B * width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, off,
+                       B, width, D, fill, dense, mask);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -325,13 +406,13 @@ int manner_hip_additive_pool(const float* x, const float* lin_w, const float* li
 }
 
 int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K, const float* weights, const int64_t* cand_off,
-                           int64_t B, float* out, manner_hip_stream_t stream) {
+                           int64_t B, float* out, float* pad_value, manner_hip_stream_t stream) {
   if (B == 0) return MANNER_HIP_OK;
   if (!scores || !cand_off || !out || K < 1 || K > 9 || (K > 1 && !weights)) return fail(MANNER_HIP_E_INVALID, "zscore_fuse: bad argument (1 <= K <= 9)");
   FuseWeights fw;
   for (int k = 0; k < 8; ++k) fw.w[k] = k < K - 1 ? weights[k] : 0.f;
   hipLaunchKernelGGL(zscore_fuse_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, plane_stride, K,
-                     fw, cand_off, B, out);
+                     fw, cand_off, B, out, pad_value);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

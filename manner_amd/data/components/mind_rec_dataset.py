@@ -219,5 +219,10 @@ class DeviceCollate:
             labels, users = torch.from_numpy(b.labels[csel]).to(dev), torch.from_numpy(b.users[idx]).to(dev)
         batch_hist, x_hist = self._side(hist_d, hist_h, hs)
         batch_cand, x_cand = self._side(cand_d, cand_h, cs)
-        return MINDRecBatch(batch_hist=batch_hist, batch_cand=batch_cand, x_hist=x_hist, x_cand=x_cand, labels=labels,
-                            users=users)
+        batch = MINDRecBatch(batch_hist=batch_hist, batch_cand=batch_cand, x_hist=x_hist, x_cand=x_cand, labels=labels,
+                             users=users)
+        # host-known extras (not part of the reference's TypedDict; its consumers ignore them): the widths of the dense
+        # [B, max, *] views, so that K9 needs no device read-back (to_dense_batch computes them with a sync)
+        batch["hist_max"] = int(hs.max()) if hs.size else 0
+        batch["cand_max"] = int(cs.max()) if cs.size else 0
+        return batch

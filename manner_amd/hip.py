@@ -34,6 +34,110 @@ def _ptr(t: Optional[Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+# ------------------------------------------------------------------ device-side input validation
+_STATUS_TEXT = {_lib.STATUS_MASK: "attention_mask is not a right-padded 0/1 prefix mask",
+                _lib.STATUS_TOKEN: "input id / position outside the embedding tables",
+                _lib.STATUS_INDEX: "news or entity index outside the table (IndexError in the reference)",
+                _lib.STATUS_LENGTHS: "host_lengths disagree with attention_mask"}
+
+
+def _status_message(flag: int) -> str:
+    return "; ".join(t for b, t in _STATUS_TEXT.items() if flag & b) or f"device status 0x{flag:x}"
+
+
+class _FlagRing:
+    """Snapshots of a device status word in a small ring of pinned host slots, each behind an event: ``completed()``
+    returns the OR of the snapshots whose copy has finished, without ever blocking."""
+
+    SLOTS = 32
+
+    def __init__(self):
+        self._host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self._pending = []                     # (slot, event), oldest first
+        self._next = 0
+
+    def slot(self):
+        """-> (flags carried over from a recycled slot, pinned one-element view to copy the word into)."""
+        carried = 0
+        if len(self._pending) == self.SLOTS:   # ring full: the oldest snapshot has long completed
+            old, ev = self._pending.pop(0)
+            ev.synchronize()
+            carried = int(self._host[old])
+        i = self._next
+        self._next = (i + 1) % self.SLOTS
+        return carried, i, self._host[i:i + 1]
+
+    def push(self, i: int) -> None:
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((i, ev))
+
+    def completed(self, wait: bool = False) -> int:
+        flag, keep = 0, []
+        for i, ev in self._pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                flag |= int(self._host[i])
+            else:
+                keep.append((i, ev))
+        self._pending = keep
+        return flag
+
+
+class DeviceStatus:
+    """The int32 status word the scoring kernels raise bits in (``MANNER_HIP_STATUS_*``) where the reference would
+    raise an exception (an out-of-range table index).  ``check()`` is blocking; ``poll()`` never is: every ``arm()``
+    enqueues a copy of the word into pinned host memory and an event, and ``poll()`` raises for the snapshots whose
+    event has completed — so a bad batch surfaces at the next call at the latest, without a host synchronisation on
+    the fast path."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ring = _FlagRing()
+        self._carry = 0
+
+    def arm(self) -> None:
+        with torch.cuda.device(self.device):
+            carried, i, host = self._ring.slot()
+            self._carry |= carried
+            host.copy_(self.word, non_blocking=True)
+            self.word.zero_()
+            self._ring.push(i)
+
+    def _raise(self, flag: int) -> None:
+        flag |= self._carry
+        self._carry = 0
+        if flag:
+            raise RuntimeError(f"manner_hip input error: {_status_message(flag)}")
+
+    def poll(self) -> None:
+        self._raise(self._ring.completed())
+
+    def check(self) -> None:
+        flag = int(self.word.item())           # synchronises with the kernels that may still raise bits
+        self.word.zero_()
+        self._raise(flag | self._ring.completed(wait=True))
+
+
+_status: Dict[str, DeviceStatus] = {}
+
+
+def device_status(device) -> DeviceStatus:
+    key = str(torch.device(device))
+    if key not in _status:
+        _status[key] = DeviceStatus(torch.device(device))
+    return _status[key]
+
+
+def check_status(device=None) -> None:
+    """Blocking: raise if any scoring / entity kernel on ``device`` (default: every device used so far) saw an
+    out-of-range index since the last check."""
+    for st in ([device_status(device)] if device is not None else list(_status.values())):
+        st.check()
+
+
 def weight_table_order(cfg: EncoderConfig) -> Sequence[str]:
     """HF parameter names in the order of the ``weights`` table of manner_hip_encoder_create."""
     names = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
@@ -82,6 +186,8 @@ class HipEncoder:
             _lib.check(lib.manner_hip_encoder_create(C.byref(cc), table, len(keep), mask, _stream(), C.byref(handle)))
         self._handle = handle
         self._ws: Optional[Tensor] = None
+        self._ring: Optional[_FlagRing] = None
+        self._carry = 0
         del keep                      # the handle owns private packed copies
 
     def close(self) -> None:
@@ -179,8 +285,31 @@ class HipEncoder:
 
     def status(self) -> None:
         """Blocking check of the device-side input validation flag (raises on bad masks/ids)."""
+        carried = 0
+        if self._ring is not None:
+            carried = self._ring.completed(wait=True) | self._carry
+            self._carry = 0
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().manner_hip_encoder_status(self._handle, _stream()))
+        if carried:
+            raise RuntimeError(f"manner_hip input error in an earlier encode call: {_status_message(carried)}")
+
+    def status_arm(self) -> None:
+        """Non-blocking: snapshot (and reset) the flag word into pinned host memory behind an event on the current
+        stream; ``status_poll`` raises for completed snapshots.  The module mirror calls both around every forward."""
+        if self._ring is None:
+            self._ring = _FlagRing()
+        with torch.cuda.device(self.device):
+            carried, i, host = self._ring.slot()
+            self._carry |= carried
+            _lib.check(_lib.load().manner_hip_encoder_status_async(self._handle, C.c_void_p(host.data_ptr()), _stream()))
+            self._ring.push(i)
+
+    def status_poll(self) -> None:
+        flag = self._carry | (self._ring.completed() if self._ring is not None else 0)
+        self._carry = 0
+        if flag:
+            raise RuntimeError(f"manner_hip input error in an earlier encode call: {_status_message(flag)}")
 
 
 def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:
@@ -233,7 +362,7 @@ def entity_encode(entity_ids: Tensor, table: Tensor, in_proj_w: Tensor, in_proj_
     with torch.cuda.device(ids.device):
         _lib.check(lib.manner_hip_entity_encode(_ptr(ids), n, e, _ptr(ts[0]), ts[0].shape[0], d, heads, _ptr(ts[1]), _ptr(ts[2]),
                                                 _ptr(ts[3]), _ptr(ts[4]), _ptr(ts[5]), _ptr(ts[6]), _ptr(ts[7]), q, _ptr(out),
-                                                _ptr(ws), need, _stream()))
+                                                _ptr(ws), need, _ptr(device_status(ids.device).word), _stream()))
     return out
 
 
@@ -265,25 +394,72 @@ def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_id
     assert cand_off.numel() == nb + 1
     total = int(cand_idx.numel()) if total_cand is None else total_cand
     out = torch.empty((total,), dtype=torch.float32, device=table.device)
+    # bind the contiguous copies to locals: a temporary's storage could be handed to the next temporary
+    # before the kernel has read it
+    hist_idx, hist_off, cand_idx, cand_off = (hist_idx.contiguous(), hist_off.contiguous(), cand_idx.contiguous(),
+                                              cand_off.contiguous())
     with torch.cuda.device(table.device):
         _lib.check(_lib.load().manner_hip_score_late_fusion(
-            _ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx.contiguous()), _ptr(hist_off.contiguous()),
-            _ptr(cand_idx.contiguous()), _ptr(cand_off.contiguous()), nb, _ptr(out), _stream()))
+            _ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
+            nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
     return out
 
 
-def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor) -> Tensor:
-    """planes [K, total] (module 0 = CR); weights of modules 1..K-1 -> fused ragged scores [total]."""
+def score_user(table: Tensor, user: Tensor, cand_idx: Tensor, cand_off: Tensor, total_cand: Optional[int] = None) -> Tensor:
+    """Ragged scores [sum c_i] = <user[i], table[cand_idx[j]]> for the candidates j of impression i (the early-fusion
+    tail of CRModule.forward, cr_module.py:125-129, without the dense candidate tensor)."""
+    table = _dev(table, torch.float32, "table").contiguous()
+    user = _dev(user, torch.float32, "user_vector").contiguous()
+    cand_idx = _dev(cand_idx, torch.int32, "cand_idx").contiguous()
+    cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
+    nb = cand_off.numel() - 1
+    assert user.shape == (nb, table.shape[1])
+    total = int(cand_idx.numel()) if total_cand is None else total_cand
+    out = torch.empty((total,), dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _lib.check(_lib.load().manner_hip_score_user(_ptr(table), table.shape[0], table.shape[1], _ptr(user), _ptr(cand_idx),
+                                                     _ptr(cand_off), nb, _ptr(out), _ptr(device_status(table.device).word),
+                                                     _stream()))
+    return out
+
+
+def to_dense(x: Tensor, off: Tensor, width: int, fill: Optional[Tensor] = None, with_mask: bool = False):
+    """K9 (``to_dense_batch``): ragged rows x [sum n_i, *] + offsets int64 [B+1] -> dense [B, width, *]; padded slots
+    hold 0 (or ``fill[b]``).  ``width`` is given by the caller — no device read-back.  With ``with_mask`` also the
+    bool [B, width] mask of real slots."""
+    x = _dev(x, torch.float32, "x").contiguous()
+    off = _dev(off, torch.int64, "off").contiguous()
+    nb = off.numel() - 1
+    inner = tuple(x.shape[1:])
+    d = 1
+    for v in inner:
+        d *= int(v)
+    if fill is not None:
+        fill = _dev(fill, torch.float32, "fill").contiguous()
+        assert fill.numel() == nb
+    dense = torch.empty((nb, width) + inner, dtype=torch.float32, device=x.device)
+    mask = torch.empty((nb, width), dtype=torch.uint8, device=x.device) if with_mask else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().manner_hip_to_dense(_ptr(x), _ptr(off), nb, int(width), d, _ptr(fill), _ptr(dense), _ptr(mask),
+                                                   _stream()))
+    return (dense, mask.bool()) if with_mask else dense
+
+
+def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor, with_pad_value: bool = False):
+    """planes [K, total] (module 0 = CR); weights of modules 1..K-1 -> fused ragged scores [total].  With
+    ``with_pad_value`` also the per-impression value [B] that the reference's dense matrix holds in padded slots
+    (its z-score runs over the zero-padded row, ensemble_module.py:145-149)."""
     planes = _dev(planes, torch.float32, "scores").contiguous()
     cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
     k, total = planes.shape
     assert len(weights) == k - 1
     w = (C.c_float * max(1, k - 1))(*[float(v) for v in weights])
     out = torch.empty((total,), dtype=torch.float32, device=planes.device)
+    pad = torch.empty((cand_off.numel() - 1,), dtype=torch.float32, device=planes.device) if with_pad_value else None
     with torch.cuda.device(planes.device):
         _lib.check(_lib.load().manner_hip_zscore_fuse(_ptr(planes), total, k, w, _ptr(cand_off), cand_off.numel() - 1,
-                                                      _ptr(out), _stream()))
-    return out
+                                                      _ptr(out), _ptr(pad), _stream()))
+    return (out, pad) if with_pad_value else out
 
 
 def rank_ndcg(scores: Tensor, labels: Optional[Tensor], cand_off: Tensor, k: int = 10, with_mrr: bool = False):

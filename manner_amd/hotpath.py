@@ -3,8 +3,8 @@
 * ``cr_forward`` / ``ensemble_forward`` restate ``CRModule.forward`` (reference
   manner/models/cr_module.py:105-131) and ``EnsembleModule.forward`` / ``_submodel_forward``
   (reference manner/models/ensemble_module.py:95-151) on the fused HIP kernels, returning the same
-  dense ``[B, Cmax]`` score matrix (padded slots 0) — mode R of SURVEY.md §8d: every history and
-  candidate occurrence is encoded.
+  dense ``[B, Cmax]`` score matrix (padded slots: 0 for the CR-Module, the z-scored zero for the ensemble)
+  — mode R of SURVEY.md §8d: every history and candidate occurrence is encoded.
 * ``encode_table`` / ``score_impressions`` are the table architecture (mode T): each unique news is
   encoded once per module into ``[N_news, D]``, impressions are scored by index.  Valid for
   ``use_entities=False`` only.
@@ -30,17 +30,21 @@ def segment_offsets(batch: Tensor, num_segments: int) -> Tensor:
     return off
 
 
-def ragged_to_dense(values: Tensor, off: Tensor, width: Optional[int] = None) -> Tensor:
-    """K9 for a ragged score vector: [sum c_i] -> zero-filled [B, Cmax] (``to_dense_batch`` layout)."""
-    nb = off.numel() - 1
-    counts = off[1:] - off[:-1]
+def _width(batch: Dict, key: str, off: Tensor) -> int:
+    """Width of a dense [B, max, *] view: the collate's host-known maximum when the batch carries it (``hist_max`` /
+    ``cand_max``, set by DeviceCollate), else one device read — the same sync ``to_dense_batch`` performs."""
+    w = batch.get(key) if hasattr(batch, "get") else None
+    if w is not None:
+        return int(w)
+    return int((off[1:] - off[:-1]).max()) if off.numel() > 1 else 0
+
+
+def ragged_to_dense(values: Tensor, off: Tensor, width: Optional[int] = None, fill: Optional[Tensor] = None) -> Tensor:
+    """K9 for a ragged vector / row matrix: [sum c_i, *] -> [B, Cmax, *] (``to_dense_batch`` layout) through
+    ``manner_hip_to_dense``; padded slots hold 0, or ``fill[b]``."""
     if width is None:
-        width = int(counts.max()) if nb else 0           # the same sync to_dense_batch performs
-    seg = torch.repeat_interleave(torch.arange(nb, device=values.device), counts, output_size=values.numel())
-    pos = torch.arange(values.numel(), device=values.device) - off[:-1][seg]
-    dense = torch.zeros((nb, width), dtype=values.dtype, device=values.device)
-    dense[seg, pos] = values
-    return dense
+        width = int((off[1:] - off[:-1]).max()) if off.numel() > 1 else 0   # the same sync to_dense_batch performs
+    return hip.to_dense(values, off, width, fill=fill)
 
 
 def _late_fusion_ragged(hist_vec: Tensor, cand_vec: Tensor, hist_off: Tensor, cand_off: Tensor) -> Tensor:
@@ -53,7 +57,8 @@ def _late_fusion_ragged(hist_vec: Tensor, cand_vec: Tensor, hist_off: Tensor, ca
 
 def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder=None, click_predictor=None,
                dense: bool = True) -> Tensor:
-    """CRModule.forward: scores [B, Cmax] (or the ragged [sum c_i] vector with ``dense=False``)."""
+    """CRModule.forward: scores [B, Cmax] (or the ragged [sum c_i] vector with ``dense=False``).  No torch indexing
+    and — when the batch carries ``hist_max`` / ``cand_max`` — no host synchronisation."""
     nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
     hist_vec = news_encoder(batch["x_hist"])
     cand_vec = news_encoder(batch["x_cand"])
@@ -61,29 +66,26 @@ def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder
     cand_off = segment_offsets(batch["batch_cand"], nb)
     if late_fusion:
         ragged = _late_fusion_ragged(hist_vec, cand_vec, hist_off, cand_off)
-        return ragged_to_dense(ragged, cand_off) if dense else ragged
-    # early fusion: the unmasked additive pooler sees the ZERO-PADDED history
-    counts = hist_off[1:] - hist_off[:-1]
-    hmax = int(counts.max())
-    seg = torch.repeat_interleave(torch.arange(nb, device=hist_vec.device), counts, output_size=hist_vec.shape[0])
-    pos = torch.arange(hist_vec.shape[0], device=hist_vec.device) - hist_off[:-1][seg]
-    hist_dense = torch.zeros((nb, hmax, hist_vec.shape[1]), dtype=hist_vec.dtype, device=hist_vec.device)
-    hist_dense[seg, pos] = hist_vec
-    user = user_encoder(hist_dense)
-    ccounts = cand_off[1:] - cand_off[:-1]
-    cmax = int(ccounts.max())
-    cseg = torch.repeat_interleave(torch.arange(nb, device=cand_vec.device), ccounts, output_size=cand_vec.shape[0])
-    cpos = torch.arange(cand_vec.shape[0], device=cand_vec.device) - cand_off[:-1][cseg]
-    cand_dense = torch.zeros((nb, cmax, cand_vec.shape[1]), dtype=cand_vec.dtype, device=cand_vec.device)
-    cand_dense[cseg, cpos] = cand_vec
-    scores = (click_predictor or hip.dot)(user.unsqueeze(1), cand_dense.permute(0, 2, 1))
-    return scores if dense else scores[torch.arange(cmax, device=scores.device)[None, :] < ccounts[:, None]]
+    else:
+        # early fusion: the unmasked additive pooler sees the ZERO-PADDED history
+        hist_dense = hip.to_dense(hist_vec, hist_off, _width(batch, "hist_max", hist_off))
+        user = user_encoder(hist_dense)
+        if click_predictor is not None and dense:
+            # the reference's own call shape: DotProduct(user [B,1,D], cand^T [B,D,Cmax]) on the dense candidates
+            cand_dense = hip.to_dense(cand_vec, cand_off, _width(batch, "cand_max", cand_off))
+            return click_predictor(user.unsqueeze(1), cand_dense.permute(0, 2, 1))
+        cidx = torch.arange(cand_vec.shape[0], dtype=torch.int32, device=cand_vec.device)
+        ragged = hip.score_user(cand_vec, user, cidx, cand_off)
+    return hip.to_dense(ragged, cand_off, _width(batch, "cand_max", cand_off)) if dense else ragged
 
 
 def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[float], dense: bool = True) -> Tensor:
     """EnsembleModule.forward: CR scores + weighted A-module scores, each z-normalised per impression.
     ``news_encoders[0]`` is the CR-Module's encoder; a zero weight skips that module's encoder entirely
-    (ensemble_module.py:100,105)."""
+    (ensemble_module.py:100,105).  ``dense=True`` returns the reference's [B, Cmax] matrix slot for slot: its z-score
+    runs over the whole zero-padded row (ensemble_module.py:145-149), so PADDED slots hold
+    ``sum_k w_k (0 - mean_k) / std_k`` rather than 0 (the reference's consumers mask them away; they are reproduced
+    here so that the output is identical, not merely equivalent)."""
     nb = batch["users"].numel()
     hist_off = segment_offsets(batch["batch_hist"], nb)
     cand_off = segment_offsets(batch["batch_cand"], nb)
@@ -94,8 +96,10 @@ def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[flo
         planes.append(_late_fusion_ragged(enc(batch["x_hist"]), enc(batch["x_cand"]), hist_off, cand_off))
         if k > 0:
             used.append(weights[k - 1])
-    fused = hip.zscore_fuse(torch.stack(planes), used, cand_off)
-    return ragged_to_dense(fused, cand_off) if dense else fused
+    if not dense:
+        return hip.zscore_fuse(torch.stack(planes), used, cand_off)
+    fused, pad = hip.zscore_fuse(torch.stack(planes), used, cand_off, with_pad_value=True)
+    return hip.to_dense(fused, cand_off, _width(batch, "cand_max", cand_off), fill=pad)
 
 
 # ------------------------------------------------------------------------------------- table mode

@@ -131,8 +131,21 @@ class MannerTextEncoder(nn.Module):
             if bool(torch.count_nonzero(tokenized_text["token_type_ids"])):
                 raise ValueError("non-zero token_type_ids: the reference collate never passes them "
                                  "(mind_rec_dataset.py:134-137) and the HIP encoder assumes segment 0")
-        # CLS slice of the last hidden state; dropout is the identity in eval()
-        return self._encoder(ids.device).encode_cls(ids, mask, precision=self.precision)
+        # CLS slice of the last hidden state; dropout is the identity in eval().
+        # Input validation (bad mask, id outside the vocabulary: ValueError / IndexError in the reference) happens on
+        # the device; its flag word is snapshotted behind an event after every call and the completed snapshots are
+        # examined before the next one — an invalid batch raises at the following forward (or at check_inputs()),
+        # never passes silently, and the fast path has no host synchronisation.
+        enc = self._encoder(ids.device)
+        enc.status_poll()
+        out = enc.encode_cls(ids, mask, precision=self.precision)
+        enc.status_arm()
+        return out
+
+    def check_inputs(self) -> None:
+        """Blocking: raise if any forward so far saw an invalid attention_mask / input id."""
+        if self._hip is not None:
+            self._hip.status()
 
 
     def frozen_hidden_states(self, tokenized_text, n_layers: Optional[int] = None,

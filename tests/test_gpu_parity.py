@@ -378,15 +378,28 @@ def test_cr_forward_matches_oracle(late_fusion):
     assert out.shape == ref.shape and np.abs(out - ref).max() < FP32_TOL
 
 
+def _ragged_impressions(hist_sizes, cand_sizes, n_news, seed):
+    """Impressions with the given (ragged) history / candidate counts over a pool of n_news."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    ho = np.concatenate([[0], np.cumsum(hist_sizes)]).astype(np.int64)
+    co = np.concatenate([[0], np.cumsum(cand_sizes)]).astype(np.int64)
+    return {"hist_off": ho, "cand_off": co, "hist_idx": g.integers(0, n_news, int(ho[-1])).astype(np.int32),
+            "cand_idx": g.integers(0, n_news, int(co[-1])).astype(np.int32)}
+
+
 @pytest.mark.parametrize("weights", [(0.0, 0.0), (-0.3, 0.0), (-0.3, 0.2)])
 def test_ensemble_forward_matches_oracle(weights):
     """EnsembleModule.forward (a8) end to end: three tiny encoders (CR + two A-modules), every occurrence
-    encoded, late fusion, per-impression z-score, weighted sum; zero-weight modules are skipped."""
+    encoded, late fusion, per-impression z-score, weighted sum; zero-weight modules are skipped.  RAGGED
+    impressions: the reference z-scores the zero-padded [B, Cmax] matrix (ensemble_module.py:145-149), so padded
+    slots hold sum_k w_k (0 - mean_k)/std_k — reproduced slot for slot — and the impression with ONE candidate is a
+    NaN row (torch.std of one value)."""
     cfg = PRESETS["tiny-bert"]
     seeds = (7, 8, 9)
     ws = [make_plm_weights(cfg, seed=sd, std=0.05) for sd in seeds]
     encs = [_encoder("tiny-bert", sd, 0.05)[0] for sd in seeds]
-    imp = synth_impressions(7, 50, seed=4, max_hist=8, max_cand=11)
+    cand_sizes = [5, 1, 11, 3, 7, 2, 9]
+    imp = _ragged_impressions([3, 1, 8, 2, 5, 4, 6], cand_sizes, 50, seed=4)
     pool_ids, pool_mask = synth_news_tokens(50, cfg, seed=4, max_len=28)
 
     def sub(idx):
@@ -396,8 +409,6 @@ def test_ensemble_forward_matches_oracle(weights):
 
     (hi, hm), (ci, cm) = sub(imp["hist_idx"]), sub(imp["cand_idx"])
     bh, bc = torch.from_numpy(segment_ids(imp["hist_off"])), torch.from_numpy(segment_ids(imp["cand_off"]))
-    vecs = [(O.encode_cls(hi, hm, w, cfg), O.encode_cls(ci, cm, w, cfg)) for w in ws]
-    ref = O.ensemble_scores(vecs, bh, bc, weights).numpy()
     batch = {"x_hist": {"input_ids": _cuda(hi), "attention_mask": _cuda(hm)},
              "x_cand": {"input_ids": _cuda(ci), "attention_mask": _cuda(cm)},
              "batch_hist": bh.to(DEV), "batch_cand": bc.to(DEV), "users": torch.zeros(7, dtype=torch.int64, device=DEV)}
@@ -410,8 +421,163 @@ def test_ensemble_forward_matches_oracle(weights):
         return f
 
     out = hotpath.ensemble_forward([wrap(0), wrap(1), wrap(2)], batch, weights).cpu().numpy()
-    assert out.shape == ref.shape and np.abs(out - ref).max() < 2e-3       # z-scores: O(1) values, std-normalised
     assert set(calls) == {0} | {i + 1 for i, wv in enumerate(weights) if wv != 0}
+    # (1) end to end against the oracle's own encoder: the z-score divides the 1e-5 embedding error by std
+    vecs = [(O.encode_cls(hi, hm, w, cfg), O.encode_cls(ci, cm, w, cfg)) for w in ws]
+    ref = O.ensemble_scores(vecs, bh, bc, weights).numpy()
+    assert out.shape == ref.shape == (7, 11)
+    assert np.isnan(out[1]).all() and np.isnan(ref[1]).all()                # c_i = 1: NaN row, padded slots included
+    ok = ~np.isnan(ref)
+    assert np.abs(out - ref)[ok].max() < 2e-3
+    # (2) the composition alone — scorer, z-score, fusion, padded-slot values — against the oracle fed with the HIP
+    #     fp32 embeddings: tight
+    hvecs = [(encs[i].encode_cls(_cuda(hi), _cuda(hm), precision="fp32").cpu(),
+              encs[i].encode_cls(_cuda(ci), _cuda(cm), precision="fp32").cpu()) for i in range(3)]
+    ref2 = O.ensemble_scores(hvecs, bh, bc, weights).numpy()
+    assert np.abs(out - ref2)[ok].max() < 2e-5
+    pad = np.arange(11)[None, :] >= np.asarray(cand_sizes)[:, None]
+    assert pad.sum() > 0 and np.abs(ref2[pad & ok]).min() > 1e-3            # the padded slots are NOT zero in the reference
+    # ragged output = the valid slots of the dense one
+    rag = hotpath.ensemble_forward([wrap(0), wrap(1), wrap(2)], batch, weights, dense=False).cpu().numpy()
+    assert np.array_equal(rag, out[~pad], equal_nan=True)
+
+
+def test_to_dense_matches_oracle():
+    """K9 (manner_hip_to_dense) vs the restated to_dense_batch: row matrices, scalars, the mask, per-row fill, and a
+    width larger than the batch maximum (extra all-padding columns)."""
+    g = np.random.Generator(np.random.PCG64(21))
+    sizes = np.array([3, 0, 7, 1, 5, 0, 2])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    batch = torch.from_numpy(segment_ids(off))
+    for inner in ((), (1,), (3,), (64,), (768,)):
+        x = g.standard_normal((int(off[-1]),) + inner).astype(np.float32)
+        # to_dense_batch drops trailing empty segments (B = batch.max() + 1): sizes ends with a non-empty one
+        ref, rmask = O.to_dense_batch(torch.from_numpy(x), batch)
+        dense, mask = hip.to_dense(_cuda(x), _cuda(off), int(sizes.max()), with_mask=True)
+        assert torch.equal(dense.cpu(), ref) and torch.equal(mask.cpu(), rmask)
+        wide = hip.to_dense(_cuda(x), _cuda(off), int(sizes.max()) + 3).cpu()
+        assert torch.equal(wide[:, : int(sizes.max())], ref) and not wide[:, int(sizes.max()):].any()
+    fill = g.standard_normal(len(sizes)).astype(np.float32)
+    x = g.standard_normal(int(off[-1])).astype(np.float32)
+    dense = hip.to_dense(_cuda(x), _cuda(off), 7, fill=_cuda(fill)).cpu().numpy()
+    ref, rmask = O.to_dense_batch(torch.from_numpy(x), batch)
+    want = np.where(rmask.numpy(), ref.numpy(), fill[:, None])
+    assert np.array_equal(dense, want)
+    assert hip.to_dense(_cuda(x[:0]), _cuda(off[:1]), 4).shape == (0, 4)
+
+
+def test_score_user_matches_dense_dot():
+    """Early-fusion tail on ragged candidates (manner_hip_score_user) = DotProduct on the dense candidates."""
+    g = np.random.Generator(np.random.PCG64(22))
+    imp = synth_impressions(9, 200, seed=22, max_hist=5, max_cand=14)
+    table = g.standard_normal((200, 768)).astype(np.float32)
+    user = g.standard_normal((9, 768)).astype(np.float32)
+    co = imp["cand_off"]
+    rag = hip.score_user(_cuda(table), _cuda(user), _cuda(imp["cand_idx"]), _cuda(co))
+    cand = torch.from_numpy(table[imp["cand_idx"].astype(np.int64)])
+    dense, mask = O.to_dense_batch(cand, torch.from_numpy(segment_ids(co)))
+    ref = O.dot_product(torch.from_numpy(user).unsqueeze(1), dense.permute(0, 2, 1))[mask]
+    assert np.abs(rag.cpu().numpy() - ref.numpy()).max() < 1e-3 * 1e-1      # |scores| ~ 30, f32 sums of 768 products
+    got = hip.dot(_cuda(user).unsqueeze(1), hip.to_dense(_cuda(cand.numpy()), _cuda(co), int(np.diff(co).max())).permute(0, 2, 1))
+    assert (got[mask.to(DEV)] - rag).abs().max().item() < 1e-4
+
+
+def test_out_of_range_indices_raise():
+    """Where the reference raises IndexError (a gather outside the table / nn.Embedding) the kernels flag the
+    caller's status word instead of silently clamping: blocking check_status() and the non-blocking arm/poll pair."""
+    g = np.random.Generator(np.random.PCG64(23))
+    table = _cuda(g.standard_normal((50, 64)).astype(np.float32))
+    ho, co = _cuda(np.array([0, 2, 3], np.int64)), _cuda(np.array([0, 2, 5], np.int64))
+    good_h, good_c = np.array([1, 2, 3], np.int32), np.array([4, 5, 6, 7, 8], np.int32)
+    hip.check_status(DEV)
+    ref = hip.score_late_fusion(table, _cuda(good_h), ho, _cuda(good_c), co)
+    hip.check_status(DEV)                                   # clean inputs: no flag
+    for bad_h, bad_c in ((np.array([1, 50, 3], np.int32), good_c), (good_h, np.array([4, -1, 6, 7, 8], np.int32))):
+        hip.score_late_fusion(table, _cuda(bad_h), ho, _cuda(bad_c), co)
+        with pytest.raises(RuntimeError, match="index outside the table"):
+            hip.check_status(DEV)
+    hip.check_status(DEV)                                   # the flag is cleared by the check
+    st = hip.device_status(DEV)
+    hip.score_user(table, table[:2].contiguous(), _cuda(np.array([0, 1, 99, 3, 4], np.int32)), co)
+    st.arm()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="index outside the table"):
+        st.poll()
+    st.poll()
+    # strided index tensors (ADVICE r1: temporaries released before launch): same result as contiguous ones
+    wide_h, wide_c = _cuda(np.stack([good_h, good_h * 0], 1)), _cuda(np.stack([good_c, good_c * 0], 1))
+    out = hip.score_late_fusion(table, wide_h[:, 0], ho, wide_c[:, 0], co)
+    assert torch.equal(out, ref)
+
+
+def test_host_lengths_mismatch_is_flagged_not_corrupting():
+    """host_lengths only size the chunks; if they disagree with the mask the device flags it and drops the
+    surplus tokens instead of writing past the chunk's buffers."""
+    enc, cfg = _encoder("tiny-bert", 7, 0.05)
+    lens = np.array([40, 41, 42, 43] * 16)
+    ids, mask = synth_news_tokens(len(lens), cfg, seed=31, lengths=lens)
+    good = enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32", host_lengths=lens)
+    enc.status()
+    short = np.full_like(lens, 8)                          # claims 512 tokens where the mask holds 2656
+    enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32", host_lengths=short, max_chunk_tokens=512)
+    with pytest.raises(RuntimeError, match="host_lengths disagree"):
+        enc.status()
+    again = enc.encode_cls(_cuda(ids), _cuda(mask), precision="fp32", host_lengths=lens)
+    enc.status()
+    assert torch.equal(good, again)                        # nothing was corrupted, the handle is still usable
+
+
+@pytest.mark.parametrize("preset,n_layers", [("tiny-bert", 0), ("tiny-bert-1layer", None)])
+def test_side_stream_is_ordered_when_no_full_layer_runs(monkeypatch, preset, n_layers):
+    """with more than one chunk the side stream waits on a phase event that used to be recorded only inside
+    a full layer — encode_hidden(n_layers=0) and one-layer models never recorded it.  Two-stream results must equal
+    the single-stream ones bit for bit, run right behind a producer kernel on the caller's stream."""
+    from manner_amd.config import EncoderConfig
+    base = PRESETS["tiny-bert"]
+    cfg = base if preset == "tiny-bert" else EncoderConfig(**{**base.to_dict(), "layers": 1})
+    w = make_plm_weights(cfg, seed=5, std=0.05)
+    lens = np.array([30, 31, 29, 32] * 24)
+    ids, mask = synth_news_tokens(len(lens), cfg, seed=5, lengths=lens)
+    outs = []
+    for streams in ("1", "2"):
+        monkeypatch.setenv("MANNER_HIP_STREAMS", streams)
+        enc = hip.HipEncoder(cfg, w, device=DEV)
+        for _ in range(3):
+            ids_d = torch.from_numpy(ids).to(DEV) + 0       # produced by a kernel on the caller's stream just before
+            mask_d = torch.from_numpy(mask).to(DEV) * 1
+            if n_layers is None:
+                o = enc.encode_cls(ids_d, mask_d, precision="fp32", host_lengths=lens, max_chunk_tokens=512)
+            else:
+                o = enc.encode_hidden(ids_d, mask_d, n_layers, precision="fp32", host_lengths=lens, max_chunk_tokens=512)
+            outs.append(o.cpu())
+        enc.status()
+        enc.close()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_module_mirror_surfaces_bad_inputs(golden_dir):
+    """a bad mask through the drop-in module must not pass silently — it raises at the next
+    forward (non-blocking path) or at check_inputs() (blocking)."""
+    from manner_amd.models.components.news_encoder import MannerTextEncoder
+    enc = MannerTextEncoder("tiny-bert", [], 0.2).to(DEV).eval()
+    cfg = PRESETS["tiny-bert"]
+    ids, mask = synth_news_tokens(8, cfg, seed=1, max_len=20)
+    good = {"input_ids": _cuda(ids), "attention_mask": _cuda(mask)}
+    bad_mask = mask.copy()
+    bad_mask[3, 0] = 0                                     # a hole: not a prefix mask
+    bad = {"input_ids": _cuda(ids), "attention_mask": _cuda(bad_mask)}
+    with torch.no_grad():
+        enc(good)
+        enc.check_inputs()
+        enc(bad)
+        with pytest.raises(RuntimeError, match="prefix"):
+            enc.check_inputs()
+        enc(bad)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="prefix"):
+            enc(good)                                      # surfaced by the poll in front of the next forward
+        enc(good)
+        enc.check_inputs()
 
 
 def test_mrr_and_aspect_metrics_match_oracle():

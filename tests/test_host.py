@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 18 and set(syms) == set(_lib.SIGNATURES)
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
-    assert lib.manner_hip_abi_version() == 1
+    assert lib.manner_hip_abi_version() == _lib.ABI_VERSION == 2
     assert lib.manner_hip_encoder_workspace_bytes(None, 1, 1, 0) == 0          # null handle: no crash
 
 
@@ -31,7 +31,9 @@ def test_library_argument_errors_without_gpu():
     assert lib.manner_hip_dot(None, None, 2, 2, 4, 8, 1, 4, None, None) == 1    # MANNER_HIP_E_INVALID
     assert b"dot" in lib.manner_hip_last_error()
     assert lib.manner_hip_encode_cls(None, None, None, None, 1, 8, 0, None, None, 0, None) == 1
-    assert lib.manner_hip_zscore_fuse(None, 0, 1, None, None, 0, None, None) == 0   # B == 0: nothing to do
+    assert lib.manner_hip_zscore_fuse(None, 0, 1, None, None, 0, None, None, None) == 0   # B == 0: nothing to do
+    assert lib.manner_hip_to_dense(None, None, 0, 4, 1, None, None, None, None) == 0         # no slots: nothing to do
+    assert lib.manner_hip_to_dense(None, None, 2, 4, 1, None, None, None, None) == 1
 
 
 def test_module_surface_matches_reference_signatures(golden_dir):
