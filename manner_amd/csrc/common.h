@@ -69,6 +69,10 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
 int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
 
+// K11 logits[r] = sum_j tanh(x[r] . W[j] + b[j]) q[j] on the f32 MFMA (D % 32 == 0, Q <= 256); x [R, D], W [Q, D]
+int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,
+                     float* logits, hipStream_t stream);
+
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // m_bound: rows the chunk's buffers hold; expect_tokens >= 0: what the caller's host_lengths promised.  A mask that
 // yields more tokens than m_bound is truncated there (cu clamped) and, like any disagreement with expect_tokens,

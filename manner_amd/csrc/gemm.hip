@@ -430,6 +430,137 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K11 logits on the f32 matrix cores: logits[r] = sum_{j<Q} tanh(<x[r,:], W[j,:]> + b[j]) q[j]   (AdditiveAttention,
+// reference manner/models/components/attention.py:21-25).  The x W^T product is the gemm_tn_big_kernel<float> main
+// loop (exact f32 FMA chains on v_mfma_f32_32x32x2_f32, 256 rows x 256 columns per workgroup, BK = 32 floats); Q <= 256
+// so ONE column tile holds every attention unit and the tanh / dot-with-query reduction happens in the epilogue —
+// the [R, Q] intermediate never exists.  Operands are the caller's tensors as they are: rows past R (or past Q for W)
+// are CLAMPED to the last valid row on the staging address (no padded copies, nothing read out of bounds) and their
+// contributions dropped (rows >= R are not written, units >= Q carry q = 0).
+__global__ __launch_bounds__(512, 1) void pool_logits_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, const float* __restrict__ query,
+                                                             int64_t R, int K, int Q, float* __restrict__ logits) {
+  constexpr int EPC = 4, BK = 32;
+  typedef f32x4 frag_t;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * G_STAGE_BYTES];   // 128 KiB
+  const int64_t mt = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rr = lane & 31, h = lane >> 5;
+  const int wn = wave & 3, wm = wave >> 2;
+
+  const bool is_w = wave < 4;
+  const int prow0 = 64 * (wave & 3);
+  const float* gsrc = is_w ? W : X;
+  const int64_t row_base = is_w ? 0 : mt * G_BM, row_last = (is_w ? (int64_t)Q : R) - 1;
+  const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
+  const int lrow = lane >> 3;
+  size_t poff[8];                                                       // element offset of this lane's 16 bytes in piece i
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = min(row_base + prow0 + 8 * i + lrow, row_last);
+    poff[i] = (size_t)row * K + (((lane & 7) ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * EPC);
+  }
+  auto issue2 = [&](int buf, int k0, int pair) {
+    char* base = lds + buf * G_STAGE_BYTES + ldst0;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int i = 2 * pair + par;
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + poff[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (rr >> 1) & 7;
+  const int woff = (wn * 64 + rr) * ROW_BYTES;
+  const int xoff = G_OP_BYTES + (wm * 128 + rr) * ROW_BYTES;
+  auto read_frags = [&](const char* base, int kc, frag_t (&wf)[2], frag_t (&xf)[4]) {
+    const int coff = ((2 * kc + h) ^ swz) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const frag_t*>(base + woff + i * 32 * ROW_BYTES + coff);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const frag_t*>(base + xoff + j * 32 * ROW_BYTES + coff);
+  };
+  auto mma8 = [&](const frag_t (&wf)[2], const frag_t (&xf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma_chunk<float>(wf[i], xf[j], acc[i][j]);
+  };
+  auto kstep = [&](int cur, int k1, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* base = lds + cur * G_STAGE_BYTES;
+    frag_t wa[2], xa[4], wb[2], xb[4];
+    read_frags(base, 0, wa, xa);
+    read_frags(base, 1, wb, xb);
+    if (NEXT) issue2(cur ^ 1, k1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wa, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(base, 2, wa, xa);
+    if (NEXT) issue2(cur ^ 1, k1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wb, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(base, 3, wb, xb);
+    if (NEXT) issue2(cur ^ 1, k1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wa, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT) issue2(cur ^ 1, k1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(wb, xb);
+  };
+  const int nk = K / BK;
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) issue2(0, 0, pair);
+  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, (kt + 1) * BK, std::true_type{});
+  kstep((nk - 1) & 1, 0, std::false_type{});
+
+  // ---- epilogue.  acc[i][j][reg] = D[n][m], n = 64 wn + 32i + (reg&3) + 8(reg>>2) + 4h, m = 128 wm + 32j + rr:
+  // a lane sums tanh(.) q over its 32 units, the two lane halves combine by one shuffle, the four unit-quarter waves
+  // through LDS in a fixed order (deterministic).
+  __builtin_amdgcn_s_barrier();                      // all waves finished reading the K-loop stages
+  float* red = reinterpret_cast<float*>(lds);        // [4][256]
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n0 = 64 * wn + 32 * i + 8 * g + 4 * h;
+      float bv[4], qv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = n0 + e < Q;
+        bv[e] = ok ? bias[n0 + e] : 0.f;
+        qv[e] = ok ? query[n0 + e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[j] += tanhf(acc[i][j][4 * g + e] + bv[e]) * qv[e];
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[j] += __shfl_xor(p[j], 32, 64);
+    if (h == 0) red[wn * 256 + wm * 128 + 32 * j + rr] = p[j];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int64_t r = mt * G_BM + tid;
+    if (r < R) logits[r] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16 production kernel: the 256x256 / 8-wave / 2-stage structure of gemm_tn_big_kernel on
 // v_mfma_f32_16x16x32_bf16, PERSISTENT over tiles.
 //  * MFMA shape: on MI355X with random operands a register-only MFMA loop sustains 2.04 PFLOP/s with
@@ -962,6 +1093,18 @@ int device_cus() {
     n_cus = v > 0 ? v : 256;
   }
   return n_cus;
+}
+
+int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,
+                     float* logits, hipStream_t stream) {
+  if (R <= 0) return MANNER_HIP_OK;
+  if (D % 32 || D < 32 || Q < 1 || Q > G_BN || (uintptr_t)x % 16 || (uintptr_t)W % 16)
+    return fail(MANNER_HIP_E_INVALID, "pool_logits_mfma: D=%d Q=%d unsupported (D %% 32 == 0, Q <= 256, 16-byte aligned rows)", D, Q);
+  const int64_t tiles = (R + G_BM - 1) / G_BM;
+  if (tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "pool_logits_mfma: too many rows");
+  hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)tiles), dim3(512), 0, stream, x, W, bias, query, R, D, Q, logits);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
 }
 
 int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,

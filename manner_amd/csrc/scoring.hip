@@ -3,6 +3,7 @@
 // weighted fusion (K13+K14) and stable ranking / nDCG@k (K15).  All of it is f32, coalesced
 // 16-byte row reads with 64-lane shuffle reductions; no matrix cores (≈0.5 FLOP per byte).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -156,44 +157,68 @@ __global__ __launch_bounds__(256) void dot_strided_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- K11 additive attention
-// one workgroup per batch row b: logits[s] = sum_j tanh(<x[b,s],W[j]> + b[j]) q[j]; softmax over s
-// (NO padding mask — attention.py:21-27); out[b] = sum_s w_s x[b,s].
-__global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, const float* __restrict__ query,
-                                                            int64_t S, int D, int Q, float* __restrict__ out,
-                                                            float* __restrict__ logits) {
+// AdditiveAttention.forward (attention.py:21-27), NO padding mask, in two passes:
+//   logits[b,s] = sum_j tanh(<x[b,s], W[j]> + b[j]) q[j]   — on the f32 matrix cores (pool_logits_mfma, gemm.hip) when
+//                 D % 32 == 0 and Q <= 256, else the VALU kernel below (one workgroup per (b,s) row; the entity
+//                 branch's D = 100);
+//   out[b]      = sum_s softmax_s(logits[b,:]) x[b,s]      — pool_apply_kernel: x is read once, 16 bytes per lane.
+__global__ __launch_bounds__(256) void pool_logits_valu_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, const float* __restrict__ query,
+                                                               int D, int Q, float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] row + [4] wave partials
+  const int64_t r = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* part = sm + D;
+  for (int c = threadIdx.x * 4; c < D; c += 1024)
+    *reinterpret_cast<f32x4*>(sm + c) = *reinterpret_cast<const f32x4*>(x + r * D + c);
+  __syncthreads();
+  float acc = 0.f;
+  for (int j = wave; j < Q; j += 4) {
+    const float d = row_dot(W + (size_t)j * D, sm, D, lane);
+    acc += tanhf(d + bias[j]) * query[j];
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) logits[r] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// grid (B, ceil(D / 1024)): a thread owns 4 consecutive columns; the softmax over s (dim=1) is recomputed per block
+__global__ __launch_bounds__(256) void pool_apply_kernel(const float* __restrict__ x, const float* __restrict__ logits,
+                                                         int64_t S, int D, float* __restrict__ out) {
+  __shared__ float wts[256];
+  __shared__ float red[8];
   const int64_t b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float* xb = x + b * S * D;
-  float* lg = logits + b * S;
-  float* part = sm + D;
-  for (int64_t s = 0; s < S; ++s) {
-    for (int c = threadIdx.x * 4; c < D; c += 1024)
-      *reinterpret_cast<f32x4*>(sm + c) = *reinterpret_cast<const f32x4*>(xb + s * D + c);
-    __syncthreads();
-    float acc = 0.f;
-    for (int j = wave; j < Q; j += 4) {
-      const float d = row_dot(W + (size_t)j * D, sm, D, lane);
-      acc += tanhf(d + bias[j]) * query[j];
-    }
-    if (lane == 0) part[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) lg[s] = (part[0] + part[1]) + (part[2] + part[3]);
-    __syncthreads();
-  }
-  // softmax over s (dim=1), every wave redundantly
+  const float* lg = logits + b * S;
   float mx = -INFINITY;
-  for (int64_t s = lane; s < S; s += 64) mx = fmaxf(mx, lg[s]);
+  for (int64_t s = threadIdx.x; s < S; s += 256) mx = fmaxf(mx, lg[s]);
   mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float den = 0.f;
-  for (int64_t s = lane; s < S; s += 64) den += expf(lg[s] - mx);
+  for (int64_t s = threadIdx.x; s < S; s += 256) den += expf(lg[s] - mx);
   den = wave_sum(den);
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float a = 0.f;
-    for (int64_t s = 0; s < S; ++s) a = fmaf(expf(lg[s] - mx) / den, xb[s * D + c], a);
-    out[b * D + c] = a;
+  if (lane == 0) red[4 + wave] = den;
+  __syncthreads();
+  den = (red[4] + red[5]) + (red[6] + red[7]);
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  const float* xb = x + b * S * D;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t s0 = 0; s0 < S; s0 += 256) {
+    const int64_t ns = min((int64_t)256, S - s0);
+    __syncthreads();
+    if (threadIdx.x < ns) wts[threadIdx.x] = expf(lg[s0 + threadIdx.x] - mx) / den;
+    __syncthreads();
+    if (c < D)
+      for (int64_t s = 0; s < ns; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (s0 + s) * D + c);
+        const float w = wts[s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaf(w, v[e], a[e]);
+      }
   }
+  if (c < D) *reinterpret_cast<f32x4*>(out + b * D + c) = a;
 }
 
 // ---------------------------------------------------------------- K13 + K14
@@ -399,8 +424,18 @@ int manner_hip_additive_pool(const float* x, const float* lin_w, const float* li
   if (B == 0) return MANNER_HIP_OK;
   if (!x || !lin_w || !lin_b || !query || !out || !scratch) return fail(MANNER_HIP_E_INVALID, "additive_pool: null pointer");
   if (S <= 0 || D <= 0 || D % 4 || D > 8192 || Q <= 0) return fail(MANNER_HIP_E_INVALID, "additive_pool: S=%lld D=%d Q=%d unsupported", (long long)S, D, Q);
-  hipLaunchKernelGGL(additive_pool_kernel, dim3((unsigned)B), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, lin_w,
-                     lin_b, query, S, D, Q, out, scratch);
+  if (B > 0x7fffffffll || B * S > 0x7fffffffll) return fail(MANNER_HIP_E_INVALID, "additive_pool: B*S exceeds the grid");
+  static const bool force_valu = getenv("MANNER_HIP_POOL_VALU") != nullptr;      // A/B switch for development
+  if (!force_valu && D % 32 == 0 && Q <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)lin_w % 16 == 0) {
+    int rc = pool_logits_mfma(x, lin_w, lin_b, query, B * S, D, Q, scratch, (hipStream_t)stream);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(pool_logits_valu_kernel, dim3((unsigned)(B * S)), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream,
+                       x, lin_w, lin_b, query, D, Q, scratch);
+    MANNER_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(pool_apply_kernel, dim3((unsigned)B, (unsigned)((D + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x,
+                     scratch, S, D, out);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
