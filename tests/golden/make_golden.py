@@ -96,6 +96,46 @@ def gen_encoder(name, preset, n, lp, seed, std, lengths=None):
     return keys
 
 
+def gen_pair(name, preset, n, seed, std, max_length=96):
+    """Two text aspects: the reference collate hands the tokenizer [title, abstract] PAIRS with
+    return_token_type_ids=False, padding=True, truncation=True (mind_rec_dataset.py:134-137, 161-163; the tokenizer is
+    built with model_max_length = tokenizer_max_length = 96, mind_rec_datamodule.py:52-56), so the PLM sees
+    [CLS] title [SEP] abstract [SEP] with token type 0 everywhere.  No vocabulary is available offline: a synthetic
+    WordPiece vocabulary of the preset's size (whole-word entries w<i>) drives a real BertTokenizerFast through exactly
+    that call; the fixture keeps its ids / mask and the reference encoder's output on them."""
+    from transformers import BatchEncoding, BertTokenizerFast
+    cfg = PRESETS[preset]
+    w = make_plm_weights(cfg, seed=seed, std=std)
+    g = np.random.Generator(np.random.PCG64(seed))
+    with tempfile.TemporaryDirectory() as tmp:
+        special = {0: "[PAD]", 100: "[UNK]", 101: "[CLS]", 102: "[SEP]", 103: "[MASK]"} if cfg.vocab > 200 else \
+                  {0: "[PAD]", 1: "[UNK]", 2: "[CLS]", 3: "[SEP]", 4: "[MASK]"}
+        with open(os.path.join(tmp, "vocab.txt"), "w") as f:
+            for i in range(cfg.vocab):
+                f.write(special.get(i, f"w{i}") + "\n")
+        tok = BertTokenizerFast(vocab_file=os.path.join(tmp, "vocab.txt"), do_lower_case=True, model_max_length=max_length)
+        words = [i for i in range(cfg.vocab) if i not in special]
+        def text(k):
+            return " ".join(f"w{words[j]}" for j in g.integers(0, len(words), k))
+        title_len = [3, 9, 14, 20, 11, 7, 30, 16][:n]
+        abstr_len = [0, 12, 40, 120, 70, 1, 66, 75][:n]          # 0: empty abstract; 120: truncated at max_length
+        pairs = [[text(a), text(b)] for a, b in zip(title_len, abstr_len)]
+        enc_in = tok(pairs, return_tensors="pt", return_token_type_ids=False, padding=True, truncation=True)   # _tokenize
+        assert "token_type_ids" not in enc_in
+        ids, mask = enc_in["input_ids"].numpy(), enc_in["attention_mask"].numpy()
+        sep = tok.sep_token_id
+        assert ids.shape[1] == max_length and all((row == sep).sum() == 2 for row in ids)
+        enc = reference_news_encoder(hf_model_dir(cfg, w, os.path.join(tmp, "plm")), cfg.hidden)
+        out = enc({"text": BatchEncoding({"input_ids": enc_in["input_ids"], "attention_mask": enc_in["attention_mask"]})}).numpy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), ids=ids, mask=mask, out=out,
+                        meta=json.dumps({"source": "reference MannerNewsEncoder on BertTokenizerFast([title, abstract] pairs, "
+                                                   "return_token_type_ids=False, padding=True, truncation=True) — "
+                                                   "mind_rec_dataset.py:134-137,161-163; synthetic vocabulary",
+                                         "preset": preset, "seed": seed, "std": std, "sep_id": int(sep),
+                                         "title_words": title_len, "abstract_words": abstr_len}))
+    print(name, ids.shape, out.shape, mask.sum(1).tolist())
+
+
 def gen_hidden(name, preset, n, lp, seed, std, lengths, layers_out):
     """hidden_states[k] of the reference's text encoder (the tensor HF hands from layer k-1 to layer k; k = 8 is the
     frozen / trainable boundary of configs/model/cr_module.yaml:10), real tokens only, packed news after news."""
@@ -231,6 +271,15 @@ if __name__ == "__main__":
         keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)
         with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
             json.dump(keys, f, indent=0)
+        sys.exit(0)
+    if "--round2-only" in sys.argv:
+        # >= 64 news incl. the extreme lengths 2 and 96, and the two-text-aspect (pair) input
+        lens64 = np.concatenate([[2, 2, 3, 96, 96, 95], np.arange(4, 96, 2)[:46], [17, 33, 49, 64, 65, 80, 81, 31, 32, 63, 94, 5]])
+        assert lens64.shape == (64,)
+        gen_encoder("enc_bert_base_64", "bert-base-uncased", n=64, lp=96, seed=47, std=0.02, lengths=lens64)
+        gen_encoder("enc_roberta_base_64", "roberta-base", n=64, lp=96, seed=48, std=0.02, lengths=lens64)
+        gen_pair("enc_pair_bert_base", "bert-base-uncased", n=8, seed=49, std=0.02)
+        gen_pair("enc_pair_tiny_bert", "tiny-bert", n=8, seed=50, std=0.05, max_length=48)
         sys.exit(0)
     if "--hidden-only" in sys.argv:
         gen_hidden("hidden_tiny_bert", "tiny-bert", n=6, lp=24, seed=42, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),

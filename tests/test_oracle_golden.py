@@ -17,12 +17,17 @@ def _load(golden_dir, name):
     return z, json.loads(str(z["meta"]))
 
 
-@pytest.mark.parametrize("name", ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base"])
+GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base",
+              # round 2: 64 news incl. lengths 2 and 96; [title, abstract] pair inputs through a real tokenizer call (Q4)
+              "enc_bert_base_64", "enc_roberta_base_64", "enc_pair_bert_base", "enc_pair_tiny_bert"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_ENC)
 def test_encoder_matches_reference(golden_dir, name):
     z, meta = _load(golden_dir, name)
     cfg = PRESETS[meta["preset"]]
     w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
-    for k, h in meta["sha256"].items():           # the seeded weights regenerate bit-identically
+    for k, h in meta.get("sha256", {}).items():   # the seeded weights regenerate bit-identically
         assert tensor_sha256(w[k]) == h, k
     out = O.encode_cls(z["ids"], z["mask"], w, cfg).numpy()
     assert out.shape == z["out"].shape
@@ -198,3 +203,80 @@ def test_hidden_states_match_reference(golden_dir, name):
     for k in meta["layers"]:
         h = O.encode_tokens(z["ids"], z["mask"], w, cfg, layers=k)[keep].numpy()
         assert np.abs(h - z[f"h{k}"]).max() < 2e-5, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Independent pins of the restated (un-importable) pieces — VERDICT r1 item 5.  torchmetrics / torch_geometric are not
+# installed; scikit-learn and torch.nn.utils.rnn are, and implement the same definitions independently.
+
+def test_ndcg_against_sklearn():
+    """RetrievalNormalizedDCG(top_k=k) restatement vs sklearn.metrics.ndcg_score(k=k) on tie-free scores: same
+    definition (linear gains, log2 discounts, IDCG from the sorted targets); an impression without a positive is 0
+    in both the restatement (empty_target_action='neg') and here (handled explicitly: sklearn returns 0 too)."""
+    from sklearn.metrics import ndcg_score
+    g = np.random.Generator(np.random.PCG64(5))
+    sizes = [2, 3, 5, 10, 11, 37, 120, 300]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    scores = g.permutation(int(off[-1])).astype(np.float32) / 7.0              # distinct values: tie-free
+    for graded in (False, True):
+        tgt = (g.random(int(off[-1])) < 0.15).astype(np.float32)
+        if graded:
+            tgt *= g.integers(1, 4, tgt.shape[0]).astype(np.float32)
+        tgt[off[2]:off[3]] = 0.0                                               # one impression without a positive
+        for k in (5, 10):
+            mean, per = O.ndcg_at_k(torch.from_numpy(scores), torch.from_numpy(tgt), off.tolist(), k)
+            want = [ndcg_score(tgt[None, a:b], scores[None, a:b], k=k) if tgt[a:b].sum() > 0 else 0.0
+                    for a, b in zip(off[:-1], off[1:])]
+            assert np.abs(per.numpy() - np.asarray(want)).max() < 1e-12
+            assert abs(mean - float(np.mean(want))) < 1e-12
+
+
+def test_mrr_against_brute_force():
+    """RetrievalMRR restatement vs a literal search: rank every candidate by counting the ones that beat it."""
+    g = np.random.Generator(np.random.PCG64(6))
+    sizes = [1, 2, 3, 8, 40, 300]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    scores = g.permutation(int(off[-1])).astype(np.float32)
+    tgt = (g.random(int(off[-1])) < 0.1).astype(np.float32)
+    tgt[off[3]:off[4]] = 0.0
+    _, per = O.mrr(torch.from_numpy(scores), torch.from_numpy(tgt), off.tolist())
+    want = []
+    for a, b in zip(off[:-1], off[1:]):
+        best = None
+        for j in range(a, b):
+            if tgt[j] > 0:
+                rank = 1 + sum(1 for i in range(a, b) if scores[i] > scores[j])
+                best = rank if best is None else min(best, rank)
+        want.append(0.0 if best is None else 1.0 / best)
+    assert np.abs(per.numpy() - np.asarray(want)).max() < 1e-12
+
+
+def test_to_dense_batch_against_pad_sequence():
+    """to_dense_batch restatement vs torch.nn.utils.rnn.pad_sequence over the per-segment slices (both zero-pad to the
+    longest segment, keep the original order inside a segment)."""
+    from torch.nn.utils.rnn import pad_sequence
+    g = np.random.Generator(np.random.PCG64(7))
+    sizes = [3, 1, 7, 2, 5]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))      # _make_batch_assignees
+    for inner in ((), (4,), (2, 3)):
+        x = torch.from_numpy(g.standard_normal((sum(sizes),) + inner).astype(np.float32))
+        dense, mask = O.to_dense_batch(x, batch)
+        want = pad_sequence(list(torch.split(x, sizes)), batch_first=True)
+        assert torch.equal(dense, want)
+        assert torch.equal(mask, pad_sequence([torch.ones(s, dtype=torch.bool) for s in sizes], batch_first=True))
+
+
+def test_zscore_against_numpy():
+    """K13 restatement vs a direct numpy evaluation of ensemble_module.py:138-149 on a ragged batch: mean over the
+    zero-padded row divided by c_i, unbiased std of the valid entries, the WHOLE padded row normalised."""
+    g = np.random.Generator(np.random.PCG64(8))
+    sizes = [4, 9, 2, 6]
+    batch = torch.repeat_interleave(torch.arange(4), torch.tensor(sizes))
+    flat = torch.from_numpy(g.standard_normal(sum(sizes)).astype(np.float32) * 3 + 1)
+    dense, mask = O.to_dense_batch(flat, batch)
+    z = O.zscore(dense, mask).numpy()
+    for i, c in enumerate(sizes):
+        row = dense[i].numpy().astype(np.float64)
+        mean, std = row.sum() / c, row[:c].std(ddof=1)
+        assert np.abs(z[i] - (row - mean) / std).max() < 1e-5
+        assert c == max(sizes) or abs(z[i, c] - (-mean / std)) < 1e-5            # padded slot: not zero
