@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""Headline bench: candidate news encoded+scored per second (BASELINE.json metric), configs[1]:
-CR-Module, MIND-small shape, bert-base-uncased architecture, bf16, HIP NewsEncoder + scorer.
+"""Headline bench: candidate news encoded+scored per second (BASELINE.json metric).
 
-One STEP = one pass of the hot path over one batch of synthetic impressions in reference-faithful
-mode R: EVERY history and candidate occurrence of the batch is encoded by the PLM
-(as reference cr_module.py:107,113 does — nothing is cached or deduplicated), then late-fusion
-mean + dot product per candidate, stable top-10 ranking and nDCG@10.  Token tensors, index lists
-and labels of every step are resident in HBM before the timed region; each step uses different
-impressions.  value = candidates scored by all ranks / max-over-ranks wall time of the K steps.
-
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py [--config 1|2|3|4] --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: impressions are independent, so ranks take disjoint impression batches (weak scaling,
-no data-path collective in mode R; barrier + MAX over ranks for the clock).  The table
-architecture with the RCCL all-gather of the news-embedding table is measured by --table.
+--config selects the BASELINE.json configuration (default 1, the one the metric is quoted on):
+  1  CR-Module, MIND-small shape, bert-base-uncased architecture, bf16
+  2  CR-Module + category A-Module ensemble (two encoders, z-score fusion), MIND-small shape
+  3  full MANNeR (CR + category + sentiment A-Modules: three encoders), MIND-large shape (161 013-news pool)
+  4  roberta-large architecture, MIND-large shape (bf16: the fp8 path does not exist yet)
+
+One STEP = one pass of the hot path over one batch of synthetic impressions in reference-faithful mode R (SURVEY.md
+§8d): EVERY history and candidate occurrence of the batch is encoded by every active module's PLM (as reference
+cr_module.py:107,113 / ensemble_module.py:115-121 do — nothing is cached or deduplicated), then late-fusion mean + dot
+per candidate (per module), per-impression z-score + weighted fusion when there is more than one module, stable top-10
+ranking and nDCG@10.  Token tensors, index lists and labels of every step are resident in HBM before the timed region;
+each step uses different impressions.  value = candidates scored by all ranks / max-over-ranks wall time of the K steps.
+
+Multi-GPU: impressions are independent, so ranks take disjoint impression batches (weak scaling, no data-path
+collective in mode R; barrier + MAX over ranks for the clock).  The table architecture with the RCCL all-gather of the
+news-embedding table is measured in the `table_mode` object.
 """
 from __future__ import annotations
 
@@ -33,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 from manner_amd import hip, hotpath  # noqa: E402
 from manner_amd.config import PRESETS  # noqa: E402
-from manner_amd.synth import (MIND_SMALL, shard_range, synth_impression_blocks, synth_impressions,  # noqa: E402
+from manner_amd.synth import (MIND_LARGE, MIND_SMALL, shard_range, synth_impression_blocks, synth_impressions,  # noqa: E402
                               synth_news_tokens)
 from manner_amd.weights import make_plm_weights  # noqa: E402
 
@@ -41,6 +46,17 @@ BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 F32_PEAK_TFLOPS = 157.3        # f32-input MFMA
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs[1..4]; ensemble weights from SURVEY.md §8d (categ_weight, sent_weight)
+CONFIGS = {
+    1: dict(model="bert-base-uncased", shape="MIND-small", dims=MIND_SMALL, weights=(),
+            what="configs[1]: CR-Module late fusion"),
+    2: dict(model="bert-base-uncased", shape="MIND-small", dims=MIND_SMALL, weights=(-0.3,),
+            what="configs[2]: CR-Module + category A-Module ensemble (2 encoders, z-score fusion, categ_weight -0.3)"),
+    3: dict(model="bert-base-uncased", shape="MIND-large", dims=MIND_LARGE, weights=(-0.3, 0.2),
+            what="configs[3]: full MANNeR, CR + category + sentiment A-Modules (3 encoders, weights -0.3 / 0.2)"),
+    4: dict(model="roberta-large", shape="MIND-large", dims=MIND_LARGE, weights=(),
+            what="configs[4]: CR-Module late fusion, roberta-large architecture in bf16 (the fp8 path is not built)"),
+}
 
 _T0 = time.perf_counter()
 
@@ -55,11 +71,12 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     p.add_argument("--impressions", type=int, default=256, help="impressions per step per GPU")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     p.add_argument("--profile", default="title_abstract", choices=["title", "title_abstract"],
                    help="token-length profile of the news pool (SURVEY.md §8d)")
-    p.add_argument("--model", default="bert-base-uncased")
+    p.add_argument("--model", default=None, help="override the configuration's PLM architecture preset")
     p.add_argument("--std", type=float, default=0.02, help="std of the seeded PLM weight matrices")
     p.add_argument("--chunk-tokens", type=int, default=65536)
     p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline sample")
@@ -67,6 +84,8 @@ def parse():
     p.add_argument("--no-kernel-profile", action="store_true")
     p.add_argument("--no-collate", action="store_true", help="skip the device-side collate leg")
     p.add_argument("--no-table", action="store_true", help="skip the table-mode (encode pool once + all-gather) leg")
+    p.add_argument("--no-scale-parity", action="store_true", help="skip the at-scale bf16-vs-fp32 ranking comparison")
+    p.add_argument("--no-small-ops", action="store_true", help="skip the pooler / dot / z-score kernel legs")
     return p.parse_args()
 
 
@@ -89,52 +108,118 @@ class StepBatch:
         self.cand_idx = torch.arange(self.n_hist, self.n_hist + self.n_cand, dtype=torch.int32, device=dev)
         self.labels = torch.from_numpy(imp["labels"][c0:c1]).to(dev)
         self.tokens = int(self.lens.sum())
-        self.flops = None
 
 
-def run_step(enc, b, precision, chunk_tokens, table_buf):
-    table = enc.encode_cls(b.ids, b.mask, precision=precision, host_lengths=b.lens, max_chunk_tokens=chunk_tokens,
-                           out=table_buf[: b.ids.shape[0]])
-    scores = hip.score_late_fusion(table, b.hist_idx, b.hist_off, b.cand_idx, b.cand_off, total_cand=b.n_cand)
+def run_step(encs, b, precision, chunk_tokens, table_bufs, plane_buf, weights):
+    """Mode R for K = len(encs) modules: encode every occurrence with every module, score, fuse, rank."""
+    n = b.ids.shape[0]
+    for k, enc in enumerate(encs):
+        table = enc.encode_cls(b.ids, b.mask, precision=precision, host_lengths=b.lens, max_chunk_tokens=chunk_tokens,
+                               out=table_bufs[k][:n])
+        hip.score_late_fusion(table, b.hist_idx, b.hist_off, b.cand_idx, b.cand_off, total_cand=b.n_cand,
+                              out=plane_buf[k, : b.n_cand])
+    if len(encs) == 1:
+        scores = plane_buf[0, : b.n_cand]
+    else:
+        scores = hip.zscore_fuse(plane_buf[:, : b.n_cand], list(weights), b.cand_off)
     topk, ndcg = hip.rank_ndcg(scores, b.labels, b.cand_off, 10)
     return scores, topk, ndcg
 
 
-def cpu_baseline_and_parity(args, cfg, weights, enc, imp, pool, dev, nb=None):
-    """Oracle (CPU port of the reference path) on a bounded sample + parity of the HIP path on it."""
+# --------------------------------------------------------------------------------------------------- CPU baseline
+def host_cpu():
+    """(threads to use, how that number was found, CPU model).  The GPU box grants a CPU share per GPU through the
+    cgroup quota; os.cpu_count() reports the whole host."""
+    aff = len(os.sched_getaffinity(0))
+    quota, how = None, f"sched_getaffinity={aff}"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+            how += f", cgroup cpu.max={q}/{per}"
+    except OSError:
+        pass
+    cores = min(aff, quota) if quota else aff
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return cores, how, model
+
+
+def cpu_reference(O, cfg, weight_sets, fuse_w, pool, imp, nb):
+    """The oracle's mode R on the first nb impressions: ragged scores (one module) or fused z-scores (ensemble)."""
+    pool_ids, pool_mask, _ = pool
+    ho, co = imp["hist_off"][: nb + 1], imp["cand_off"][: nb + 1]
+    hi, ci = imp["hist_idx"][: ho[-1]].astype(np.int64), imp["cand_idx"][: co[-1]].astype(np.int64)
+    if len(weight_sets) == 1:
+        return O.reference_faithful_scores(pool_ids, pool_mask, hi, ho.tolist(), ci, co.tolist(), weight_sets[0], cfg, chunk=64)
+    bh, bc = O.offsets_to_batch(ho.tolist()), O.offsets_to_batch(co.tolist())
+
+    def enc(w, idx):
+        outs = []
+        for s in range(0, idx.shape[0], 64):
+            j = idx[s:s + 64]
+            m = pool_mask[j]
+            lp = int(m.sum(1).max())
+            outs.append(O.encode_cls(pool_ids[j][:, :lp], m[:, :lp], w, cfg))
+        return torch.cat(outs)
+
+    vecs = [(enc(w, hi), enc(w, ci)) if (k == 0 or fuse_w[k - 1] != 0) else None for k, w in enumerate(weight_sets)]
+    vecs = [v if v is not None else vecs[0] for v in vecs]
+    return O.ragged(O.ensemble_scores(vecs, bh, bc, fuse_w), bc)
+
+
+def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev, nb, time_it=True):
+    """Oracle (CPU port of the reference path) on a bounded sample — one warm-up impression, then best of 3 — and
+    parity of the HIP path on the same sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import manner_oracle as O
     pool_ids, pool_mask, pool_len = pool
-    nb = nb or args.cpu_impressions
-    ho, co = imp["hist_off"][: nb + 1], imp["cand_off"][: nb + 1]
-    hi, ci = imp["hist_idx"][: ho[-1]], imp["cand_idx"][: co[-1]]
-    # the GPU box grants a CPU share of 16 cores per GPU; os.cpu_count() reports the whole host
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores, how, model = host_cpu()
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    ref = O.reference_faithful_scores(pool_ids, pool_mask, hi.astype(np.int64), ho.tolist(), ci.astype(np.int64),
-                                      co.tolist(), weights, cfg, chunk=64)
-    cpu_s = time.perf_counter() - t0
+    co = imp["cand_off"][: nb + 1]
+    ho = imp["hist_off"][: nb + 1]
+    times = []
+    if time_it:
+        cpu_reference(O, cfg, weight_sets, fuse_w, pool, imp, 1)              # warm-up (thread pool, allocator, oneDNN)
+    for _ in range(3 if time_it else 1):
+        t0 = time.perf_counter()
+        ref = cpu_reference(O, cfg, weight_sets, fuse_w, pool, imp, nb)
+        times.append(time.perf_counter() - t0)
+    cpu_s = min(times)
     labels = torch.from_numpy(imp["labels"][: co[-1]])
     ref_ndcg, _ = O.ndcg_at_k(ref, labels, co.tolist(), 10)
     ref_top = O.topk_indices(ref, co.tolist(), 10)
     b = StepBatch(imp, 0, nb, torch.from_numpy(pool_ids).to(dev), torch.from_numpy(pool_mask).to(dev), pool_len, dev)
-    buf = torch.empty((b.ids.shape[0], cfg.hidden), dtype=torch.float32, device=dev)
+    bufs = [torch.empty((b.ids.shape[0], cfg.hidden), dtype=torch.float32, device=dev) for _ in encs]
+    planes = torch.empty((len(encs), b.n_cand), dtype=torch.float32, device=dev)
     par = {}
     for prec in ("fp32", "bf16"):
-        scores, topk, ndcg = run_step(enc, b, prec, args.chunk_tokens, buf)
+        scores, topk, ndcg = run_step(encs, b, prec, args.chunk_tokens, bufs, planes, fuse_w)
         top = [[v for v in row if v >= 0] for row in topk.cpu().tolist()]
         agree = float(np.mean([t == r for t, r in zip(top, ref_top)]))
-        par[prec] = {"score_max_abs_err": float((scores.cpu() - ref).abs().max()),
+        par[prec] = {"score_max_abs_err": float((scores.cpu() - ref).abs().nan_to_num(0.0).max()),
                      "top10_identical_frac": agree,
                      "ndcg10_delta": float(abs(ndcg.double().mean().item() - ref_ndcg))}
-    par["score_abs_scale"] = float(ref.abs().max())
+    par["score_abs_scale"] = float(ref.abs().nan_to_num(0.0).max())
+    par["impressions"] = nb
     cpu = {"value": float(co[-1] / cpu_s), "unit": "candidates/s", "cores": cores, "kind": "port",
-           "sample": f"oracle/manner_oracle.py mode R on the first {nb} impressions "
-                     f"({int(ho[-1] + co[-1])} news encodes, {cpu_s:.1f} s, torch {torch.__version__} CPU fp32)"}
+           "cpu_model": model, "cores_how": how, "runs_s": [round(t, 2) for t in times],
+           "sample": f"oracle/manner_oracle.py mode R on the first {nb} impressions ({int(ho[-1] + co[-1])} news encodes x "
+                     f"{sum(1 for k in range(len(weight_sets)) if k == 0 or fuse_w[k - 1] != 0)} module(s)), 1-impression warm-up then best of 3 "
+                     f"({cpu_s:.1f} s), torch {torch.__version__} CPU fp32, {cores} threads; SURVEY §8d asks for a 64-impression "
+                     "slice — the cost is linear in impressions, so this slice is extrapolated, bounded to ~30 s of CPU work"}
     return cpu, par
 
 
+# --------------------------------------------------------------------------------------------------- collate leg
 def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
     """Device-side collate of one step's impressions from the tokenised store: checked against
     the step's own input tensors, timed with events; algorithmic bytes = 4 B read + 16 B written per token slot
@@ -147,7 +232,6 @@ def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
     collate = DeviceCollate(store, bhv)
     rng = range(lo, lo + args.impressions)
     mb = collate(rng)
-    lp = b.ids.shape[1]
     same = True
     off = 0
     for side in ("x_hist", "x_cand"):
@@ -182,7 +266,6 @@ def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
     ms_big = e0.elapsed_time(e1) / 5
     slots_big = sum(mbig[s]["text"]["input_ids"].numel() for s in ("x_hist", "x_cand"))
     bytes_big = 20 * slots_big + 8 * (mbig["batch_hist"].numel() + mbig["batch_cand"].numel())
-    # the text kernel alone (no host-side offset slicing, no allocation of the small tensors)
     rows_d, lp_big = cbig.cand_rows_d, int(mbig["x_cand"]["text"]["input_ids"].shape[1])
     hip.collate_text(store.ids_d, store.len_d, rows_d, lp_big, store.pad_id)
     torch.cuda.synchronize()
@@ -204,22 +287,99 @@ def collate_leg(args, cfg, imp, pool_ids_np, pool_len, b, lo, dev, iters=20):
                     "launch-bound at this batch size, HBM roofline applies to the text kernel only"}
 
 
-def table_mode(args, cfg, enc, pool, rank, world, dev):
-    """Mode T: every rank encodes its FLOP-balanced shard of the unique-news pool once,
-    one RCCL all-gather assembles the [N_news, D] table on every rank, then each rank scores its block of
-    MIND-small-shaped impressions (73 152 in total) by index.  Reported beside the headline, never as it."""
+# --------------------------------------------------------------------------------------------------- small kernels
+def timed_ms(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def small_ops_leg(dev, B=4096, S=50, D=768, Q=200, C=37):
+    """The HBM-side tail kernels at an evaluation-sized batch: additive-attention pooler (K11),
+    DotProduct drop-in (K12), z-score + fusion (K13+K14), to_dense (K9).  Algorithmic bytes per SURVEY §8d: every
+    input read once, every output written once; time by HIP events on the launch stream (torch's current stream)."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    out = {}
+    x = torch.randn((B, S, D), device=dev, generator=g)
+    W, bq, q = torch.randn((Q, D), device=dev, generator=g) * 0.05, torch.zeros(Q, device=dev), torch.randn(Q, device=dev, generator=g)
+    ms = timed_ms(lambda: hip.additive_pool(x, W, bq, q))
+    nbytes = x.numel() * 4 + B * D * 4 + (Q * D + 2 * Q) * 4
+    flops = 2.0 * B * S * D * Q
+    out["additive_pool"] = {"shape": {"B": B, "S": S, "D": D, "Q": Q}, "ms": ms, "algorithmic_bytes": nbytes,
+                            "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                            "logit_tflops_f32": flops / ms / 1e9, "frac_of_f32_mfma_peak": flops / ms / 1e9 / F32_PEAK_TFLOPS,
+                            "bound": "f32 MFMA (exact f32 x.W^T: 0.5 kFLOP per byte of x) — the second pass re-reads x"}
+    del x
+    user = torch.randn((B, 1, D), device=dev, generator=g)
+    cand = torch.randn((B, C, D), device=dev, generator=g)
+    ms = timed_ms(lambda: hip.dot(user, cand.permute(0, 2, 1)))
+    nbytes = (cand.numel() + user.numel() + B * C) * 4
+    out["dot"] = {"shape": {"B": B, "C": C, "D": D}, "ms": ms, "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6,
+                  "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+    imp = synth_impressions(MIND_SMALL["n_impressions"], 65238, seed=43)
+    off = torch.from_numpy(imp["cand_off"]).to(dev)
+    total = int(imp["cand_off"][-1])
+    planes = torch.randn((3, total), device=dev, generator=g)
+    ms = timed_ms(lambda: hip.zscore_fuse(planes, [-0.3, 0.2], off))
+    nbytes = (3 * total + total) * 4 + off.numel() * 8
+    out["zscore_fuse"] = {"shape": {"K": 3, "candidates": total, "impressions": int(off.numel() - 1)}, "ms": ms,
+                          "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                          "note": "124 B per impression and plane on average: latency-bound wave-per-impression work"}
+    nb = 8192
+    cvec = cand.reshape(-1, D)[: int(imp["cand_off"][nb])].contiguous() if cand.numel() // D >= int(imp["cand_off"][nb]) else None
+    if cvec is not None:
+        off8 = off[: nb + 1].contiguous()
+        width = int(np.diff(imp["cand_off"][: nb + 1]).max())
+        ms = timed_ms(lambda: hip.to_dense(cvec, off8, width))
+        nbytes = cvec.numel() * 4 + nb * width * D * 4
+        out["to_dense"] = {"shape": {"B": nb, "width": width, "D": D, "rows": int(cvec.shape[0])}, "ms": ms,
+                           "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+    return out
+
+
+# --------------------------------------------------------------------------------------------------- table mode
+def ranking_agreement(a, b, labels, off):
+    """Ranking metrics of score vector a (throughput mode) against b (the HIP fp32 parity mode, itself pinned to the
+    reference at 1e-5) over all impressions: on the device."""
+    ta, na, ma = hip.rank_ndcg(a, labels, off, 10, with_mrr=True)
+    tb, nb_, mb = hip.rank_ndcg(b, labels, off, 10, with_mrr=True)
+    same = (ta == tb).all(dim=1)
+    inter = (ta.unsqueeze(2) == tb.unsqueeze(1)) & (ta.unsqueeze(2) >= 0)
+    overlap = inter.any(dim=2).sum(1).double() / (tb >= 0).sum(1).clamp(min=1).double()
+    return {"impressions": int(same.numel()), "top10_identical_frac": float(same.double().mean()),
+            "top1_identical_frac": float((ta[:, 0] == tb[:, 0]).double().mean()),
+            "top10_set_overlap_mean": float(overlap.mean()),
+            "ndcg10": float(na.double().mean()), "ndcg10_parity_mode": float(nb_.double().mean()),
+            "ndcg10_delta": float((na.double().mean() - nb_.double().mean()).abs()),
+            "ndcg10_per_impression_abs_delta_mean": float((na.double() - nb_.double()).abs().mean()),
+            "mrr_delta": float((ma.double().mean() - mb.double().mean()).abs()),
+            "score_max_abs_err": float((a - b).abs().nan_to_num(0.0).max()), "score_abs_scale": float(b.abs().nan_to_num(0.0).max())}
+
+
+def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_parity):
+    """Mode T: every rank encodes its FLOP-balanced shard of the unique-news pool once per module,
+    one RCCL all-gather per module assembles the [N_news, D] table on every rank, then each rank scores its block of
+    the configuration's dev-set-shaped impressions by index.  Reported beside the headline, never as it."""
     from manner_amd import distributed as D
     pool_ids, pool_mask, pool_len = pool
     n_news = pool_ids.shape[0]
+    n_imp = conf["dims"]["n_impressions"]
     shards = D.balanced_news_shards(pool_len, world, cfg.flops_per_news)
     lo, hi = shards[rank]
-    imp = synth_impressions(MIND_SMALL["n_impressions"], n_news, seed=43)
-    a, b = shard_range(MIND_SMALL["n_impressions"], rank, world)
+    imp = synth_impressions(n_imp, n_news, seed=43)
+    a, b = shard_range(n_imp, rank, world)
     ho, co = imp["hist_off"], imp["cand_off"]
     dimp = {"hist_idx": torch.from_numpy(imp["hist_idx"][ho[a]:ho[b]]).to(dev), "hist_off": torch.from_numpy(ho[a:b + 1] - ho[a]).to(dev),
             "cand_idx": torch.from_numpy(imp["cand_idx"][co[a]:co[b]]).to(dev), "cand_off": torch.from_numpy(co[a:b + 1] - co[a]).to(dev)}
     labels = torch.from_numpy(imp["labels"][co[a]:co[b]]).to(dev)
-    local = torch.empty((hi - lo, cfg.hidden), dtype=torch.float32, device=dev)
+    K = len(encs)
+    local = [torch.empty((hi - lo, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]
 
     def sync():
         torch.cuda.synchronize()
@@ -227,32 +387,27 @@ def table_mode(args, cfg, enc, pool, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def encode_all(prec):
+        for k in range(K):
+            encs[k].encode_cls(pool_ids[lo:hi], pool_mask[lo:hi], precision=prec, host_lengths=pool_len[lo:hi],
+                               max_chunk_tokens=args.chunk_tokens, out=local[k])
+
     times = {}
     for it in range(2):                                 # pass 0 warms up (workspace, RCCL channels)
         sync(); t0 = time.perf_counter()
-        enc.encode_cls(pool_ids[lo:hi], pool_mask[lo:hi], precision=args.precision, host_lengths=pool_len[lo:hi],
-                       max_chunk_tokens=args.chunk_tokens, out=local)
+        encode_all(args.precision)
         sync(); t1 = time.perf_counter()
-        table = D.all_gather_table(local, shards)
+        tables = [D.all_gather_table(local[k], shards) for k in range(K)]
         sync(); t2 = time.perf_counter()
-        res = hotpath.score_impressions([table], dimp, labels=labels, k=10)
+        res = hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10)
         sync(); t3 = time.perf_counter()
         times = {"encode_s": t1 - t0, "allgather_s": t2 - t1, "score_s": t3 - t2, "total_s": t3 - t0}
-    # epoch-end metrics of this rank's block on the device: timed separately, not part of total_s
-    def timed_ms(fn, iters=5):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
     sc_r, off_r = res["scores"], dimp["cand_off"]
     n_c = int(sc_r.numel())
+    # the fused scorer alone on the first table, by HIP events (the score_s above also holds fusion + ranking)
+    scorer_ms = timed_ms(lambda: hip.score_late_fusion(tables[0], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
     metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
-                  "auc": timed_ms(lambda: hip.auc(sc_r, labels)),
+                  "auc": timed_ms(lambda: hip.auc(sc_r.nan_to_num(0.0), labels)),
                   "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
     st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"]], dtype=torch.float64, device=dev)
     nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a)], dtype=torch.float64, device=dev)
@@ -261,22 +416,48 @@ def table_mode(args, cfg, enc, pool, rank, world, dev):
         D.allreduce_metric_sums(nd)
     enc_s, ag_s, sc_s, tot_s = st.tolist()
     total_c = int(co[-1])
-    hbm_bytes = float(ho[-1] + co[-1]) * (cfg.hidden * 4 + 4) + float(co[-1]) * 4
-    return {"what": "unique-news table: encode shard -> all-gather -> score all 73152 MIND-small-shaped impressions",
-            "candidates_per_s": total_c / tot_s, "news_encoded_per_s": n_news / enc_s,
-            "scorer_pairs_per_s": total_c / sc_s, "scorer_GBps_algorithmic": hbm_bytes / sc_s / 1e9 / world,
-            "scorer_frac_of_8TBps": hbm_bytes / sc_s / 1e9 / world / HBM_PEAK_GBS,
-            "allgather_ms": 1e3 * ag_s, "allgather_bytes_per_rank": (n_news - (hi - lo)) * cfg.hidden * 4 if world > 1 else 0,
-            # bytes every rank RECEIVES over xGMI / time, against 7 links x 153 GB/s per GPU
-            "allgather_GBps_per_rank": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9) if world > 1 and ag_s > 0 else None,
-            "allgather_frac_of_xgmi": ((n_news - (hi - lo)) * cfg.hidden * 4 / ag_s / 1e9 / (7 * 153.0)) if world > 1 and ag_s > 0 else None,
-            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(),
-            "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
-                                 "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}
+    occ_local = float((ho[b] - ho[a]) + (co[b] - co[a]))
+    scorer_bytes = occ_local * (cfg.hidden * 4 + 4) + float(co[b] - co[a]) * 4
+    table_bytes = n_news * cfg.hidden * 4
+    out = {"what": f"unique-news table ({n_news} news x {K} module(s)): encode shard -> all-gather -> score all {n_imp} "
+                   f"{conf['shape']}-shaped impressions",
+           "candidates_per_s": total_c / tot_s, "news_encoded_per_s": n_news * K / enc_s,
+           "scorer_pairs_per_s": total_c * K / sc_s,
+           "scorer_kernel_ms_rank0": scorer_ms, "scorer_algorithmic_bytes_rank0": scorer_bytes,
+           "scorer_GBps_algorithmic": scorer_bytes / scorer_ms / 1e6,
+           "scorer_frac_of_8TBps": scorer_bytes / scorer_ms / 1e6 / HBM_PEAK_GBS,
+           "table_MB": table_bytes / 1e6,
+           "scorer_note": ("occurrence bytes: every history/candidate row read counts once; rows repeat (Zipf), so a table "
+                           "that fits the 256 MiB Infinity Cache is served from cache and this is a cache hit rate, not an "
+                           "HBM fraction — see profiles/ for the FETCH_SIZE pass" if table_bytes < 256 * 2 ** 20 else
+                           "occurrence bytes: every history/candidate row read counts once; the table exceeds the 256 MiB "
+                           "Infinity Cache, popular rows (Zipf) still hit — HBM-side bytes are in profiles/ (FETCH_SIZE pass)"),
+           "allgather_ms": 1e3 * ag_s, "allgather_bytes_per_rank": (n_news - (hi - lo)) * cfg.hidden * 4 * K if world > 1 else 0,
+           "allgather_GBps_per_rank": ((n_news - (hi - lo)) * cfg.hidden * 4 * K / ag_s / 1e9) if world > 1 and ag_s > 0 else None,
+           "allgather_frac_of_xgmi": ((n_news - (hi - lo)) * cfg.hidden * 4 * K / ag_s / 1e9 / (7 * 153.0)) if world > 1 and ag_s > 0 else None,
+           "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(),
+           "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
+                                "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}
+    parity = None
+    if scale_parity and world == 1:
+        # the throughput mode against the HIP fp32 mode (pinned to the reference at <= 2e-5 by the
+        # golden tests) on the WHOLE dev-set shape, same tables / impressions, both weight sets
+        log("at-scale parity: fp32 encode of the pool")
+        sc_fast = sc_r.clone()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        encode_all("fp32")
+        torch.cuda.synchronize(); t_f32 = time.perf_counter() - t0
+        res32 = hotpath.score_impressions(list(local), dimp, weights=fuse_w, labels=labels, k=10)
+        parity = {"what": f"{args.precision} vs the HIP fp32 parity mode, table mode, {n_news} news, all {n_imp} impressions",
+                  "hf_init_weights_std0.02": ranking_agreement(sc_fast, res32["scores"], labels, off_r),
+                  "parity_mode_news_per_s": n_news * K / t_f32, "parity_mode_encode_s": t_f32}
+    return out, parity, (dimp, labels)
 
 
+# --------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    conf = CONFIGS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,13 +477,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = PRESETS[args.model]
-    log("generating seeded weights")
-    weights = make_plm_weights(cfg, seed=42, std=args.std)
-    log("packing weights into the HIP encoder")
-    enc = hip.HipEncoder(cfg, weights, precisions=("bf16", "fp32") + (("bf16x3",) if args.precision == "bf16x3" else ()), device=dev)
-    n_news = MIND_SMALL["n_news"]
-    log("synthesising news pool + impressions")
+    model = args.model or conf["model"]
+    cfg = PRESETS[model]
+    fuse_w = tuple(conf["weights"])
+    K = 1 + len(fuse_w)
+    log(f"config {args.config}: {conf['what']}; generating seeded weights for {K} module(s)")
+    weight_sets = [make_plm_weights(cfg, seed=42 + 100 * k, std=args.std) for k in range(K)]
+    log("packing weights into the HIP encoders")
+    precs = ("bf16", "fp32") + (("bf16x3",) if args.precision == "bf16x3" else ())
+    encs = [hip.HipEncoder(cfg, w, precisions=precs, device=dev) for w in weight_sets]
+    n_news = conf["dims"]["n_news"]
+    log(f"synthesising the {conf['shape']}-shaped news pool ({n_news} news) + impressions")
     pool_ids_np, pool_mask_np = synth_news_tokens(n_news, cfg, seed=42, max_len=96, profile=args.profile)
     pool_len = pool_mask_np.sum(1)
     pool_ids, pool_mask = torch.from_numpy(pool_ids_np).to(dev), torch.from_numpy(pool_mask_np).to(dev)
@@ -310,11 +495,12 @@ def main():
     # one independent 256-impression draw per (rank, step): step s of rank r is the same batch for every --steps and
     # --gpus, so the figure does not depend on how many steps were asked for beyond averaging over more batches
     imp_all = synth_impression_blocks([rank * 1_000_000 + s for s in range(n_steps)], args.impressions, n_news, seed=42)
-    lo_r = 0
-    batches = [StepBatch(imp_all, lo_r + s * args.impressions, lo_r + (s + 1) * args.impressions, pool_ids, pool_mask,
-                         pool_len, dev) for s in range(n_steps)]
+    batches = [StepBatch(imp_all, s * args.impressions, (s + 1) * args.impressions, pool_ids, pool_mask, pool_len, dev)
+               for s in range(n_steps)]
     max_news = max(b.ids.shape[0] for b in batches)
-    table_buf = torch.empty((max_news, cfg.hidden), dtype=torch.float32, device=dev)
+    max_cand = max(b.n_cand for b in batches)
+    table_bufs = [torch.empty((max_news, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]
+    plane_buf = torch.empty((K, max_cand), dtype=torch.float32, device=dev)
 
     def barrier():
         if world > 1:
@@ -322,30 +508,32 @@ def main():
 
     log(f"{n_steps} step batches resident ({batches[0].ids.shape[0]} news, {batches[0].tokens} tokens in step 0); warm-up")
     for b in batches[: args.warmup]:
-        run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+        run_step(encs, b, args.precision, args.chunk_tokens, table_bufs, plane_buf, fuse_w)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
     for b in batches[args.warmup:]:
-        last = run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+        last = run_step(encs, b, args.precision, args.chunk_tokens, table_bufs, plane_buf, fuse_w)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
-    enc.status()
+    for e in encs:
+        e.status()
+    hip.check_status(dev)
 
     timed = batches[args.warmup:]
     cands = float(sum(b.n_cand for b in timed))
-    news = float(sum(b.n_hist + b.n_cand for b in timed))
-    tokens = float(sum(b.tokens for b in timed))
-    enc_flops = float(sum(cfg.flops_per_news(int(l)) for b in timed for l in b.lens))
+    news = float(sum(b.n_hist + b.n_cand for b in timed)) * K
+    tokens = float(sum(b.tokens for b in timed)) * K
+    enc_flops = float(sum(cfg.flops_per_news(int(l)) for b in timed for l in b.lens)) * K
     h_, i_ = cfg.hidden, cfg.intermediate
     per_layer = lambda l: 8 * l * h_ * h_ + 4 * l * h_ * i_ + 4 * l * l * h_      # noqa: E731
     exec_flops = float(sum((cfg.layers - 1) * per_layer(int(l)) + 4 * int(l) * h_ * h_ + 4 * int(l) * h_
-                           + 4 * h_ * h_ + 4 * h_ * i_ for b in timed for l in b.lens))
+                           + 4 * h_ * h_ + 4 * h_ * i_ for b in timed for l in b.lens)) * K
     stats = torch.tensor([elapsed, cands, news, tokens, enc_flops, exec_flops], dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone()
@@ -356,14 +544,15 @@ def main():
 
     result = None
     if rank == 0:
-        peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else F32_PEAK_TFLOPS
+        peak = BF16_PEAK_TFLOPS if args.precision in ("bf16", "bf16x3") else F32_PEAK_TFLOPS
         result = {
             "metric": "candidate news encoded+scored/sec", "value": cands_all / elapsed_max, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "configs[1]: CR-Module late fusion, MIND-small shape (65238-news pool), "
-                                   f"{args.model} architecture, mode R (every history+candidate occurrence encoded)",
+            "config": {"workload": f"{conf['what']}, {conf['shape']} shape ({n_news}-news pool), {model} architecture, "
+                                   "mode R (every history+candidate occurrence encoded by every active module)",
+                       "baseline_config": args.config, "modules": K, "ensemble_weights": list(fuse_w),
                        "impressions_per_step_per_gpu": args.impressions, "length_profile": args.profile,
                        "seeded_weights_std": args.std, "parallelism": f"dp{world} (impressions sharded, no collective)"},
             "news_encoded_per_s": news_all / elapsed_max, "tokens_per_s": tokens_all / elapsed_max,
@@ -379,9 +568,10 @@ def main():
     # per-kernel roofline: same steps again with every launch bracketed by HIP events on the launch stream
     if rank == 0 and not args.no_kernel_profile:
         log("per-kernel HIP-event pass")
+        enc = encs[0]
         enc.profile(True)
         for b in timed:
-            run_step(enc, b, args.precision, args.chunk_tokens, table_buf)
+            run_step([enc], b, args.precision, args.chunk_tokens, table_bufs, plane_buf, ())
         prof = enc.profile_read()
         enc.profile(False)
         tok_local = float(sum(b.tokens for b in timed))
@@ -398,49 +588,70 @@ def main():
                 continue
             ent = {"ms_total": ms, "launches": cnt, "avg_us": 1e3 * ms / cnt}
             if cls in shape:
-                n_, k_ = shape[cls]
                 fl = 2.0 * nk_total[cls] * tok_local / cnt                 # algorithmic FLOPs per launch (average)
                 ent["flops_per_launch"] = fl
                 ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
             kern[cls] = ent
         dom = max((c for c in kern if c in shape), key=lambda c: kern[c]["ms_total"])
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-        # runs; bench.py cannot collect counters itself): profiles/r1_final/pmc_traffic.json
+        # runs; bench.py cannot collect counters itself): the newest profiles/r*_final/pmc_traffic.json
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_final", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.chunk_tokens == 65536 and args.model == "bert-base-uncased":
-            with open(tpath) as f:
-                tj = json.load(f)
-            if dom in tj:
-                traffic = tj[dom]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r1_final/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, full 65536-token launch)"
+        for rdir in ("r2_final", "r1_final"):
+            tpath = os.path.join(ROOT, "profiles", rdir, "pmc_traffic.json")
+            if os.path.exists(tpath) and args.chunk_tokens == 65536 and model == "bert-base-uncased" and args.precision == "bf16":
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if dom in tj:
+                    traffic = tj[dom]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/{rdir}/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of this command, full 65536-token launch)"
+                    break
         result["kernels"] = kern
         result["roofline"] = {
-            "kernel": dom + " (gemm_tn_x16_kernel)", "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+            "kernel": dom + (" (gemm_tn_x16_kernel)" if args.precision != "fp32" else " (gemm_tn_big_kernel)"), "bound": "mfma",
+            "achieved": kern[dom]["tflops"], "peak": peak,
             "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
             "mfma_only_ceiling_tflops": 2040.0 if args.precision == "bf16" else None,
             "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops_per_launch"]}
     barrier()
 
     if rank == 0 and not args.no_collate:
-        result["collate"] = collate_leg(args, cfg, imp_all, pool_ids_np, pool_len, batches[-1], lo_r + (n_steps - 1) * args.impressions, dev)
+        result["collate"] = collate_leg(args, cfg, imp_all, pool_ids_np, pool_len, batches[-1], (n_steps - 1) * args.impressions, dev)
+    del batches, table_bufs
     if not args.no_table:
-        tab = table_mode(args, cfg, enc, (pool_ids, pool_mask, pool_len), rank, world, dev)
+        log("table mode")
+        tab, par_scale, held = table_mode(args, conf, cfg, encs, fuse_w, (pool_ids, pool_mask, pool_len), rank, world, dev,
+                                          scale_parity=not args.no_scale_parity)
         if rank == 0:
             result["table_mode"] = tab
+        if rank == 0 and par_scale is not None:
+            if K == 1:
+                log("at-scale parity on spread weights (std 0.05)")
+                w2 = make_plm_weights(cfg, seed=44, std=0.05)
+                enc2 = hip.HipEncoder(cfg, w2, precisions=("bf16", "fp32"), device=dev)
+                dimp, labels = held
+                tabs = {}
+                for prec in (args.precision if args.precision != "fp32" else "bf16", "fp32"):
+                    tabs[prec] = enc2.encode_cls(pool_ids, pool_mask, precision=prec, host_lengths=pool_len, max_chunk_tokens=args.chunk_tokens)
+                fast = [v for k_, v in tabs.items() if k_ != "fp32"][0]
+                s_fast = hip.score_late_fusion(fast, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+                s_32 = hip.score_late_fusion(tabs["fp32"], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+                par_scale["spread_weights_std0.05"] = ranking_agreement(s_fast, s_32, labels, dimp["cand_off"])
+                enc2.close()
+                del tabs, fast
+            result["parity_at_scale"] = par_scale
+            # the parity mode's own throughput, in the driver-run line
+            result["parity_mode"] = {"dtype": "fp32", "news_encoded_per_s": par_scale["parity_mode_news_per_s"],
+                                     "what": "HIP f32-MFMA mode (<= 2e-5 from the reference on the goldens), table-mode encode of the pool"}
+        del held
+    if rank == 0 and world == 1 and not args.no_small_ops:
+        log("small-kernel legs (pooler, dot, z-score, to_dense)")
+        result["small_ops"] = small_ops_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu:
         log("CPU baseline (oracle) + parity on the bounded sample")
-        cpu, par = cpu_baseline_and_parity(args, cfg, weights, enc, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev)
+        nb = max(2, args.cpu_impressions // K)
+        cpu, par = cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
         result["cpu_baseline"] = cpu
         result["parity"] = par
-        # the same check on "trained-like" weights (matrices ~N(0, 0.05^2)): with HF-init weights the CLS
-        # vectors of different news are almost collinear, so bf16 rounding reorders near-tied scores
-        log("parity on spread weights (std 0.05)")
-        w2 = make_plm_weights(cfg, seed=44, std=0.05)
-        enc2 = hip.HipEncoder(cfg, w2, precisions=("bf16", "fp32"), device=dev)
-        _, par2 = cpu_baseline_and_parity(args, cfg, w2, enc2, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb=4)
-        enc2.close()
-        result["parity_spread_weights"] = par2
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -385,7 +385,7 @@ def dot(user: Tensor, cand: Tensor) -> Tensor:
 
 
 def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
-                      total_cand: Optional[int] = None) -> Tensor:
+                      total_cand: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
     """Ragged scores [sum c_i] of impressions given as CSR index lists into ``table`` [n, D]."""
     table = _dev(table, torch.float32, "table").contiguous()
     hist_idx, cand_idx = _dev(hist_idx, torch.int32, "hist_idx"), _dev(cand_idx, torch.int32, "cand_idx")
@@ -393,7 +393,11 @@ def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_id
     nb = hist_off.numel() - 1
     assert cand_off.numel() == nb + 1
     total = int(cand_idx.numel()) if total_cand is None else total_cand
-    out = torch.empty((total,), dtype=torch.float32, device=table.device)
+    if out is None:
+        out = torch.empty((total,), dtype=torch.float32, device=table.device)
+    else:
+        _dev(out, torch.float32, "out")
+        assert out.is_contiguous() and out.numel() == total
     # bind the contiguous copies to locals: a temporary's storage could be handed to the next temporary
     # before the kernel has read it
     hist_idx, hist_off, cand_idx, cand_off = (hist_idx.contiguous(), hist_off.contiguous(), cand_idx.contiguous(),
@@ -449,7 +453,9 @@ def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor, with
     """planes [K, total] (module 0 = CR); weights of modules 1..K-1 -> fused ragged scores [total].  With
     ``with_pad_value`` also the per-impression value [B] that the reference's dense matrix holds in padded slots
     (its z-score runs over the zero-padded row, ensemble_module.py:145-149)."""
-    planes = _dev(planes, torch.float32, "scores").contiguous()
+    planes = _dev(planes, torch.float32, "scores")
+    if planes.dim() != 2 or planes.stride(1) != 1:
+        planes = planes.contiguous()               # planes may be row views of a wider buffer (stride(0) > total)
     cand_off = _dev(cand_off, torch.int64, "cand_off").contiguous()
     k, total = planes.shape
     assert len(weights) == k - 1
@@ -457,8 +463,8 @@ def zscore_fuse(planes: Tensor, weights: Sequence[float], cand_off: Tensor, with
     out = torch.empty((total,), dtype=torch.float32, device=planes.device)
     pad = torch.empty((cand_off.numel() - 1,), dtype=torch.float32, device=planes.device) if with_pad_value else None
     with torch.cuda.device(planes.device):
-        _lib.check(_lib.load().manner_hip_zscore_fuse(_ptr(planes), total, k, w, _ptr(cand_off), cand_off.numel() - 1,
-                                                      _ptr(out), _ptr(pad), _stream()))
+        _lib.check(_lib.load().manner_hip_zscore_fuse(_ptr(planes), planes.stride(0) if k > 1 else total, k, w, _ptr(cand_off),
+                                                      cand_off.numel() - 1, _ptr(out), _ptr(pad), _stream()))
     return (out, pad) if with_pad_value else out
 
 
