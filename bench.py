@@ -332,6 +332,8 @@ def small_ops_leg(dev, B=4096, S=50, D=768, Q=200, C=37):
                           "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS,
                           "note": "124 B per impression and plane on average: latency-bound wave-per-impression work"}
     nb = 8192
+    while nb > 256 and int(imp["cand_off"][nb]) > cand.numel() // D:
+        nb //= 2
     cvec = cand.reshape(-1, D)[: int(imp["cand_off"][nb])].contiguous() if cand.numel() // D >= int(imp["cand_off"][nb]) else None
     if cvec is not None:
         off8 = off[: nb + 1].contiguous()

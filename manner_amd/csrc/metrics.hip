@@ -16,14 +16,16 @@
 namespace manner {
 namespace {
 
-constexpr int RS_ITEMS = 8;                        // keys per lane
-constexpr int RS_TILE = 256 * RS_ITEMS;            // keys per workgroup (4 waves x 64 lanes x 8 rounds)
+constexpr int RS_ITEMS = 16;                       // keys per lane
+constexpr int RS_TILE = 256 * RS_ITEMS;
+constexpr int SCAN_SEG = 256 * 16;                 // entries per workgroup of the two-level histogram scan            // keys per workgroup (4 waves x 64 lanes x 8 rounds)
 
 struct AucWs {            // carved from the caller's workspace
   uint32_t* neg_a;        // negatives' keys (ping)
   uint32_t* neg_b;        // (pong)
   uint32_t* pos;          // positives' keys
   uint32_t* hist;         // [256][blocks] digit counts of one pass
+  uint32_t* seg;          // per-segment totals of the two-level scan
   uint32_t* scalars;      // [0] outside-[0,1] flag, [1] #negatives, [2] #positives
   unsigned long long* acc;   // [0] 2U
 };
@@ -41,9 +43,10 @@ size_t carve(int64_t n, char* base, AucWs* w) {
   const size_t vec = (size_t)n * sizeof(uint32_t);
   char* a = take(vec); char* b = take(vec); char* p = take(vec);
   char* h = take((size_t)256 * rs_blocks(n) * sizeof(uint32_t));
+  char* sg = take((size_t)(256 * rs_blocks(n) / SCAN_SEG + 1) * sizeof(uint32_t));
   char* sc = take(64); char* ac = take(64);
   if (w) {
-    w->neg_a = (uint32_t*)a; w->neg_b = (uint32_t*)b; w->pos = (uint32_t*)p; w->hist = (uint32_t*)h;
+    w->neg_a = (uint32_t*)a; w->neg_b = (uint32_t*)b; w->pos = (uint32_t*)p; w->hist = (uint32_t*)h; w->seg = (uint32_t*)sg;
     w->scalars = (uint32_t*)sc; w->acc = (unsigned long long*)ac;
   }
   return off;
@@ -113,26 +116,69 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict
   hist[(size_t)threadIdx.x * blocks + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. len) in place (digit-major, so the result is each (digit, block)'s first output slot)
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int64_t len) {
-  __shared__ uint32_t part[1024];
+// exclusive scan of hist[0 .. len) in place (digit-major, so the result is each (digit, block)'s first output slot),
+// two levels: per-segment totals (SCAN_SEG entries per workgroup) -> one workgroup scans the totals -> every workgroup
+// rescans its segment from its base.  A thread owns 16 consecutive entries.
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sm /*[256]*/, uint32_t* total) {
   const int t = threadIdx.x;
-  const int64_t per = (len + 1023) / 1024, lo = t * per, hi = min(len, lo + per);
-  uint32_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += hist[i];
-  part[t] = s;
+  sm[t] = v;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const uint32_t v = t >= o ? part[t - o] : 0;
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t a = t >= o ? sm[t - o] : 0;
     __syncthreads();
-    part[t] += v;
+    sm[t] += a;
     __syncthreads();
   }
-  uint32_t run = part[t] - s;
-  for (int64_t i = lo; i < hi; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
+  if (total) *total = sm[255];
+  return sm[t] - v;
 }
 
-// stable scatter.  Wave w of a workgroup owns the contiguous keys [base + w*512, +512) in 8 rounds of 64; the order
+__global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t* __restrict__ hist, int64_t len,
+                                                            uint32_t* __restrict__ seg) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_SEG + threadIdx.x * 16;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) if (base + i < len) s += hist[base + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ uint32_t part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) seg[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void rs_scan_segs_kernel(uint32_t* __restrict__ seg, int n_seg) {
+  __shared__ uint32_t sm[256];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < n_seg; s0 += 256) {
+    const int i = s0 + threadIdx.x;
+    const uint32_t v = i < n_seg ? seg[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan_256(v, sm, &tot);
+    const uint32_t c = carry;
+    if (i < n_seg) seg[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void rs_scan_apply_kernel(uint32_t* __restrict__ hist, int64_t len,
+                                                           const uint32_t* __restrict__ seg) {
+  __shared__ uint32_t sm[256];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_SEG + threadIdx.x * 16;
+  uint32_t v[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = base + i < len ? hist[base + i] : 0; s += v[i]; }
+  uint32_t run = seg[blockIdx.x] + block_exclusive_scan_256(s, sm, nullptr);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { if (base + i < len) hist[base + i] = run; run += v[i]; }
+}
+
+// stable scatter.  Wave w of a workgroup owns the contiguous keys [base + w*1024, +1024) in 16 rounds of 64; the order
 // (wave, round, lane) is the input order, so ranking in that order keeps the pass stable.
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                         const uint32_t* __restrict__ count, int shift,
@@ -268,10 +314,14 @@ int manner_hip_auc(const float* scores, const float* labels, int64_t n, int32_t 
                      w.neg_a, w.pos);
   MANNER_LAUNCH_CHECK();
   const int blocks = (int)rs_blocks(n);
+  const int64_t hist_len = (int64_t)256 * blocks;
+  const int n_seg = (int)((hist_len + SCAN_SEG - 1) / SCAN_SEG);
   uint32_t *src = w.neg_a, *dst = w.neg_b;
   for (int shift = 0; shift < 32; shift += 8) {
     hipLaunchKernelGGL(rs_hist_kernel, dim3(blocks), dim3(256), 0, stream, src, w.scalars + 1, shift, w.hist, blocks);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, stream, w.hist, (int64_t)256 * blocks);
+    hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(n_seg), dim3(256), 0, stream, w.hist, hist_len, w.seg);
+    hipLaunchKernelGGL(rs_scan_segs_kernel, dim3(1), dim3(256), 0, stream, w.seg, n_seg);
+    hipLaunchKernelGGL(rs_scan_apply_kernel, dim3(n_seg), dim3(256), 0, stream, w.hist, hist_len, w.seg);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, w.scalars + 1, shift, w.hist, blocks);
     MANNER_LAUNCH_CHECK();
     uint32_t* t = src; src = dst; dst = t;

@@ -445,7 +445,7 @@ def test_ensemble_forward_matches_oracle(weights):
     out2 = hotpath.ensemble_forward([lambda idx, t=t: _cuda(t[idx]) for t in tabs], fake, weights).cpu().numpy()
     assert np.isnan(out2[1]).all() and rel(out2, ref2) < 2e-5
     pad = np.arange(11)[None, :] >= np.asarray(cand_sizes)[:, None]
-    assert pad.sum() > 0 and np.abs(ref2[pad & ok]).min() > 1e-3            # the padded slots are NOT zero in the reference
+    assert pad.sum() > 0 and np.median(np.abs(ref2[pad & ok])) > 0.05       # the padded slots are NOT zero in the reference
     # ragged output = the valid slots of the dense one
     rag = hotpath.ensemble_forward([wrap(0), wrap(1), wrap(2)], batch, weights, dense=False).cpu().numpy()
     assert np.array_equal(rag, out[~pad], equal_nan=True)
