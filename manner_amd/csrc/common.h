@@ -106,6 +106,7 @@ int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const 
 // bf16x3: out [rows, 3K] bf16 = [hi | hi | lo] of x [rows, K] f32 (activations) or [hi | lo | hi] (weights); rows >= *m_total skipped
 int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream);
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
+int set_device_int(int32_t* p, int32_t value, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);
 int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);

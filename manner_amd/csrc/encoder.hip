@@ -124,7 +124,14 @@ struct Workspace {
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
   void *mr_in, *mr_mid, *part;       // deferred LayerNorm: {mean, rstd} per row (layer input / after attention), partial sums
   void* a3;                          // BF16X3: split copy [M, 3*max(H, I)] bf16 of the current GEMM's f32 A operand
+  // last layer, [CLS] rows only: the rows of several chunks are collected (acc_*) and the tail of the layer — output
+  // projection, LayerNorm, FFN, LayerNorm — runs ONCE over them (run_cls_tail) instead of as 5 small launches per chunk
+  void *acc_x, *acc_ctx, *acc_x1;    // [cls_cap + 256, H]: layer input (normalised) / attention output / LN1 output of the [CLS] rows
+  int32_t* cls_total;                // device scalar: rows collected
+  int64_t cls_cap;
 };
+
+constexpr int64_t CLS_CAP = 16384;   // [CLS] rows collected per stream before the tail runs (bounded by the chunk capacity)
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
   const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
@@ -148,6 +155,12 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   p = take((size_t)m_cap * 8); if (ws) ws->mr_mid = p;
   p = take((size_t)m_cap * (H / 64) * 8); if (ws) ws->part = p;
   if (prec == MANNER_HIP_PREC_BF16X3) { p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p; }
+  const int64_t cls_cap = m_cap < CLS_CAP ? m_cap : CLS_CAP;     // the tail borrows pre / ffn (m_cap rows) as scratch
+  if (ws) ws->cls_cap = cls_cap;
+  p = take((size_t)(cls_cap + 256) * H * es); if (ws) ws->acc_x = p;
+  p = take((size_t)(cls_cap + 256) * H * es); if (ws) ws->acc_ctx = p;
+  p = take((size_t)(cls_cap + 256) * H * es); if (ws) ws->acc_x1 = p;
+  p = take(256); if (ws) ws->cls_total = (int32_t*)p;
   return off;
 }
 
@@ -162,9 +175,11 @@ struct PhaseGuard {
   ~PhaseGuard() { mark(); }
 };
 
+// [CLS] path: `cls_off` = rows already collected in ws.acc_* — this chunk's n_news rows are appended there and `out` is
+// not written (run_cls_tail does, for all collected rows at once).
 int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t lp,
                  int64_t m_bound, int64_t expect_tokens, int prec, void* out, const Workspace& ws, hipStream_t s,
-                 hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32) {
+                 hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32, int64_t cls_off = 0) {
   PhaseGuard phase{phase_mark, s};
   const manner_hip_encoder_config& c = e->cfg;
   const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;   // activation dtype (BF16X3 keeps f32 activations)
@@ -194,14 +209,11 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
         const int32_t* n_total = ws.m_total + 1;
         const char* wkv = static_cast<const char*>(w.wqkv_f) + (size_t)H * H * 2;
         PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, wkv, p.cq2 + H, p.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
-        PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ws.xcls, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total, s))
-        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, static_cast<float*>(out), n_bound, n_total, s))
+        char* ax = static_cast<char*>(ws.acc_x) + (size_t)cls_off * H * es;
+        char* actx = static_cast<char*>(ws.acc_ctx) + (size_t)cls_off * H * es;
+        PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ax, s))
+        PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ax, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
+        PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, actx, ws.cu, n_news, c.heads, H, s))
         break;
       }
       PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, w.wqkv_f, p.cq2, p.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
@@ -264,15 +276,40 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     const int32_t* n_total = ws.m_total + 1;
     const char* wkv = static_cast<const char*>(w.wqkv) + (size_t)H * (x3 ? (size_t)3 * H * 2 : (size_t)H * es);
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total))
-    PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_rows(dt, ws.x, ws.cu, n_news, H, ws.xcls, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS, ws.xcls, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total))
-    PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.ctx, w.wo, p.bo, ws.xcls, ws.pre, n_bound, H, H, n_total))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.qcls, n_bound, n_total, s))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS_GELU, ws.qcls, w.w1, p.b1, nullptr, ws.ffn, n_bound, I, H, n_total))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.qcls, ws.pre, n_bound, H, I, n_total))
-    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, static_cast<float*>(out), n_bound, n_total, s))
+    char* ax = static_cast<char*>(ws.acc_x) + (size_t)cls_off * H * es;
+    char* actx = static_cast<char*>(ws.acc_ctx) + (size_t)cls_off * H * es;
+    PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_rows(dt, ws.x, ws.cu, n_news, H, ax, s))
+    PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS, ax, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total))
+    PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, actx, ws.cu, n_news, c.heads, H, s))
   }
+  return MANNER_HIP_OK;
+}
+
+// Tail of the last layer over the `rows` [CLS] rows collected in ws.acc_* (K4-K6 on one row per news, then the CLS slice
+// K7 is the result itself): pre = ctx Wo^T + b + x; x1 = LN(pre); pre = gelu(x1 W1^T + b) W2^T + b + x1; out = LN(pre).
+// Scratch: ws.pre / ws.ffn of the (finished) chunk.  `out` receives f32 [rows, H].
+int run_cls_tail(manner_hip_encoder* e, int prec, const Workspace& ws, int64_t rows, float* out, hipStream_t s) {
+  if (rows <= 0) return MANNER_HIP_OK;
+  const manner_hip_encoder_config& c = e->cfg;
+  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
+  const int H = c.hidden, I = c.intermediate;
+  const bool x3 = prec == MANNER_HIP_PREC_BF16X3;
+  const LayerWeights& w = e->w[prec][c.layers - 1];
+  const LayerParams& p = e->params[c.layers - 1];
+  const int64_t bound = round_up(rows, 256);
+  int rc;
+  if ((rc = set_device_int(ws.cls_total, (int32_t)rows, s))) return rc;
+  auto gemm = [&](DType out_dt, Epilogue epi, const void* A, const void* Wm, const float* bias, const void* res, void* Y, int N, int K) -> int {
+    if (!x3) return gemm_tn(dt, out_dt, epi, A, Wm, bias, res, Y, bound, N, K, ws.cls_total, s);
+    int r = split3_rows(false, static_cast<const float*>(A), ws.a3, K, bound, ws.cls_total, s);
+    if (r) return r;
+    return gemm_tn(DT_BF16, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, bound, N, 3 * K, ws.cls_total, s);
+  };
+  PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.acc_ctx, w.wo, p.bo, ws.acc_x, ws.pre, H, H))
+  PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.acc_x1, bound, ws.cls_total, s))
+  PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(dt, EPI_BIAS_GELU, ws.acc_x1, w.w1, p.b1, nullptr, ws.ffn, I, H))
+  PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.ffn, w.w2, p.b2, ws.acc_x1, ws.pre, H, I))
+  PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(DT_F32, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, out, bound, ws.cls_total, s))
   return MANNER_HIP_OK;
 }
 
@@ -472,18 +509,18 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
     forked = 0;
     return MANNER_HIP_OK;
   };
-  int64_t n0 = 0;
-  int chunk = 0;
-  while (n0 < n_news) {
+  // ---- plan: chunk boundaries (host arithmetic only), then CONTIGUOUS runs of chunks per stream, so that the [CLS] rows
+  // a stream collects for its batched last-layer tail are consecutive rows of `out`
+  struct Chunk { int64_t n0, cnt, m_bound, expect; };
+  std::vector<Chunk> plan;
+  for (int64_t n0 = 0; n0 < n_news;) {
     int64_t cnt = 0, m_bound, expect = -1;
     if (host_lengths) {
       int64_t tok = 0;
       while (n0 + cnt < n_news && cnt < n_cap) {
         const int64_t len = host_lengths[n0 + cnt];
-        if (len < 1 || len > padded_len) {
-          (void)join();
+        if (len < 1 || len > padded_len)
           return fail(MANNER_HIP_E_INVALID, "encode_cls: host_lengths[%lld]=%lld outside [1, padded_len]", (long long)(n0 + cnt), (long long)len);
-        }
         if (tok + len > m_cap) break;
         tok += len;
         ++cnt;
@@ -496,25 +533,55 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
       if (cnt > n_news - n0) cnt = n_news - n0;
       m_bound = round_up(cnt * padded_len, 256);
     }
-    const int lane = chunk % ns;
-    hipStream_t s = lane == 0 ? s0 : enc->side[lane];
-    if (lane > 0 && chunk < ns) {
-      // stream `lane` starts when the first chunk of stream lane-1 is half a layer in (its phase mark): from
-      // then on the streams run out of phase, so the HBM-bound kernels of one (LayerNorm, attention, GEMM
-      // epilogues) meet the MFMA-bound main loops of another
-      if (hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0) != hipSuccess) {
-        (void)join();
-        return fail(MANNER_HIP_E_RUNTIME, "encode_cls: hipStreamWaitEvent failed");
-      }
-      forked = lane;
-    }
-    const size_t news_bytes = hidden_layers < 0 ? (size_t)H * 4 : (size_t)padded_len * H * (hidden_dt == DT_F32 ? 4 : 2);
-    int rc = encode_chunk(enc, ids + n0 * padded_len, mask + n0 * padded_len, cnt, padded_len, m_bound, expect, precision,
-                          static_cast<char*>(out) + n0 * news_bytes, ws[lane], s,
-                          (ns > 1 && chunk < ns - 1) ? enc->phase_ev[lane] : nullptr, hidden_layers, hidden_dt);
-    if (rc) { (void)join(); return rc; }
+    plan.push_back({n0, cnt, m_bound, expect});
     n0 += cnt;
-    ++chunk;
+  }
+  const int n_chunks = (int)plan.size();
+  const int lanes = n_chunks < ns ? n_chunks : ns;
+  int first[manner_hip_encoder::MAX_STREAMS + 1];                 // lane l runs chunks [first[l], first[l+1])
+  for (int l = 0; l <= lanes; ++l) first[l] = (int)((int64_t)n_chunks * l / lanes);
+  int next[manner_hip_encoder::MAX_STREAMS];
+  int64_t acc_rows[manner_hip_encoder::MAX_STREAMS] = {}, acc_first[manner_hip_encoder::MAX_STREAMS] = {};
+  for (int l = 0; l < lanes; ++l) next[l] = first[l];
+  const bool cls = hidden_layers < 0;
+  const size_t news_bytes = cls ? (size_t)H * 4 : (size_t)padded_len * H * (hidden_dt == DT_F32 ? 4 : 2);
+  auto flush = [&](int lane, hipStream_t s) -> int {              // the batched tail over the rows this lane has collected
+    if (!cls || acc_rows[lane] == 0) return MANNER_HIP_OK;
+    int rc = run_cls_tail(enc, precision, ws[lane], acc_rows[lane], static_cast<float*>(out) + acc_first[lane] * H, s);
+    acc_rows[lane] = 0;
+    return rc;
+  };
+  // chunks are enqueued round-robin over the lanes so that every stream always has work queued
+  for (int left = n_chunks; left > 0;) {
+    for (int lane = 0; lane < lanes; ++lane) {
+      if (next[lane] >= first[lane + 1]) continue;
+      const Chunk& ck = plan[next[lane]];
+      const bool lane_first = next[lane] == first[lane];
+      hipStream_t s = lane == 0 ? s0 : enc->side[lane];
+      if (lane > 0 && lane_first) {
+        // stream `lane` starts when the first chunk of stream lane-1 is half a layer in (its phase mark): from
+        // then on the streams run out of phase, so the HBM-bound kernels of one (attention, GEMM epilogues) meet
+        // the MFMA-bound main loops of another
+        if (hipStreamWaitEvent(s, enc->phase_ev[lane - 1], 0) != hipSuccess) {
+          (void)join();
+          return fail(MANNER_HIP_E_RUNTIME, "encode_cls: hipStreamWaitEvent failed");
+        }
+        forked = lane;
+      }
+      int rc = MANNER_HIP_OK;
+      if (cls && acc_rows[lane] + ck.cnt > ws[lane].cls_cap) rc = flush(lane, s);
+      if (cls && acc_rows[lane] == 0) acc_first[lane] = ck.n0;
+      if (!rc)
+        rc = encode_chunk(enc, ids + ck.n0 * padded_len, mask + ck.n0 * padded_len, ck.cnt, padded_len, ck.m_bound, ck.expect,
+                          precision, static_cast<char*>(out) + ck.n0 * news_bytes, ws[lane], s,
+                          (lane_first && lane + 1 < lanes) ? enc->phase_ev[lane] : nullptr, hidden_layers, hidden_dt,
+                          acc_rows[lane]);
+      if (rc) { (void)join(); return rc; }
+      if (cls) acc_rows[lane] += ck.cnt;
+      ++next[lane];
+      --left;
+      if (next[lane] == first[lane + 1] && (rc = flush(lane, s))) { (void)join(); return rc; }
+    }
   }
   return join();
 }

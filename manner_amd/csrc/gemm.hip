@@ -1091,6 +1091,9 @@ int device_cus() {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
     n_cus = v > 0 ? v : 256;
+    // A/B switch: persistent GEMM grids of fewer workgroups than CUs, so that two streams' GEMMs run side by side on
+    // disjoint CUs (measured: -3 % — kept for re-measurement only)
+    if (const char* ev = getenv("MANNER_HIP_GEMM_CUS")) { const int c = atoi(ev); if (c > 0 && c < n_cus) n_cus = c; }
   }
   return n_cus;
 }

@@ -429,6 +429,14 @@ int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, con
   return MANNER_HIP_OK;
 }
 
+__global__ void set_int_kernel(int32_t* p, int32_t v) { *p = v; }
+
+int set_device_int(int32_t* p, int32_t value, hipStream_t stream) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, stream, p, value);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
   MANNER_LAUNCH_CHECK();
