@@ -454,11 +454,11 @@ __global__ __launch_bounds__(512, 1) void pool_logits_kernel(const float* __rest
   const int64_t row_base = is_w ? 0 : mt * G_BM, row_last = (is_w ? (int64_t)Q : R) - 1;
   const int ldst0 = (is_w ? 0 : G_OP_BYTES) + prow0 * ROW_BYTES;
   const int lrow = lane >> 3;
-  size_t poff[8];                                                       // element offset of this lane's 16 bytes in piece i
+  uint32_t poff[8];                              // element offset of this lane's 16 bytes in piece i (R * K < 2^31: launcher)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t row = min(row_base + prow0 + 8 * i + lrow, row_last);
-    poff[i] = (size_t)row * K + (((lane & 7) ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * EPC);
+    poff[i] = (uint32_t)(row * K) + (((lane & 7) ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * EPC);
   }
   auto issue2 = [&](int buf, int k0, int pair) {
     char* base = lds + buf * G_STAGE_BYTES + ldst0;
@@ -546,7 +546,13 @@ __global__ __launch_bounds__(512, 1) void pool_logits_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p[j] += tanhf(acc[i][j][4 * g + e] + bv[e]) * qv[e];
+        for (int e = 0; e < 4; ++e) {
+          // tanh(z) = 1 - 2 / (exp(2z) + 1) on the hardware exp / rcp (|z| clamped: tanh(+-15) is +-1 in f32);
+          // absolute error ~1e-7, far inside the 1e-4 bar of the pooled vectors
+          const float z = fminf(fmaxf(acc[i][j][4 * g + e] + bv[e], -15.f), 15.f);
+          const float t = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * z) + 1.0f);
+          p[j] = fmaf(t, qv[e], p[j]);
+        }
     }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1103,10 +1109,14 @@ int pool_logits_mfma(const float* x, const float* W, const float* bias, const fl
   if (R <= 0) return MANNER_HIP_OK;
   if (D % 32 || D < 32 || Q < 1 || Q > G_BN || (uintptr_t)x % 16 || (uintptr_t)W % 16)
     return fail(MANNER_HIP_E_INVALID, "pool_logits_mfma: D=%d Q=%d unsupported (D %% 32 == 0, Q <= 256, 16-byte aligned rows)", D, Q);
-  const int64_t tiles = (R + G_BM - 1) / G_BM;
-  if (tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "pool_logits_mfma: too many rows");
-  hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)tiles), dim3(512), 0, stream, x, W, bias, query, R, D, Q, logits);
-  MANNER_LAUNCH_CHECK();
+  // 32-bit element offsets inside the kernel: rows are processed in slices of fewer than 2^31 / D
+  const int64_t slice = ((int64_t)0x7fffffff / D) / G_BM * G_BM;
+  for (int64_t r0 = 0; r0 < R; r0 += slice) {
+    const int64_t rows = R - r0 < slice ? R - r0 : slice;
+    hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)((rows + G_BM - 1) / G_BM)), dim3(512), 0, stream, x + r0 * D, W, bias,
+                       query, rows, D, Q, logits + r0);
+    MANNER_LAUNCH_CHECK();
+  }
   return MANNER_HIP_OK;
 }
 
