@@ -54,8 +54,11 @@ enum { MANNER_HIP_ARCH_BERT = 0, MANNER_HIP_ARCH_ROBERTA = 1 };
  * BF16X3: f32 activations and f32 attention / LayerNorm / erf-GeLU as in F32, but every GEMM runs on the bf16 MFMA
  * over split operands — x = hi + lo, W = hi + lo (bf16 each), x W^T ~ hi.hi + hi.lo + lo.hi as ONE bf16 GEMM of
  * depth 3K: 16-bit operand mantissas, f32 accumulation.  2.3x the F32 mode's speed at 3e-5 .. 1.1e-4 of the reference
- * (stated tolerance 2.5e-4; F32 remains THE 1e-4 parity mode).  Needs H and I multiples of 256. */
-enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1, MANNER_HIP_PREC_BF16X3 = 2 };
+ * (stated tolerance 2.5e-4; F32 remains THE 1e-4 parity mode).  Needs H and I multiples of 256.
+ * F16: the BF16 schedule and kernels on IEEE half operands (v_mfma_f32_*_f16: same rate, same bytes): 11 mantissa
+ * bits instead of 8 (~8x smaller error), f16's exponent range (max 65504) — the arithmetic the reference's own GPU
+ * setting computes in (`precision: 16-mixed`, configs/trainer/default.yaml:12). */
+enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1, MANNER_HIP_PREC_BF16X3 = 2, MANNER_HIP_PREC_F16 = 3 };
 
 typedef void* manner_hip_stream_t;
 typedef struct manner_hip_encoder* manner_hip_encoder_t;

@@ -29,15 +29,17 @@
 namespace manner {
 namespace {
 
-template <int NKT>
-__device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <typename TE, int NKT>
+__device__ __forceinline__ void attn_wave_bf16(const TE* __restrict__ qkv, TE* __restrict__ ctx,
                                                int tok0, int L, int H, int head, char* vl) {
+  typedef typename E16<TE>::v8 e16x8;           // TE: bf16_t or f16_t — same layout, the MFMA of the type
+  typedef typename E16<TE>::v4 e16x4;
   const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
   char* ol = vl + NKT * 32 * 128;                 // output slab behind the V image
   const size_t ld = 3 * (size_t)H;
-  const bf16_t* Qb = qkv + (size_t)tok0 * ld + head * 64;
-  const bf16_t* Kb = Qb + H;
-  const bf16_t* Vb = Qb + 2 * H;
+  const TE* Qb = qkv + (size_t)tok0 * ld + head * 64;
+  const TE* Kb = Qb + H;
+  const TE* Vb = Qb + 2 * H;
 
   // Every global access is a 16-byte piece of a whole 128-byte row segment (lane = (row lane>>3, chunk lane&7));
   // the MFMA-layout fragments are then read back from LDS.  Loads straight in the fragment layout touch each row in
@@ -70,7 +72,7 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
   load_q(0);
   // K: one 32-key tile at a time through the 4 KiB slab, chunk-swizzled -> fragments: lane (rr, h) holds
   // K[key = 32kt + rr][d = 16ks + 8h .. +7], i.e. chunk 2ks + h of row rr
-  bf16x8 kf[NKT][4];
+  e16x8 kf[NKT][4];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -78,7 +80,7 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      kf[kt][ks] = *reinterpret_cast<const bf16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
+      kf[kt][ks] = *reinterpret_cast<const e16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -92,13 +94,13 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
     if (32 * qb >= L) break;
     // Q block: rows -> output slab (free between blocks), chunk-swizzled -> fragments; the next block's rows are
     // requested before this block's arithmetic starts
-    bf16x8 qfb[4];
+    e16x8 qfb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ol + (8 * i + r8) * 128 + (c8 << 4)) = qt_[i];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qfb[ks] = *reinterpret_cast<const bf16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
+      qfb[ks] = *reinterpret_cast<const e16x8*>(ol + rr * 128 + (((2 * ks + h) ^ ((rr >> 1) & 7)) << 4));
     __builtin_amdgcn_wave_barrier();
     if (qb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the V image (LDS-DMA is not tracked by the compiler)
     if (qb + 1 < NKT && 32 * (qb + 1) < L) load_q(qb + 1);
@@ -119,7 +121,7 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qfb[ks], st, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) st = E16<TE>::mfma32(kf[kt][ks], qfb[ks], st);
       if (kt == NKT - 1) {                             // L > 32 (NKT - 1): earlier tiles hold real keys only
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -133,11 +135,11 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
       const float mn = fmaxf(m, tmx);                  // finite: tile 0 always holds key 0 < L
       const float nmc = -mn * C;
       float rs = 0.f;
-      bf16x8 pf[2];
+      e16x8 pf[2];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float p = __builtin_amdgcn_exp2f(fmaf(st[e], C, nmc));   // exp((s - max) / 8); 0 for masked keys
-        pf[e >> 3][e & 7] = (bf16_t)p;
+        pf[e >> 3][e & 7] = (TE)p;
         rs += p;
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -163,8 +165,8 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * 128));
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[dt], 0, 0, 0);
+          const e16x8 vf = __builtin_bit_cast(e16x8, both);
+          o[dt] = E16<TE>::mfma32(vf, pf[s2], o[dt]);
         }
       }
     }
@@ -178,9 +180,9 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = 4 * dt + g;
-          *reinterpret_cast<bf16x4*>(ol + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4) + 8 * h) =
-              bf16x4{(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv),
-                     (bf16_t)(o[dt][4 * g + 2] * inv), (bf16_t)(o[dt][4 * g + 3] * inv)};
+          *reinterpret_cast<e16x4*>(ol + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4) + 8 * h) =
+              e16x4{(TE)(o[dt][4 * g] * inv), (TE)(o[dt][4 * g + 1] * inv),
+                     (TE)(o[dt][4 * g + 2] * inv), (TE)(o[dt][4 * g + 3] * inv)};
         }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -195,7 +197,8 @@ __device__ __forceinline__ void attn_wave_bf16(const bf16_t* __restrict__ qkv, b
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <typename TE>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const TE* __restrict__ qkv, TE* __restrict__ ctx,
                                                            const int32_t* __restrict__ cu, int64_t n_pairs,
                                                            int heads, int H, int lds_per_wave) {
   extern __shared__ __attribute__((aligned(16))) char vlds[];
@@ -206,10 +209,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   const int tok0 = __builtin_amdgcn_readfirstlane(cu[n]);
   const int L = __builtin_amdgcn_readfirstlane(cu[n + 1]) - tok0;
   char* vl = vlds + wave * lds_per_wave;
-  if (L <= 32) attn_wave_bf16<1>(qkv, ctx, tok0, L, H, head, vl);
-  else if (L <= 64) attn_wave_bf16<2>(qkv, ctx, tok0, L, H, head, vl);
-  else if (L <= 96) attn_wave_bf16<3>(qkv, ctx, tok0, L, H, head, vl);
-  else attn_wave_bf16<4>(qkv, ctx, tok0, L, H, head, vl);
+  if (L <= 32) attn_wave_bf16<TE, 1>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 64) attn_wave_bf16<TE, 2>(qkv, ctx, tok0, L, H, head, vl);
+  else if (L <= 96) attn_wave_bf16<TE, 3>(qkv, ctx, tok0, L, H, head, vl);
+  else attn_wave_bf16<TE, 4>(qkv, ctx, tok0, L, H, head, vl);
 }
 
 // ---- exact-f32 attention on the f32 matrix pipe: the structure of attn_wave_bf16 with v_mfma_f32_32x32x2_f32 (exact f32
@@ -418,6 +421,19 @@ template <> struct Row8<bf16_t> {
     *reinterpret_cast<bf16x8*>(p) = t;
   }
 };
+template <> struct Row8<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float v[8]) {
+    const f16x8 t = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float v[8]) {
+    f16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (f16_t)v[e];
+    *reinterpret_cast<f16x8*>(p) = t;
+  }
+};
 template <> struct Row8<float> {
   static __device__ __forceinline__ void load(const float* p, float v[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -501,6 +517,9 @@ int attention_cls(DType dt, const void* qcls, const void* kv, void* ctx_cls, con
   if (dt == DT_BF16)
     hipLaunchKernelGGL(attn_cls_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(qcls), static_cast<const bf16_t*>(kv),
                        static_cast<bf16_t*>(ctx_cls), cu, pairs, heads, H);
+  else if (dt == DT_F16)
+    hipLaunchKernelGGL(attn_cls_kernel<f16_t>, g, b, 0, stream, static_cast<const f16_t*>(qcls), static_cast<const f16_t*>(kv),
+                       static_cast<f16_t*>(ctx_cls), cu, pairs, heads, H);
   else
     hipLaunchKernelGGL(attn_cls_kernel<float>, g, b, 0, stream, static_cast<const float*>(qcls), static_cast<const float*>(kv),
                        static_cast<float*>(ctx_cls), cu, pairs, heads, H);
@@ -514,17 +533,22 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
   if (max_len < 1 || max_len > MANNER_HIP_MAX_LEN)
     return fail(MANNER_HIP_E_INVALID, "padded length %d exceeds the %d-token attention tile", max_len, MANNER_HIP_MAX_LEN);
   const int64_t pairs = n_news * heads;
-  if (dt == DT_BF16) {
+  if (is_16bit(dt)) {
     const int nkt = (max_len + 31) / 32;
     const int lds_per_wave = nkt * 32 * 128 + 4096;   // V image + the 32-query output slab
     static bool lds_raised_dev[MAX_DEVICES] = {};     // 4 waves x 20 KiB exceeds the 64 KiB default of dynamic LDS
     bool& lds_raised = lds_raised_dev[current_device_slot()];   // the attribute is per device
     if (!lds_raised) {
-      MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 32 * 128 + 4096)));
+      MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 32 * 128 + 4096)));
+      MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 32 * 128 + 4096)));
       lds_raised = true;
     }
-    hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
-                       static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
+    if (dt == DT_F16)
+      hipLaunchKernelGGL(attn_bf16_kernel<f16_t>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
+                         static_cast<const f16_t*>(qkv), static_cast<f16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
+    else
+      hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 4 * lds_per_wave, stream,
+                         static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(ctx), cu, pairs, heads, H, lds_per_wave);
   } else {
     static const bool valu = getenv("MANNER_HIP_ATTN_F32_VALU") != nullptr;       // A/B switch: the older VALU kernel
     if (valu) {

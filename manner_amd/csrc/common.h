@@ -9,6 +9,9 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +53,24 @@ int device_cus();   // compute units of the current device (gemm.hip)
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5,
                 EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */ };
-enum DType { DT_F32 = 0, DT_BF16 = 1 };
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+static inline bool is_16bit(DType d) { return d != DT_F32; }
+
+// The two 16-bit element types of the MFMA encoder path (bf16: 8 mantissa bits, f32's exponent range; f16: 11 mantissa
+// bits, what the reference's own `precision: 16-mixed` autocast computes in): same size, same MFMA rate, same kernels.
+template <typename T> struct E16;
+template <> struct E16<bf16_t> {
+  typedef bf16x8 v8; typedef bf16x4 v4;
+  static constexpr DType dtype = DT_BF16;
+  static __device__ __forceinline__ f32x4 mfma16(const v8& a, const v8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct E16<f16_t> {
+  typedef f16x8 v8; typedef f16x4 v4;
+  static constexpr DType dtype = DT_F16;
+  static __device__ __forceinline__ f32x4 mfma16(const v8& a, const v8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // Y[m, n] = epi( sum_k X[m, k] * W[n, k] + bias[n] )  for m < *m_total (device scalar).
 // X [m_bound, K], W [N, K] row-major of dtype `in`; Y [m_bound, N] of dtype `out`;
@@ -60,13 +80,13 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
             hipStream_t stream);
 
-// Deferred-LayerNorm GEMMs (bf16 in/out, 256x256 tiles: N % 256 == 0, m_bound % 256 == 0, K >= 128).  The residual
+// Deferred-LayerNorm GEMMs (16-bit elements `dt` in/out, 256x256 tiles: N % 256 == 0, m_bound % 256 == 0, K >= 128).  The residual
 // stream holds pre-LayerNorm sums `raw` plus per-row {mean, rstd} (`mr`, float2 [m_bound]):
 //   EPI_NORM / EPI_NORM_GELU : Y = [gelu]( rstd * (X W'^T - mean * vec) + bias ),  X = raw, W' = gamma-folded weight,
 //                              vec = c1 (column sums of W'), bias = c2 (see fold_layernorm)
 //   EPI_NRES (in place on Y) : Y = X W^T + bias + ((Y - mean) * rstd) * vec,  vec = gamma, bias = b + beta;
 //                              also writes part[N/64][m_bound] = per-wave {sum, sum of squares} of the new rows.
-int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
+int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
 
 // K11 logits[r] = sum_j tanh(x[r] . W[j] + b[j]) q[j] on the f32 MFMA (D % 32 == 0, Q <= 256); x [R, D], W [Q, D]
@@ -88,17 +108,17 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
                    void* x, int64_t m_bound, const int* m_total, hipStream_t stream);
 // ---- deferred LayerNorm helpers (bf16 path)
 // raw[cu[n]+t] = bf16(word + type + pos) and mr = {mean, rstd} of the rounded row (K1 without the normalisation)
-int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
+int embed_raw(DType dt, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
               const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
               void* raw, void* mr, int32_t* status, hipStream_t stream);
 // mr[m] = {mean, rstd} from the `groups` partial sums part[g][m] of row m (fixed summation order)
 int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
                  hipStream_t stream);
 // dst[n] = bf16(LN(raw[cu[n]])) — the [CLS] rows of the last layer, normalised on the way
-int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
+int gather_cls_ln(DType dt, const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
                   const float* beta, void* dst, hipStream_t stream);
 // pack time: wf[n,k] = bf16(gamma[k] w[n,k]); c1[n] = sum_k wf[n,k]; c2[n] = bias[n] + sum_k beta[k] w[n,k]
-int fold_layernorm(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
+int fold_layernorm(DType dt, const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
                    float* c1, float* c2, hipStream_t stream);
 // out[n, t, :] = x[cu[n]+t] (normalised with mr/gamma/beta when mr != NULL) for t < len(n), zeros for padded positions
 int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const int32_t* cu, int64_t n_news, int64_t lp, int H,
@@ -109,7 +129,7 @@ int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s
 int set_device_int(int32_t* p, int32_t value, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream);
-int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);
+int convert_f32_to_16(DType dt, const float* src, void* dst, int64_t n, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 // ctx[tok, head*64 + d] = softmax_k(q.k/8) v over the tokens of the same news; qkv [m, 3H] = [Q|K|V].

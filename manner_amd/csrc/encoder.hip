@@ -8,7 +8,7 @@
 //             ctx = attention(qkv)        (per news, per head)
 //             pre = ctx Wo^T + b + x      (f32)         x = LN(pre)
 //             ffn = gelu(x W1^T + b)                    pre = ffn W2^T + b + x ; x = LN(pre)
-// Activations x/qkv/ctx/ffn are bf16 (MANNER_HIP_PREC_BF16) or f32 (MANNER_HIP_PREC_F32); LayerNorm statistics,
+// Activations x/qkv/ctx/ffn are bf16 / f16 (MANNER_HIP_PREC_BF16 / _F16) or f32 (MANNER_HIP_PREC_F32); LayerNorm statistics,
 // softmax and all accumulation are f32 in both modes.
 // bf16 with 256-tileable shapes runs the DEFERRED-LayerNorm schedule: no LayerNorm kernel and no f32 `pre`
 // round trip — the residual stream keeps the pre-LayerNorm sums (bf16) plus {mean, rstd} per row, the
@@ -39,13 +39,14 @@ struct LayerWeights {
   void* wo = nullptr;     // [H, H]
   void* w1 = nullptr;     // [I, H]
   void* w2 = nullptr;     // [H, I]
-  void* wqkv_f = nullptr; // bf16, deferred LayerNorm: gamma_in o Wqkv   (gamma_in: the LayerNorm feeding this layer)
-  void* w1_f = nullptr;   // bf16, deferred LayerNorm: ln1g o W1
+  void* wqkv_f = nullptr; // 16-bit modes, deferred LayerNorm: gamma_in o Wqkv   (gamma_in: the LayerNorm feeding this layer)
+  void* w1_f = nullptr;   // 16-bit modes, deferred LayerNorm: ln1g o W1
+  float *cq1 = nullptr, *cf1 = nullptr;   // column sums of the ROUNDED folded weights (they differ between bf16 and f16)
 };
 struct LayerParams {      // f32, shared by both precisions
   float *bqkv, *bo, *ln1g, *ln1b, *b1, *b2, *ln2g, *ln2b;
-  // deferred LayerNorm (see fold_layernorm): column sums / folded biases of wqkv_f and w1_f, residual biases
-  float *cq1 = nullptr, *cq2 = nullptr, *cf1 = nullptr, *cf2 = nullptr, *bo_res = nullptr, *b2_res = nullptr;
+  // deferred LayerNorm (see fold_layernorm): folded biases of wqkv_f and w1_f, residual biases
+  float *cq2 = nullptr, *cf2 = nullptr, *bo_res = nullptr, *b2_res = nullptr;
 };
 
 }  // namespace manner
@@ -55,7 +56,7 @@ struct manner_hip_encoder {
   uint32_t precisions = 0;
   float *word = nullptr, *pos = nullptr, *type0 = nullptr, *embg = nullptr, *embb = nullptr;
   std::vector<manner::LayerParams> params;
-  std::vector<manner::LayerWeights> w[3];   // [MANNER_HIP_PREC_*]; BF16X3: bf16 [out, 3*in] split weights
+  std::vector<manner::LayerWeights> w[4];   // [MANNER_HIP_PREC_*]; BF16X3: bf16 [out, 3*in] split weights
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
@@ -78,6 +79,10 @@ struct manner_hip_encoder {
 namespace manner {
 namespace {
 
+// activation dtype / element size of a precision mode (BF16X3 keeps f32 activations)
+inline DType act_dtype(int prec) { return prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_F32; }
+inline size_t act_bytes(int prec) { return (prec == MANNER_HIP_PREC_BF16 || prec == MANNER_HIP_PREC_F16) ? 2 : 4; }
+
 int dev_alloc(manner_hip_encoder* e, size_t bytes, void** out) {
   MANNER_HIP_TRY(hipMalloc(out, bytes));
   e->allocs.push_back(*out);
@@ -91,7 +96,8 @@ int dev_copy_f32(manner_hip_encoder* e, const float* src, size_t n, float** out,
 }
 // place rows of an f32 [rows, cols] matrix at dst (+row offset) in the precision's element type
 int pack_matrix(int prec, const float* src, size_t n, void* dst, size_t elem_off, hipStream_t s) {
-  if (prec == MANNER_HIP_PREC_BF16) return convert_f32_to_bf16(src, static_cast<bf16_t*>(dst) + elem_off, (int64_t)n, s);
+  if (prec == MANNER_HIP_PREC_BF16 || prec == MANNER_HIP_PREC_F16)
+    return convert_f32_to_16(prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_BF16, src, static_cast<char*>(dst) + elem_off * 2, (int64_t)n, s);
   MANNER_HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst) + elem_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return MANNER_HIP_OK;
 }
@@ -134,7 +140,7 @@ struct Workspace {
 constexpr int64_t CLS_CAP = 16384;   // [CLS] rows collected per stream before the tail runs (bounded by the chunk capacity)
 
 size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int prec, char* base, Workspace* ws) {
-  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  const size_t es = act_bytes(prec);
   const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
   size_t off = 0;
   if (ws) ws->a3 = nullptr;
@@ -182,7 +188,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
                  hipEvent_t phase_mark = nullptr, int hidden_layers = -1, DType hidden_dt = DT_F32, int64_t cls_off = 0) {
   PhaseGuard phase{phase_mark, s};
   const manner_hip_encoder_config& c = e->cfg;
-  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;   // activation dtype (BF16X3 keeps f32 activations)
+  const DType dt = act_dtype(prec);
   const int H = c.hidden, I = c.intermediate;
   int rc;
   {
@@ -191,10 +197,10 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
   }
   const int pos_offset = c.arch == MANNER_HIP_ARCH_ROBERTA ? c.pad_id + 1 : 0;
 #define PROF_STEP(cls, call) { ProfScope ps(e, s, cls); if ((rc = (call))) return rc; }
-  const size_t es = prec == MANNER_HIP_PREC_BF16 ? 2 : 4;
-  if (dt == DT_BF16 && e->defer_ln) {
+  const size_t es = act_bytes(prec);
+  if (is_16bit(dt) && e->defer_ln) {
     // ---- deferred-LayerNorm schedule: ws.x holds the pre-LayerNorm sums, mr_in / mr_mid their row statistics
-    PROF_STEP(MANNER_HIP_PROF_EMBED, embed_raw(ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, H, c.ln_eps, pos_offset,
+    PROF_STEP(MANNER_HIP_PROF_EMBED, embed_raw(dt, ids, n_news, lp, ws.cu, e->word, e->pos, e->type0, H, c.ln_eps, pos_offset,
                                                c.vocab, c.max_pos, ws.x, ws.mr_in, e->status, s))
     const int groups = H / 64;
     for (int l = 0; l < c.layers; ++l) {
@@ -208,21 +214,21 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
         const int64_t n_bound = round_up(n_news, 256);
         const int32_t* n_total = ws.m_total + 1;
         const char* wkv = static_cast<const char*>(w.wqkv_f) + (size_t)H * H * 2;
-        PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, wkv, p.cq2 + H, p.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
+        PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, wkv, p.cq2 + H, w.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
         char* ax = static_cast<char*>(ws.acc_x) + (size_t)cls_off * H * es;
         char* actx = static_cast<char*>(ws.acc_ctx) + (size_t)cls_off * H * es;
-        PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ax, s))
+        PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(dt, ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ax, s))
         PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm_tn(dt, dt, EPI_BIAS, ax, w.wqkv, p.bqkv, nullptr, ws.qcls, n_bound, H, H, n_total, s))
         PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, actx, ws.cu, n_news, c.heads, H, s))
         break;
       }
-      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(EPI_NORM, ws.x, w.wqkv_f, p.cq2, p.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, w.wqkv_f, p.cq2, w.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
       if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, p.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(dt, EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, w.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
     }
     if (hidden_layers >= 0) {   // the residual stream is still un-normalised: apply the LayerNorm that closes layer hidden_layers-1
@@ -291,7 +297,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
 int run_cls_tail(manner_hip_encoder* e, int prec, const Workspace& ws, int64_t rows, float* out, hipStream_t s) {
   if (rows <= 0) return MANNER_HIP_OK;
   const manner_hip_encoder_config& c = e->cfg;
-  const DType dt = prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : DT_F32;
+  const DType dt = act_dtype(prec);
   const int H = c.hidden, I = c.intermediate;
   const bool x3 = prec == MANNER_HIP_PREC_BF16X3;
   const LayerWeights& w = e->w[prec][c.layers - 1];
@@ -365,7 +371,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
   if (I <= 0 || I % 128 || L <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: intermediate=%d layers=%d unsupported", I, L);
   if (cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->type_vocab <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: bad table sizes");
   if (n_weights != MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT) return fail(MANNER_HIP_E_INVALID, "encoder_create: expected %d weight pointers, got %d", MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT, n_weights);
-  if (!(precisions & 7u) || (precisions & ~7u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
+  if (!(precisions & 15u) || (precisions & ~15u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
   if ((precisions & (1u << MANNER_HIP_PREC_BF16X3)) && (H % 256 || I % 256)) return fail(MANNER_HIP_E_INVALID, "encoder_create: BF16X3 needs hidden and intermediate sizes that are multiples of 256 (H=%d I=%d)", H, I);
   for (int i = 0; i < n_weights; ++i)
     if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "encoder_create: weight pointer %d is null", i);
@@ -390,7 +396,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
       e->n_streams = v < 1 ? 1 : (v > manner_hip_encoder::MAX_STREAMS ? manner_hip_encoder::MAX_STREAMS : v);
     }
     // deferred LayerNorm needs every full-size GEMM on the 256x256 kernel: H, 3H, 2H and I multiples of 256
-    e->defer_ln = (precisions & (1u << MANNER_HIP_PREC_BF16)) && H % 256 == 0 && I % 256 == 0;
+    e->defer_ln = (precisions & ((1u << MANNER_HIP_PREC_BF16) | (1u << MANNER_HIP_PREC_F16))) && H % 256 == 0 && I % 256 == 0;
     if (const char* ev = getenv("MANNER_HIP_DEFER_LN")) e->defer_ln = e->defer_ln && atoi(ev) != 0;
     for (int i = 0; i < e->n_streams && !rc; ++i) {
       if ((i > 0 && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) ||
@@ -400,7 +406,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     }
     if (rc) break;
     e->params.resize(L);
-    for (int p = 0; p < 3; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
+    for (int p = 0; p < 4; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
     for (int l = 0; l < L && !rc; ++l) {
       const float* const* wl = weights + MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT;
       LayerParams& P = e->params[l];
@@ -414,9 +420,9 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
       guard(dev_copy_f32(e, wl[MANNER_HIP_WL_FF2_B], H, &P.b2, s));
       guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_G], H, &P.ln2g, s));
       guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_B], H, &P.ln2b, s));
-      for (int p = 0; p < 2 && !rc; ++p) {
-        if (!(precisions & (1u << p))) continue;
-        const size_t es = p == MANNER_HIP_PREC_BF16 ? 2 : 4;
+      for (int p = 0; p < 4 && !rc; ++p) {
+        if (p == MANNER_HIP_PREC_BF16X3 || !(precisions & (1u << p))) continue;
+        const size_t es = act_bytes(p);
         LayerWeights& W = e->w[p][l];
         if (!guard(dev_alloc(e, 3 * HH * es, &W.wqkv))) break;
         if (!guard(dev_alloc(e, HH * es, &W.wo))) break;
@@ -440,17 +446,21 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
       if (e->defer_ln && !rc) {
         // fold the LayerNorm that feeds each GEMM into its weight: the embedding LayerNorm (layer 0) or the
         // previous layer's output LayerNorm for Q|K|V, this layer's attention-output LayerNorm for FFN1
-        LayerWeights& W = e->w[MANNER_HIP_PREC_BF16][l];
         const float* g_in = l == 0 ? e->embg : e->params[l - 1].ln2g;
         const float* b_in = l == 0 ? e->embb : e->params[l - 1].ln2b;
-        if (!guard(dev_alloc(e, 3 * HH * 2, &W.wqkv_f)) || !guard(dev_alloc(e, HI * 2, &W.w1_f))) break;
-        if (!guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.cq1)) || !guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.cq2))) break;
-        if (!guard(dev_alloc(e, (size_t)I * 4, (void**)&P.cf1)) || !guard(dev_alloc(e, (size_t)I * 4, (void**)&P.cf2))) break;
+        if (!guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&P.cq2)) || !guard(dev_alloc(e, (size_t)I * 4, (void**)&P.cf2))) break;
         if (!guard(dev_alloc(e, (size_t)H * 4, (void**)&P.bo_res)) || !guard(dev_alloc(e, (size_t)H * 4, (void**)&P.b2_res))) break;
-        for (int j = 0; j < 3; ++j)
-          guard(fold_layernorm(wl[MANNER_HIP_WL_Q_W + 2 * j], wl[MANNER_HIP_WL_Q_B + 2 * j], g_in, b_in, H, H,
-                               static_cast<bf16_t*>(W.wqkv_f) + j * HH, P.cq1 + j * H, P.cq2 + j * H, s));
-        guard(fold_layernorm(wl[MANNER_HIP_WL_FF1_W], wl[MANNER_HIP_WL_FF1_B], P.ln1g, P.ln1b, I, H, W.w1_f, P.cf1, P.cf2, s));
+        for (int p : {MANNER_HIP_PREC_BF16, MANNER_HIP_PREC_F16}) {
+          if (!(precisions & (1u << p)) || rc) continue;
+          const DType fdt = act_dtype(p);
+          LayerWeights& W = e->w[p][l];
+          if (!guard(dev_alloc(e, 3 * HH * 2, &W.wqkv_f)) || !guard(dev_alloc(e, HI * 2, &W.w1_f))) break;
+          if (!guard(dev_alloc(e, 3 * (size_t)H * 4, (void**)&W.cq1)) || !guard(dev_alloc(e, (size_t)I * 4, (void**)&W.cf1))) break;
+          for (int j = 0; j < 3; ++j)
+            guard(fold_layernorm(fdt, wl[MANNER_HIP_WL_Q_W + 2 * j], wl[MANNER_HIP_WL_Q_B + 2 * j], g_in, b_in, H, H,
+                                 static_cast<char*>(W.wqkv_f) + j * HH * 2, W.cq1 + j * H, P.cq2 + j * H, s));
+          guard(fold_layernorm(fdt, wl[MANNER_HIP_WL_FF1_W], wl[MANNER_HIP_WL_FF1_B], P.ln1g, P.ln1b, I, H, W.w1_f, W.cf1, P.cf2, s));
+        }
         guard(add_vectors(P.bo, b_in, P.bo_res, H, s));
         guard(add_vectors(P.b2, P.ln1b, P.b2_res, H, s));
       }
@@ -464,7 +474,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
 }
 
 size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens, int32_t precision) {
-  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 2) return 0;
+  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 3) return 0;
   return enc->n_streams * carve(enc, max_news, round_up(max_tokens, 256), precision, nullptr, nullptr);
 }
 
@@ -475,7 +485,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_cls: null handle");
   if (n_news == 0) return MANNER_HIP_OK;
   if (!ids || !mask || !out || !workspace || n_news < 0) return fail(MANNER_HIP_E_INVALID, "encode_cls: null pointer");
-  if (precision < 0 || precision > 2 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
+  if (precision < 0 || precision > 3 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
   if (padded_len < 1 || padded_len > MANNER_HIP_MAX_LEN) return fail(MANNER_HIP_E_INVALID, "encode_cls: padded_len %lld outside [1, %d]", (long long)padded_len, MANNER_HIP_MAX_LEN);
   if ((uintptr_t)workspace % 256) return fail(MANNER_HIP_E_INVALID, "encode_cls: workspace must be 256-byte aligned");
   const int H = enc->cfg.hidden;
@@ -483,7 +493,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   // With two streams the workspace is split into two independent halves.
   const int ns = enc->profiling ? 1 : enc->n_streams;   // per-kernel timing wants un-overlapped launches
   const size_t ws_each = (workspace_bytes / enc->n_streams) / 256 * 256;   // same chunk size with or without profiling
-  const size_t es = precision == MANNER_HIP_PREC_BF16 ? 2 : 4;
+  const size_t es = act_bytes(precision);
   const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es +
                          (precision == MANNER_HIP_PREC_BF16X3 ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) : 0);
   int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;

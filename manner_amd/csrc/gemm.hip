@@ -70,9 +70,11 @@ __device__ __forceinline__ float gelu_poly(float x) {
 template <typename TIn> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return gelu_erf_fast(x); }
+template <> __device__ __forceinline__ float gelu_for<f16_t>(float x) { return gelu_erf_fast(x); }
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<f16_t> { typedef f16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
 
 template <typename T>
@@ -81,6 +83,10 @@ __device__ __forceinline__ void mma_chunk(const typename Frag<T>::type& a, const
 template <>
 __device__ __forceinline__ void mma_chunk<bf16_t>(const bf16x8& a, const bf16x8& b, f32x16& acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<f16_t>(const f16x8& a, const f16x8& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma_chunk<float>(const f32x4& a, const f32x4& b, f32x16& acc) {
@@ -98,8 +104,17 @@ template <>
 __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
   *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
+template <>
+__device__ __forceinline__ void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f16x4*>(p) = f16x4{(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
+}
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <>
+__device__ __forceinline__ void load4<f16_t>(const f16_t* p, float v[4]) {
+  f16x4 t = *reinterpret_cast<const f16x4*>(p);
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
 template <>
 __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
   f32x4 t = *reinterpret_cast<const f32x4*>(p);
@@ -606,12 +621,14 @@ struct DlnAux {
   int col_group;          // column tiles per pass over the rows (0 = all): see the tile order in the kernel
 };
 
-template <typename TOut, int EPI, int ABL = 0>
+template <typename TE, typename TOut, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
-    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    const bf16_t* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
     int n_tiles, DlnAux dln) {
-  typedef bf16_t TIn;
+  typedef TE TIn;                               // bf16_t or f16_t (E16<TE>: vector types and the MFMA of the type)
+  typedef typename E16<TE>::v8 e16x8;
+  typedef typename E16<TE>::v4 e16x4;
   constexpr int EPC = 8, BK = 64;
   // 2 weight stages [0, 64 KiB) + 3 activation stages [64, 160 KiB): the activation tile's first touch
   // comes from HBM (~2 us), so it is prefetched TWO K-steps ahead; weights are L2-resident (one ahead)
@@ -673,28 +690,28 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int swz = (kl15 >> 1) & 7;
   const int woff = (kwn * 64 + kl15) * ROW_BYTES;
   const int xoff = (kwm * 128 + kl15) * ROW_BYTES;
-  auto read_w = [&](const char* base, int s2, bf16x8 (&wf)[4]) {
+  auto read_w = [&](const char* base, int s2, e16x8 (&wf)[4]) {
     const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(base + woff + a * 16 * ROW_BYTES + coff);
+    for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const e16x8*>(base + woff + a * 16 * ROW_BYTES + coff);
   };
-  auto read_x = [&](const char* base, int s2, int half, bf16x8 (&xf)[4]) {
+  auto read_x = [&](const char* base, int s2, int half, e16x8 (&xf)[4]) {
     const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
-      xf[bb] = *reinterpret_cast<const bf16x8*>(base + xoff + (4 * half + bb) * 16 * ROW_BYTES + coff);
+      xf[bb] = *reinterpret_cast<const e16x8*>(base + xoff + (4 * half + bb) * 16 * ROW_BYTES + coff);
   };
 
   f32x4 acc[4][8];
-  auto mma16 = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4], int half) {
+  auto mma16 = [&](const e16x8 (&wf)[4], const e16x8 (&xf)[4], int half) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
-        acc[a][4 * half + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[bb], acc[a][4 * half + bb], 0, 0, 0);
+        acc[a][4 * half + bb] = E16<TE>::mfma16(wf[a], xf[bb], acc[a][4 * half + bb]);
   };
 
-  bf16x8 w0[4], w1[4], xa[4], xb[4];
+  e16x8 w0[4], w1[4], xa[4], xb[4];
   // DMA issue is STAGGERED between the two waves of a SIMD (waves w and w+4): an LDS-DMA piece costs the
   // issuing wave ~60-100 cycles, 8 pieces per K-step; if both partners issued in the same chunk neither
   // could feed the matrix pipe meanwhile.  Waves 0-3 (weight tile) issue all 8 pieces of step k+2 in
@@ -866,7 +883,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
               *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
             }
           __builtin_amdgcn_wave_barrier();
-          bf16x4 res[4][4];
+          e16x4 res[4][4];
 #pragma unroll
           for (int b4 = 0; b4 < 4; ++b4) {
             const int row = 16 * (b4 & 1) + l15;
@@ -874,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
               const int c = (16 * a + 4 * lq) / 8;
-              res[b4][a] = *reinterpret_cast<const bf16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+              res[b4][a] = *reinterpret_cast<const e16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
             }
           }
           __builtin_amdgcn_wave_barrier();
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
               const int c = (16 * a + 4 * lq) / 8;
-              store4<bf16_t>(reinterpret_cast<bf16_t*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)),
+              store4<TE>(reinterpret_cast<TE*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)),
                              acc[a][2 * j + b2][0], acc[a][2 * j + b2][1], acc[a][2 * j + b2][2], acc[a][2 * j + b2][3]);
             }
           }
@@ -922,7 +939,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
             const int c = sl ^ (row & 7);
             const int m = mrow0 + 32 * j + row;
             const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * 128 + (sl << 4));
-            if (m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<bf16_t*>(Y) + (size_t)m * N + nbase + 8 * c) = raw;
+            if (m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<TE*>(Y) + (size_t)m * N + nbase + 8 * c) = raw;
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -984,7 +1001,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         }
       }
       __builtin_amdgcn_wave_barrier();
-      bf16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
+      e16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
       f32x4 resf[EPI == EPI_BIAS_RES_F32 ? SQ : 1];
       if ((EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_F32) && ABL != 1) {   // TOut == float: the slab's residual loads in one batch
 #pragma unroll
@@ -992,7 +1009,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           const int row = q * ROWS_PER_INST + row0;
           const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
           const size_t idx = (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC;
-          if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const bf16x4*>(R + idx);
+          if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const e16x4*>(R + idx);
           else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
         }
       }
@@ -1025,7 +1042,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   }
 }
 
-template <typename TOut>
+template <typename TE, typename TOut>
 int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
   const int n_tiles = N / G_BN;
@@ -1033,26 +1050,26 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
   if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
   const int n_cus = device_cus();       // persistent grid: one workgroup per CU (160 KiB LDS each)
   dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
-  const bf16_t* x = static_cast<const bf16_t*>(X);
-  const bf16_t* w = static_cast<const bf16_t*>(W);
-  const bf16_t* r = static_cast<const bf16_t*>(R);
+  const TE* x = static_cast<const TE*>(X);
+  const TE* w = static_cast<const TE*>(W);
+  const TE* r = static_cast<const TE*>(R);
   TOut* y = static_cast<TOut*>(Y);
   switch (epi) {
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_RES:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_RES_F32:
-      if constexpr (sizeof(TOut) == 4) {
-        hipLaunchKernelGGL((gemm_tn_x16_kernel<TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      if constexpr (sizeof(TOut) == 4 && std::is_same<TE, bf16_t>::value) {
+        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
         break;
       }
-      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 writes f32");
+      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 takes bf16 operands and writes f32");
     default:
       return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
@@ -1120,30 +1137,22 @@ int pool_logits_mfma(const float* x, const float* W, const float* bias, const fl
   return MANNER_HIP_OK;
 }
 
-int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
-                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
-  static const int col_group_env = getenv("MANNER_HIP_COL_GROUP") ? atoi(getenv("MANNER_HIP_COL_GROUP")) : -1;   // A/B switch
-  const int col_group = col_group_env >= 0 ? col_group_env : 0;
-  if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
-    return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
-  if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
-  const int n_tiles = N / G_BN;
-  const int64_t tiles = (m_bound / G_BM) * n_tiles;
-  const int64_t cus = device_cus();
-  dim3 g((unsigned)(tiles < cus ? tiles : cus)), b(512);
-  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group};
-  const bf16_t* x = static_cast<const bf16_t*>(X);
-  const bf16_t* w = static_cast<const bf16_t*>(W);
-  bf16_t* y = static_cast<bf16_t*>(Y);
+template <typename TE>
+static int launch_dln(Epilogue epi, const void* X, const void* W, const float* bias, void* Y, int N, int K, const int* m_total,
+                      int n_tiles, dim3 g, const DlnAux& aux, hipStream_t stream) {
+  const dim3 b(512);
+  const TE* x = static_cast<const TE*>(X);
+  const TE* w = static_cast<const TE*>(W);
+  TE* y = static_cast<TE*>(Y);
   switch (epi) {
     case EPI_NORM:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NORM>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TE, EPI_NORM>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
       break;
     case EPI_NORM_GELU:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NORM_GELU>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TE, EPI_NORM_GELU>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
       break;
     case EPI_NRES:   // in place: the residual is the output buffer
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI_NRES>), g, b, 0, stream, x, w, bias, y, y, N, K, m_total, n_tiles, aux);
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TE, EPI_NRES>), g, b, 0, stream, x, w, bias, y, y, N, K, m_total, n_tiles, aux);
       break;
     default:
       return fail(MANNER_HIP_E_INVALID, "gemm_dln: epilogue %d", (int)epi);
@@ -1152,21 +1161,43 @@ int gemm_tn_dln(Epilogue epi, const void* X, const void* W, const float* bias, c
   return MANNER_HIP_OK;
 }
 
+int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+  static const int col_group_env = getenv("MANNER_HIP_COL_GROUP") ? atoi(getenv("MANNER_HIP_COL_GROUP")) : -1;   // A/B switch
+  const int col_group = col_group_env >= 0 ? col_group_env : 0;
+  if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
+    return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
+  if (!is_16bit(dt)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: 16-bit element types only");
+  const int n_tiles = N / G_BN;
+  const int64_t tiles = (m_bound / G_BM) * n_tiles;
+  const int64_t cus = device_cus();
+  dim3 g((unsigned)(tiles < cus ? tiles : cus));
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group};
+  if (dt == DT_F16) return launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+  return launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+}
+
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
             hipStream_t stream) {
-  const int esz = in == DT_BF16 ? 2 : 4;
+  const int esz = in == DT_F32 ? 4 : 2;
   if (N % BN || (K * esz) % ROW_BYTES || m_bound % BM)
     return fail(MANNER_HIP_E_INVALID, "gemm shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if ((epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_F32) && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
   if (epi == EPI_BIAS_RES_F32 && !(in == DT_BF16 && out == DT_F32 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
     return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 needs bf16 operands, f32 output and 256-tileable shapes");
+  if (out != DT_F32 && out != in) return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
     static const bool use_x32 = getenv("MANNER_HIP_GEMM_X32") != nullptr;   // A/B: bf16 on the 32x32x16 shape
+    if (in == DT_F16 && K >= 128) {
+      if (out == DT_F16) return launch_x16<f16_t, f16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+      return launch_x16<f16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+    }
     if (in == DT_BF16 && !use_x32 && K >= 128) {          // the staggered DMA schedule needs >= 2 K-steps
-      if (out == DT_BF16) return launch_x16<bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
-      return launch_x16<float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+      if (out == DT_BF16) return launch_x16<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+      return launch_x16<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
     }
     if (in == DT_BF16 && out == DT_BF16) return launch_big<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
     if (in == DT_BF16 && out == DT_F32) return launch_big<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
@@ -1174,6 +1205,8 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   }
   if (in == DT_BF16 && out == DT_BF16) return launch<bf16_t, bf16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
   if (in == DT_BF16 && out == DT_F32) return launch<bf16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  if (in == DT_F16 && out == DT_F16) return launch<f16_t, f16_t>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
+  if (in == DT_F16 && out == DT_F32) return launch<f16_t, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
   if (in == DT_F32 && out == DT_F32) return launch<float, float>(epi, X, W, bias, residual, Y, m_bound, N, K, m_total, stream);
   return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
 }

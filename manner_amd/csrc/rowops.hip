@@ -80,6 +80,10 @@ template <>
 __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
 }
+template <>
+__device__ __forceinline__ void store_vec<f16_t>(f16_t* p, const f32x4& v) {
+  *reinterpret_cast<f16x4*>(p) = f16x4{(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+}
 
 // normalise the H values a wave holds in v[] (lane owns columns (i*64+lane)*4 .. +3) and store
 template <typename TOut>
@@ -170,12 +174,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   wave_layernorm_store<TOut>(v, H, eps, gamma, beta, x + (size_t)row * H, lane);
 }
 
-// ---- deferred LayerNorm (bf16 path): K1 without the normalisation.  The row is rounded to bf16 first and the
-// statistics are those of the rounded values — exactly what the consuming GEMM reads.
+// ---- deferred LayerNorm (16-bit path): K1 without the normalisation.  The row is rounded to the element type first and
+// the statistics are those of the rounded values — exactly what the consuming GEMM reads.
+template <typename TE>
 __global__ __launch_bounds__(256) void embed_raw_kernel(
     const int64_t* __restrict__ ids, int64_t lp, const int32_t* __restrict__ cu, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type0, int H, float eps, int pos_offset, int vocab,
-    int max_pos, bf16_t* __restrict__ raw, float2* __restrict__ mr, int32_t* __restrict__ status) {
+    int max_pos, TE* __restrict__ raw, float2* __restrict__ mr, int32_t* __restrict__ status) {
   const int64_t n = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int start = cu[n], len = cu[n + 1] - start;
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(256) void embed_raw_kernel(
         const f32x4 b = *reinterpret_cast<const f32x4*>(type0 + c);
         const f32x4 d = *reinterpret_cast<const f32x4*>(pr + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = (float)(bf16_t)((a[e] + b[e]) + d[e]);
+        for (int e = 0; e < 4; ++e) v[i][e] = (float)(TE)((a[e] + b[e]) + d[e]);
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        store_vec<bf16_t>(raw + (size_t)(start + t) * H + c, v[i]);
+        store_vec<TE>(raw + (size_t)(start + t) * H + c, v[i]);
       }
     }
     const float mean = wave_sum(s) / (float)H;
@@ -233,14 +238,15 @@ __global__ __launch_bounds__(256) void dln_finalize_kernel(const float2* __restr
   mr[m] = float2{mean, 1.0f / sqrtf(var + eps)};
 }
 
-__global__ __launch_bounds__(256) void gather_cls_ln_kernel(const bf16_t* __restrict__ raw, const float2* __restrict__ mr,
+template <typename TE>
+__global__ __launch_bounds__(256) void gather_cls_ln_kernel(const TE* __restrict__ raw, const float2* __restrict__ mr,
                                                             const int32_t* __restrict__ cu, int H, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, bf16_t* __restrict__ dst) {
+                                                            const float* __restrict__ beta, TE* __restrict__ dst) {
   const int64_t n = blockIdx.x;
   const int64_t row = cu[n];
   const float2 ms = mr[row];
-  const bf16_t* src = raw + (size_t)row * H;
-  for (int c = threadIdx.x; c < H; c += 256) dst[n * H + c] = (bf16_t)(((float)src[c] - ms.x) * ms.y * gamma[c] + beta[c]);
+  const TE* src = raw + (size_t)row * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[n * H + c] = (TE)(((float)src[c] - ms.x) * ms.y * gamma[c] + beta[c]);
 }
 
 __global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
@@ -249,15 +255,16 @@ __global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ 
 }
 
 // one wave per output row n of the folded weight
+template <typename TE>
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
-                                                      bf16_t* __restrict__ wf, float* __restrict__ c1, float* __restrict__ c2) {
+                                                      TE* __restrict__ wf, float* __restrict__ c1, float* __restrict__ c2) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   float s1 = 0.f, s2 = 0.f;
   for (int k = lane; k < K; k += 64) {
     const float x = w[(size_t)n * K + k];
-    const bf16_t f = (bf16_t)(gamma[k] * x);
+    const TE f = (TE)(gamma[k] * x);
     wf[(size_t)n * K + k] = f;
     s1 += (float)f;
     s2 = fmaf(beta[k], x, s2);
@@ -338,9 +345,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   for (int c = threadIdx.x; c < H * (int)sizeof(T) / 16; c += 256) d[c] = src[c];
 }
 
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+template <typename TE>
+__global__ __launch_bounds__(256) void cvt_16_kernel(const float* __restrict__ src, TE* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)src[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (TE)src[i];
 }
 
 }  // namespace
@@ -365,6 +373,9 @@ int embed_layernorm(DType out, const int64_t* ids, int64_t n_news, int64_t padde
   if (out == DT_BF16)
     hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, g, b, 0, stream, ids, padded_len, cu, word, pos, type0, gamma, beta,
                        H, eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(x), status);
+  else if (out == DT_F16)
+    hipLaunchKernelGGL(embed_ln_kernel<f16_t>, g, b, 0, stream, ids, padded_len, cu, word, pos, type0, gamma, beta,
+                       H, eps, pos_offset, vocab, max_pos, static_cast<f16_t*>(x), status);
   else
     hipLaunchKernelGGL(embed_ln_kernel<float>, g, b, 0, stream, ids, padded_len, cu, word, pos, type0, gamma, beta,
                        H, eps, pos_offset, vocab, max_pos, static_cast<float*>(x), status);
@@ -378,18 +389,24 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
   dim3 g((unsigned)((m_bound + 3) / 4)), b(256);
   if (out == DT_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<bf16_t*>(x), m_total);
+  else if (out == DT_F16)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<f16_t*>(x), m_total);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<float*>(x), m_total);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
 
-int embed_raw(const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
+int embed_raw(DType dt, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
               const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
               void* raw, void* mr, int32_t* status, hipStream_t stream) {
   if (H % 4 || H > MAX_H) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported (<= %d, %%4)", H, MAX_H);
-  hipLaunchKernelGGL(embed_raw_kernel, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
-                     eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(raw), static_cast<float2*>(mr), status);
+  if (dt == DT_F16)
+    hipLaunchKernelGGL(embed_raw_kernel<f16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
+                       eps, pos_offset, vocab, max_pos, static_cast<f16_t*>(raw), static_cast<float2*>(mr), status);
+  else
+    hipLaunchKernelGGL(embed_raw_kernel<bf16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
+                       eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(raw), static_cast<float2*>(mr), status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -402,10 +419,14 @@ int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64
   return MANNER_HIP_OK;
 }
 
-int gather_cls_ln(const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
+int gather_cls_ln(DType dt, const void* raw, const void* mr, const int32_t* cu, int64_t n_news, int H, const float* gamma,
                   const float* beta, void* dst, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_cls_ln_kernel, dim3((unsigned)n_news), dim3(256), 0, stream, static_cast<const bf16_t*>(raw),
-                     static_cast<const float2*>(mr), cu, H, gamma, beta, static_cast<bf16_t*>(dst));
+  if (dt == DT_F16)
+    hipLaunchKernelGGL(gather_cls_ln_kernel<f16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, static_cast<const f16_t*>(raw),
+                       static_cast<const float2*>(mr), cu, H, gamma, beta, static_cast<f16_t*>(dst));
+  else
+    hipLaunchKernelGGL(gather_cls_ln_kernel<bf16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, static_cast<const bf16_t*>(raw),
+                       static_cast<const float2*>(mr), cu, H, gamma, beta, static_cast<bf16_t*>(dst));
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -419,6 +440,9 @@ int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const 
   if (in == DT_BF16) {
     if (mr) { if (out_dt == DT_F32) SCATTER(bf16_t, float, true); else SCATTER(bf16_t, bf16_t, true); }
     else { if (out_dt == DT_F32) SCATTER(bf16_t, float, false); else SCATTER(bf16_t, bf16_t, false); }
+  } else if (in == DT_F16) {
+    if (mr) { if (out_dt == DT_F32) SCATTER(f16_t, float, true); else SCATTER(f16_t, bf16_t, true); }
+    else { if (out_dt == DT_F32) SCATTER(f16_t, float, false); else SCATTER(f16_t, bf16_t, false); }
   } else {
     if (out_dt == DT_F32) SCATTER(float, float, false); else SCATTER(float, bf16_t, false);
   }
@@ -449,10 +473,14 @@ int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s
   return MANNER_HIP_OK;
 }
 
-int fold_layernorm(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
+int fold_layernorm(DType dt, const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf,
                    float* c1, float* c2, hipStream_t stream) {
-  hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, w, bias, gamma, beta, N, K,
-                     static_cast<bf16_t*>(wf), c1, c2);
+  if (dt == DT_F16)
+    hipLaunchKernelGGL(fold_ln_kernel<f16_t>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, w, bias, gamma, beta, N, K,
+                       static_cast<f16_t*>(wf), c1, c2);
+  else
+    hipLaunchKernelGGL(fold_ln_kernel<bf16_t>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, w, bias, gamma, beta, N, K,
+                       static_cast<bf16_t*>(wf), c1, c2);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -461,6 +489,8 @@ int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H
   dim3 g((unsigned)n_news), b(256);
   if (in == DT_BF16)
     hipLaunchKernelGGL(gather_cls_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(x), cu, n_news, H, out);
+  else if (in == DT_F16)
+    hipLaunchKernelGGL(gather_cls_kernel<f16_t>, g, b, 0, stream, static_cast<const f16_t*>(x), cu, n_news, H, out);
   else
     hipLaunchKernelGGL(gather_cls_kernel<float>, g, b, 0, stream, static_cast<const float*>(x), cu, n_news, H, out);
   MANNER_LAUNCH_CHECK();
@@ -469,7 +499,7 @@ int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H
 
 int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, int H, void* dst, hipStream_t stream) {
   dim3 g((unsigned)n_news), b(256);
-  if (dt == DT_BF16)
+  if (is_16bit(dt))      // a 2-byte row copy: one instantiation serves bf16 and f16
     hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, g, b, 0, stream, static_cast<const bf16_t*>(x), cu, H, static_cast<bf16_t*>(dst));
   else
     hipLaunchKernelGGL(gather_rows_kernel<float>, g, b, 0, stream, static_cast<const float*>(x), cu, H, static_cast<float*>(dst));
@@ -477,9 +507,11 @@ int gather_cls_rows(DType dt, const void* x, const int32_t* cu, int64_t n_news, 
   return MANNER_HIP_OK;
 }
 
-int convert_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream) {
+int convert_f32_to_16(DType dt, const float* src, void* dst, int64_t n, hipStream_t stream) {
   const int64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n);
+  const dim3 g((unsigned)(blocks < 4096 ? blocks : 4096));
+  if (dt == DT_F16) hipLaunchKernelGGL(cvt_16_kernel<f16_t>, g, dim3(256), 0, stream, src, static_cast<f16_t*>(dst), n);
+  else hipLaunchKernelGGL(cvt_16_kernel<bf16_t>, g, dim3(256), 0, stream, src, static_cast<bf16_t*>(dst), n);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

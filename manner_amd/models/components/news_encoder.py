@@ -87,9 +87,10 @@ class HipPLM(nn.Module):
 class MannerTextEncoder(nn.Module):
     """reference news_encoder.py:11-37."""
 
-    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate), "fp32" (f32 MFMA parity mode) or "bf16x3"
-    #: (f32 activations, split-operand bf16 GEMMs: 2x the fp32 mode, within 2.5e-4)
-    precision: str = os.environ.get("MANNER_HIP_PRECISION", "bf16")
+    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate), "f16" (the same kernels on IEEE half — what the
+    #: reference's `precision: 16-mixed` computes in; ~8x closer to fp32 than bf16 at the same speed), "fp32" (f32 MFMA
+    #: parity mode) or "bf16x3" (f32 activations, split-operand bf16 GEMMs: 2x the fp32 mode, within 2.5e-4)
+    precision: str = os.environ.get("MANNER_HIP_PRECISION", "f16")
 
     def __init__(self, plm_model: str, frozen_layers: List[int], dropout_probability: float) -> None:
         super().__init__()
@@ -110,11 +111,11 @@ class MannerTextEncoder(nn.Module):
 
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
         params = dict(self.plm_model.named_parameters())
-        key = (str(device), self.precision == "bf16x3", tuple((p.data_ptr(), p._version) for p in params.values()))
+        key = (str(device), self.precision, tuple((p.data_ptr(), p._version) for p in params.values()))
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
                 self._hip.close()
-            precisions = ("bf16", "fp32") + (("bf16x3",) if self.precision == "bf16x3" else ())
+            precisions = tuple(dict.fromkeys(("bf16", "fp32", self.precision)))
             self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
                                        precisions=precisions, device=device)
             self._hip_key = key
