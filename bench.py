@@ -374,8 +374,9 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     pool_ids, pool_mask, pool_len = pool
     n_news = pool_ids.shape[0]
     n_imp = conf["dims"]["n_impressions"]
-    shards = D.balanced_news_shards(pool_len, world, cfg.flops_per_news)
+    shards = D.equal_news_shards(n_news, world)         # equal rows: the all-gather writes the table in place
     lo, hi = shards[rank]
+    mx_rows = max(h - l for l, h in shards)
     imp = synth_impressions(n_imp, n_news, seed=43)
     a, b = shard_range(n_imp, rank, world)
     ho, co = imp["hist_off"], imp["cand_off"]
@@ -383,7 +384,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             "cand_idx": torch.from_numpy(imp["cand_idx"][co[a]:co[b]]).to(dev), "cand_off": torch.from_numpy(co[a:b + 1] - co[a]).to(dev)}
     labels = torch.from_numpy(imp["labels"][co[a]:co[b]]).to(dev)
     K = len(encs)
-    local = [torch.empty((hi - lo, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]
+    local = [torch.zeros((mx_rows, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]   # padded send blocks
 
     def sync():
         torch.cuda.synchronize()
@@ -394,7 +395,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     def encode_all(prec):
         for k in range(K):
             encs[k].encode_cls(pool_ids[lo:hi], pool_mask[lo:hi], precision=prec, host_lengths=pool_len[lo:hi],
-                               max_chunk_tokens=args.chunk_tokens, out=local[k])
+                               max_chunk_tokens=args.chunk_tokens, out=local[k][: hi - lo])
 
     times = {}
     for it in range(2):                                 # pass 0 warms up (workspace, RCCL channels)
@@ -455,11 +456,11 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             torch.cuda.synchronize(); t0 = time.perf_counter()
             encode_all(mode)
             torch.cuda.synchronize(); speed[mode] = n_news * K / (time.perf_counter() - t0)
-            fast[mode] = hotpath.score_impressions(list(local), dimp, weights=fuse_w, labels=labels, k=10)["scores"].clone()
+            fast[mode] = hotpath.score_impressions([t[: hi - lo] for t in local], dimp, weights=fuse_w, labels=labels, k=10)["scores"].clone()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         encode_all("fp32")
         torch.cuda.synchronize(); t_f32 = time.perf_counter() - t0
-        res32 = hotpath.score_impressions(list(local), dimp, weights=fuse_w, labels=labels, k=10)
+        res32 = hotpath.score_impressions([t[: hi - lo] for t in local], dimp, weights=fuse_w, labels=labels, k=10)
         parity = {"what": f"16-bit modes vs the HIP fp32 parity mode, table mode, {n_news} news, all {n_imp} impressions",
                   "hf_init_weights_std0.02": {m: ranking_agreement(v, res32["scores"], labels, off_r) for m, v in fast.items()},
                   "other_mode_news_per_s": speed,

@@ -147,9 +147,15 @@ def _gloo_worker(rank, world, port, tmp):
         shards = D.balanced_news_shards(mask.sum(1), world, cfg.flops_per_news)
         lo, hi = shards[rank]
         local = O.encode_cls(ids[lo:hi], mask[lo:hi], w, cfg)               # stand-in for the HIP encoder on CPU
-        table = D.all_gather_table(local, shards)
+        table = D.all_gather_table(local, shards)                           # ragged (FLOP-balanced) shards: one gather
         full = O.encode_cls(ids, mask, w, cfg)
         assert table.shape == full.shape and torch.allclose(table, full, atol=1e-5)
+        eq = D.equal_news_shards(37, world)                                 # equal rows (19 + 18): blocks land in place
+        assert eq[0] == (0, 19) and eq[-1][1] == 37
+        elo, ehi = eq[rank]
+        padded = torch.zeros((19, full.shape[1]))
+        padded[: ehi - elo] = full[elo:ehi]
+        assert torch.equal(D.all_gather_table(padded, eq), full) and torch.equal(D.all_gather_table(full[elo:ehi].clone(), eq), full)
         imp = synth_impressions(11, 37, seed=5, max_hist=6, max_cand=9)
         a, b = D.impression_shard(11)
         ho, co = imp["hist_off"], imp["cand_off"]

@@ -24,6 +24,7 @@ CLASSES = [   # (class, substrings that must all occur in the kernel name)
     ("dln_finalize", ["dln_finalize_kernel"]),
     ("embed_raw", ["embed_raw_kernel"]),
     ("score_late_fusion", ["score_late_fusion_kernel"]),
+    ("rank_ndcg", ["rank_ndcg_kernel"]),
 ]
 # rocprofv3 prints some instantiations half-demangled; EPI_NRES appears as "<bool _Accum, int, ELi0E>"
 TEMPLATE_HINTS = {"Li3ELi0E": ", 3, 0>", "Li4ELi0E": ", 4, 0>", "Li5ELi0E": "int, ELi0E>"}
