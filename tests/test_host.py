@@ -122,6 +122,37 @@ def test_synthetic_inputs_are_deterministic_and_well_formed():
     assert np.array_equal(segment_ids(np.array([0, 2, 2, 5])), [0, 0, 2, 2, 2])
 
 
+def test_reference_import_paths_resolve_to_the_mirror():
+    """north_star: "keeping the NewsEncoder / UserEncoder / ClickPredictor operator surface under manner/models" — the
+    exact import statements of the reference's LightningModules (cr_module.py:13-16, a_module.py:15,
+    ensemble_module.py:13) resolve, through the in-tree shim package ``manner/``, to the HIP mirror classes."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved = {k: v for k, v in sys.modules.items() if k == "manner" or k.startswith("manner.")}
+    for k in saved:
+        del sys.modules[k]                       # a reference checkout on sys.path must not shadow the shim here
+    sys.path.insert(0, root)
+    try:
+        from manner.models.components.click_predictors import DotProduct
+        from manner.models.components.news_encoder import MannerNewsEncoder
+        from manner.models.components.user_encoder import NAMLUserEncoder as UserEncoder
+        from manner.models.components.attention import AdditiveAttention
+        import manner_amd.models.components.news_encoder as M
+        assert importlib.import_module("manner").__file__.startswith(root)
+        assert MannerNewsEncoder is M.MannerNewsEncoder
+        assert DotProduct.__module__ == "manner_amd.models.components.click_predictors"
+        assert UserEncoder.__module__ == "manner_amd.models.components.user_encoder"
+        assert AdditiveAttention.__module__ == "manner_amd.models.components.attention"
+        ue = UserEncoder(news_embedding_dim=768, query_vector_dim=200)          # the reference's call, cr_module.py:65-68
+        assert sorted(ue.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"]
+    finally:
+        sys.path.remove(root)
+        for k in [k for k in sys.modules if k == "manner" or k.startswith("manner.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 73152):
         for w in (1, 2, 3, 8):
