@@ -196,7 +196,8 @@ def test_encode_cls_is_graph_capturable():
     enc.status()
 
 
-def test_optional_paths_agree_with_default(monkeypatch):
+@pytest.mark.parametrize("prec,dtol", [("bf16", 0.2), ("f16", 0.03)])
+def test_optional_paths_agree_with_default(monkeypatch, prec, dtol):
     """Execution modes read from the environment at encoder creation: one stream vs the default two
     phase-shifted streams run the same kernels (bit-identical); the classic LayerNorm-kernel schedule
     (MANNER_HIP_DEFER_LN=0) must stay within bf16 noise of the default deferred-LayerNorm schedule."""
@@ -205,24 +206,24 @@ def test_optional_paths_agree_with_default(monkeypatch):
     ids, mask = synth_news_tokens(3000, cfg, seed=21, profile="title_abstract")
     base, _ = _encoder("bert-base-uncased", 42, 0.02)
     lens = mask.sum(1)
-    ref = base.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    ref = base.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens, max_chunk_tokens=32768)
     monkeypatch.setenv("MANNER_HIP_STREAMS", "1")          # the default is two phase-shifted streams
-    two = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
-    out2 = two.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    two = hip.HipEncoder(cfg, w, precisions=(prec,), device=DEV)
+    out2 = two.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens, max_chunk_tokens=32768)
     two.status()
     assert torch.equal(ref, out2)
     two.close()
     monkeypatch.delenv("MANNER_HIP_STREAMS")
     monkeypatch.setenv("MANNER_HIP_DEFER_LN", "0")   # classic schedule: f32 pre-LayerNorm buffer + LayerNorm kernels
-    classic = hip.HipEncoder(cfg, w, precisions=("bf16",), device=DEV)
-    out3 = classic.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    classic = hip.HipEncoder(cfg, w, precisions=(prec,), device=DEV)
+    out3 = classic.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens, max_chunk_tokens=32768)
     classic.status()
-    refb = base.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=32768)
+    refb = base.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens, max_chunk_tokens=32768)
     assert torch.equal(ref, refb)                    # deferred LayerNorm is deterministic (fixed-order partial sums)
     d = (out3 - ref).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(out3, ref, dim=1).min().item()
-    print(f"deferred vs classic LayerNorm schedule, bf16: max-abs {d:.3e}, min cosine {cos:.6f}")
-    assert d < 0.2 and cos > 0.9995                  # two bf16 roundings of the same f32 result, each ~5e-2 from it
+    print(f"deferred vs classic LayerNorm schedule, {prec}: max-abs {d:.3e}, min cosine {cos:.6f}")
+    assert d < dtol and cos > 0.9995                  # two bf16 roundings of the same f32 result, each ~5e-2 from it
     classic.close()
 
 
@@ -772,6 +773,10 @@ def test_encode_hidden_matches_reference(golden_dir, name):
         errb = np.abs(hb[keep].numpy() - ref).max()
         print(f"{name} hidden_states[{k}]: fp32 err {err:.2e}, bf16 err {errb:.2e}")
         assert errb < 0.12 and float(hb[~keep].abs().max() if (~keep).any() else 0.0) == 0.0
+        hh = enc.encode_hidden(ids, mask, k, precision="f16", out_dtype=torch.float32).cpu()
+        errh = np.abs(hh[keep].numpy() - ref).max()
+        print(f"{name} hidden_states[{k}]: f16 err {errh:.2e}")
+        assert errh < 0.02 and errh < errb and float(hh[~keep].abs().max() if (~keep).any() else 0.0) == 0.0
         h2 = enc.encode_hidden(ids, mask, k, precision="fp32", host_lengths=z["mask"].sum(1), max_chunk_tokens=256).cpu()
         assert torch.equal(h, h2)
     enc.status()
@@ -825,7 +830,8 @@ def test_encoder_bf16x3_close_to_the_fp32_bar(golden_dir, name):
     enc.close()
 
 
-def test_deferred_layernorm_chunk_invariance_fuzz():
+@pytest.mark.parametrize("prec,tol", [("bf16", 0.1), ("f16", 0.02)])
+def test_deferred_layernorm_chunk_invariance_fuzz(prec, tol):
     """Random news counts / lengths / chunk sizes on the 256x256 deferred-LayerNorm schedule: every chunking gives the same
     bits as the single-chunk run (ragged last tiles, rows beyond M, tiles straddling news), and stays near the oracle."""
     enc, cfg = _encoder("mini-roberta-large", 5, 0.03)
@@ -835,14 +841,14 @@ def test_deferred_layernorm_chunk_invariance_fuzz():
         n = int(g.integers(1, 400))
         lens = g.integers(2, 129, n)
         ids, mask = synth_news_tokens(n, cfg, seed=100 + it, lengths=lens)
-        base = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens)
+        base = enc.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens)
         for chunk in (int(g.choice([256, 512, 1000, 4096])), int(g.integers(300, 20000))):
-            out = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16", host_lengths=lens, max_chunk_tokens=chunk)
+            out = enc.encode_cls(_cuda(ids), _cuda(mask), precision=prec, host_lengths=lens, max_chunk_tokens=chunk)
             assert torch.equal(base, out), (it, n, chunk)
-        out_nolen = enc.encode_cls(_cuda(ids), _cuda(mask), precision="bf16")            # padded chunking, device-side lengths
+        out_nolen = enc.encode_cls(_cuda(ids), _cuda(mask), precision=prec)            # padded chunking, device-side lengths
         assert torch.equal(base, out_nolen), (it, n)
         if it < 3:
             ref = O.encode_cls(ids[:24], mask[:24], w, cfg).numpy()
-            assert np.abs(base[:24].cpu().numpy() - ref).max() < 0.1
+            assert np.abs(base[:24].cpu().numpy() - ref).max() < tol
     assert torch.isfinite(base).all()
     enc.status()
