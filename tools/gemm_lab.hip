@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     DlnAux aux{vec, mr, part, M, cg};
     bf16_t* y = (bf16_t*)Y;
     auto run = [&](int abl) {
-#define LX(EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, EPI, ABL>), g, b, 0, 0, X, W, bias, EPI == EPI_NRES ? y : R, y, s.N, s.K, mtot, n_tiles, aux)
+#define LX(EPI, ABL) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI, ABL>), g, b, 0, 0, X, W, bias, EPI == EPI_NRES ? y : R, y, s.N, s.K, mtot, n_tiles, aux)
 #define BYA(EPI) if (abl == 0) LX(EPI, 0); else if (abl == 1) LX(EPI, 1); else if (abl == 2) LX(EPI, 2); else if (abl == 3) LX(EPI, 3); else if (abl == 4) LX(EPI, 4); else if (abl == 5) LX(EPI, 5); else LX(EPI, 6);
       switch (s.epi) {
         case EPI_NORM: BYA(EPI_NORM) break;
