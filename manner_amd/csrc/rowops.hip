@@ -181,10 +181,12 @@ __global__ __launch_bounds__(256) void embed_raw_kernel(
     const int64_t* __restrict__ ids, int64_t lp, const int32_t* __restrict__ cu, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type0, int H, float eps, int pos_offset, int vocab,
     int max_pos, TE* __restrict__ raw, float2* __restrict__ mr, int32_t* __restrict__ status) {
+  // grid (news, 4): token t of a news goes to wave t % 16 of its four workgroups, so a wave walks at most 8 tokens
+  // (each a chain of dependent loads: id -> row address -> row) instead of 32
   const int64_t n = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int start = cu[n], len = cu[n + 1] - start;
-  for (int t = wave; t < len; t += 4) {
+  for (int t = wave; t < len; t += 16) {
     int64_t id = ids[n * lp + t];
     int p = t + pos_offset;
     if (id < 0 || id >= vocab || p >= max_pos) {
@@ -402,10 +404,10 @@ int embed_raw(DType dt, const int64_t* ids, int64_t n_news, int64_t padded_len, 
               void* raw, void* mr, int32_t* status, hipStream_t stream) {
   if (H % 4 || H > MAX_H) return fail(MANNER_HIP_E_INVALID, "hidden size %d unsupported (<= %d, %%4)", H, MAX_H);
   if (dt == DT_F16)
-    hipLaunchKernelGGL(embed_raw_kernel<f16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
+    hipLaunchKernelGGL(embed_raw_kernel<f16_t>, dim3((unsigned)n_news, 4), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
                        eps, pos_offset, vocab, max_pos, static_cast<f16_t*>(raw), static_cast<float2*>(mr), status);
   else
-    hipLaunchKernelGGL(embed_raw_kernel<bf16_t>, dim3((unsigned)n_news), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
+    hipLaunchKernelGGL(embed_raw_kernel<bf16_t>, dim3((unsigned)n_news, 4), dim3(256), 0, stream, ids, padded_len, cu, word, pos, type0, H,
                        eps, pos_offset, vocab, max_pos, static_cast<bf16_t*>(raw), static_cast<float2*>(mr), status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
