@@ -60,43 +60,75 @@ __global__ __launch_bounds__(256) void auc_range_kernel(const float* __restrict_
     const float v = s[i];
     out |= !(v >= 0.f && v <= 1.f);
   }
-  if (__any(out) && (threadIdx.x & 63) == 0) atomicOr(scalars, 1u);
+  // one atomic per workgroup at most, and none once the flag is up (a racy read is fine: the flag only ever rises) —
+  // with every score outside [0, 1], the common case for raw dot products, a per-wave atomicOr was 8 k serialised atomics
+  __shared__ int any_out;
+  if (threadIdx.x == 0) any_out = 0;
+  __syncthreads();
+  if (__any(out) && (threadIdx.x & 63) == 0) any_out = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && any_out && *reinterpret_cast<volatile uint32_t*>(scalars) == 0u) atomicOr(scalars, 1u);
 }
 
 // ascending order-preserving key of a float (flip all bits of negatives, the sign bit of the rest), appended to the
-// negatives or the positives: one atomic per wave and label, lanes take consecutive slots
+// negatives or the positives.  A workgroup owns RS_TILE consecutive pairs: it counts its two classes (ballots + a
+// 64-entry scan in LDS), reserves its two output ranges with ONE atomic each — a per-wave atomic on the two global
+// counters serialised 80 k returning atomics and cost 0.9 ms — and writes; the order inside the arrays is irrelevant.
 __global__ __launch_bounds__(256) void auc_split_kernel(const float* __restrict__ s, const float* __restrict__ lab, int64_t n,
                                                        int sigmoid_rule, uint32_t* scalars, uint32_t* __restrict__ neg,
                                                        uint32_t* __restrict__ pos) {
+  __shared__ uint32_t cnt[2][RS_ITEMS * 4];       // [class][round * 4 + wave] -> exclusive offsets
+  __shared__ uint32_t base[2];
   const bool squash = sigmoid_rule && scalars[0];
-  const int lane = threadIdx.x & 63;
-  const int64_t stride = 256ll * gridDim.x;
-  for (int64_t i0 = blockIdx.x * 256ll; i0 < n; i0 += stride) {      // workgroup-uniform trip count
-    const int64_t i = i0 + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const int64_t i0 = (int64_t)blockIdx.x * RS_TILE;
+  uint32_t key[RS_ITEMS];
+  unsigned long long mneg[RS_ITEMS], mpos[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = i0 + r * 256 + threadIdx.x;
     const bool valid = i < n;
-    uint32_t key = 0;
     bool is_neg = false;
+    key[r] = 0;
     if (valid) {
       float v = s[i];
       if (squash) v = 1.0f / (1.0f + expf(-v));
       v += 0.0f;                                   // -0 and +0 are one threshold
       const uint32_t u = __float_as_uint(v);
-      key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      key[r] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
       is_neg = !(lab[i] > 0.5f);
     }
-    const unsigned long long mn = __ballot(valid && is_neg), mp = __ballot(valid && !is_neg);
-    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint32_t bn = 0, bp = 0;
-    if (lane == 0) {
-      if (mn) bn = atomicAdd(scalars + 1, (uint32_t)__popcll(mn));
-      if (mp) bp = atomicAdd(scalars + 2, (uint32_t)__popcll(mp));
-    }
-    bn = __shfl(bn, 0, 64); bp = __shfl(bp, 0, 64);
-    if (valid) {
-      if (is_neg) neg[bn + __popcll(mn & below)] = key;
-      else pos[bp + __popcll(mp & below)] = key;
-    }
+    mneg[r] = __ballot(valid && is_neg);
+    mpos[r] = __ballot(valid && !is_neg);
+    if (lane == 0) { cnt[0][r * 4 + wave] = (uint32_t)__popcll(mneg[r]); cnt[1][r * 4 + wave] = (uint32_t)__popcll(mpos[r]); }
   }
+  __syncthreads();
+  if (threadIdx.x < 2) {                           // one thread per class: exclusive scan of the 64 counts, reserve the range
+    uint32_t run = 0;
+    for (int j = 0; j < RS_ITEMS * 4; ++j) { const uint32_t c = cnt[threadIdx.x][j]; cnt[threadIdx.x][j] = run; run += c; }
+    base[threadIdx.x] = run ? atomicAdd(scalars + 1 + threadIdx.x, run) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const unsigned long long bit = 1ull << lane;
+    if (mneg[r] & bit) neg[base[0] + cnt[0][r * 4 + wave] + (uint32_t)__popcll(mneg[r] & below)] = key[r];
+    else if (mpos[r] & bit) pos[base[1] + cnt[1][r * 4 + wave] + (uint32_t)__popcll(mpos[r] & below)] = key[r];
+  }
+}
+
+// lanes of the wave whose (valid) key has the same 8-bit digit as this lane's: 8 ballots.  Score keys share their high
+// bytes (same sign / exponent), so per-lane atomics on a digit counter would serialise 64 deep; one lane per distinct
+// digit adds the whole group's count instead.
+__device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t d, bool valid) {
+  unsigned long long same = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const unsigned long long m = __ballot((d >> bit) & 1u);
+    same &= ((d >> bit) & 1u) ? m : ~m;
+  }
+  return same;
 }
 
 // ---- LSD radix sort of keys[0 .. *count): one pass = hist -> scan -> scatter on digit (key >> shift) & 255.
@@ -107,10 +139,15 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict
   cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t n = *count, base = (int64_t)blockIdx.x * RS_TILE;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+    const bool valid = i < n;
+    const uint32_t d = valid ? (keys[i] >> shift) & 255u : 0u;
+    const unsigned long long same = same_digit_lanes(d, valid);
+    if (valid && (same & below) == 0) atomicAdd(&cnt[d], (uint32_t)__popcll(same));
   }
   __syncthreads();
   hist[(size_t)threadIdx.x * blocks + blockIdx.x] = cnt[threadIdx.x];
@@ -189,12 +226,17 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
   if ((int64_t)blockIdx.x * RS_TILE >= n) return;                   // workgroup-uniform
   for (int d = lane; d < 256; d += 64) run[wave][d] = 0;
   __syncthreads();
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
   uint32_t key[RS_ITEMS];
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; ++r) {
     const int64_t i = base + r * 64 + lane;
-    key[r] = i < n ? in[i] : 0u;
-    if (i < n) atomicAdd(&run[wave][(key[r] >> shift) & 255u], 1u);   // this wave's digit counts
+    const bool valid = i < n;
+    key[r] = valid ? in[i] : 0u;
+    const uint32_t d = (key[r] >> shift) & 255u;
+    const unsigned long long same = same_digit_lanes(d, valid);
+    if (valid && (same & below) == 0) run[wave][d] += (uint32_t)__popcll(same);   // this wave's digit counts (wave-private row)
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   {                                                 // thread d: first slot of digit d for each wave, in wave order
@@ -204,18 +246,12 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
     for (int w = 0; w < 4; ++w) { const uint32_t c = run[w][d]; run[w][d] = o; o += c; }
   }
   __syncthreads();
-  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; ++r) {
     const int64_t i = base + r * 64 + lane;
     const bool valid = i < n;
     const uint32_t d = (key[r] >> shift) & 255u;
-    unsigned long long same = __ballot(valid);      // lanes of this round holding the same digit
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      const unsigned long long m = __ballot((d >> bit) & 1u);
-      same &= ((d >> bit) & 1u) ? m : ~m;
-    }
+    const unsigned long long same = same_digit_lanes(d, valid);      // lanes of this round holding the same digit
     if (valid) {
       const uint32_t slot = run[wave][d] + (uint32_t)__popcll(same & below);
       out[slot] = key[r];
@@ -310,8 +346,8 @@ int manner_hip_auc(const float* scores, const float* labels, int64_t n, int32_t 
   MANNER_HIP_TRY(hipMemsetAsync(w.acc, 0, 64, stream));
   const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (sigmoid_rule) hipLaunchKernelGGL(auc_range_kernel, dim3(grid), dim3(256), 0, stream, scores, n, w.scalars);
-  hipLaunchKernelGGL(auc_split_kernel, dim3(grid), dim3(256), 0, stream, scores, labels, n, (int)sigmoid_rule, w.scalars,
-                     w.neg_a, w.pos);
+  hipLaunchKernelGGL(auc_split_kernel, dim3((unsigned)rs_blocks(n)), dim3(256), 0, stream, scores, labels, n, (int)sigmoid_rule,
+                     w.scalars, w.neg_a, w.pos);
   MANNER_LAUNCH_CHECK();
   const int blocks = (int)rs_blocks(n);
   const int64_t hist_len = (int64_t)256 * blocks;
