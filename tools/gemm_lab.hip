@@ -137,7 +137,8 @@ int main(int argc, char** argv) {
       printf("  cg%d %.1f us %.0f TF", c, ms * 1e3, fl / ms / 1e9);
     }
     cg = 0; aux.col_group = 0;
-    for (int abl = 1; abl < 2; ++abl) {
+    for (int abl : {1, 3}) {
+      if (abl == 3 && s.epi != EPI_NRES) continue;
       double ms = time_ms([&] { run(abl); }, 20);
       printf("  abl%d %.1f us %.0f TF (%.1f us/tile)", abl, ms * 1e3, fl / ms / 1e9, ms * 1e3 / (tiles / 256.0));
     }
