@@ -59,12 +59,14 @@ class _FlagRing:
     def slot(self):
         """-> (flags carried over from a recycled slot, pinned one-element view to copy the word into)."""
         carried = 0
-        if len(self._pending) == self.SLOTS:   # ring full: the oldest snapshot has long completed
-            old, ev = self._pending.pop(0)
-            ev.synchronize()
-            carried = int(self._host[old])
         i = self._next
         self._next = (i + 1) % self.SLOTS
+        for j, (sl, ev) in enumerate(self._pending):
+            if sl == i:                        # the slot comes round again before its snapshot was consumed: take it now
+                ev.synchronize()
+                carried = int(self._host[sl])
+                del self._pending[j]
+                break
         return carried, i, self._host[i:i + 1]
 
     def push(self, i: int) -> None:
