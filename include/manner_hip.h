@@ -57,8 +57,12 @@ enum { MANNER_HIP_ARCH_BERT = 0, MANNER_HIP_ARCH_ROBERTA = 1 };
  * (stated tolerance 2.5e-4; F32 remains THE 1e-4 parity mode).  Needs H and I multiples of 256.
  * F16: the BF16 schedule and kernels on IEEE half operands (v_mfma_f32_*_f16: same rate, same bytes): 11 mantissa
  * bits instead of 8 (~8x smaller error), f16's exponent range (max 65504) — the arithmetic the reference's own GPU
- * setting computes in (`precision: 16-mixed`, configs/trainer/default.yaml:12). */
-enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1, MANNER_HIP_PREC_BF16X3 = 2, MANNER_HIP_PREC_F16 = 3 };
+ * setting computes in (`precision: 16-mixed`, configs/trainer/default.yaml:12).
+ * F16X3: BF16X3 with IEEE half splits — hi and lo carry 11 bits each, so the three products reproduce ~21 operand
+ * bits (lo parts below 6e-5 fall into f16's subnormals and keep 3e-8 absolute): within 1e-4 of the reference like F32,
+ * at the speed of BF16X3.  Needs H and I multiples of 256. */
+enum { MANNER_HIP_PREC_F32 = 0, MANNER_HIP_PREC_BF16 = 1, MANNER_HIP_PREC_BF16X3 = 2, MANNER_HIP_PREC_F16 = 3,
+       MANNER_HIP_PREC_F16X3 = 4 };
 
 typedef void* manner_hip_stream_t;
 typedef struct manner_hip_encoder* manner_hip_encoder_t;

@@ -18,7 +18,9 @@ STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4,
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
 PREC_F16 = 3
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "fp16": PREC_F16}
+PREC_F16X3 = 4
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "fp16": PREC_F16,
+              "f16x3": PREC_F16X3}
 W_EMB_COUNT, WL_COUNT = 5, 16
 MAX_LEN = 128
 PROF_CLASSES = ["lengths", "embed_ln", "gemm_qkv", "attention", "gemm_out", "layernorm", "gemm_ffn1", "gemm_ffn2",

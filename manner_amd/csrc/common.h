@@ -123,8 +123,8 @@ int fold_layernorm(DType dt, const float* w, const float* bias, const float* gam
 // out[n, t, :] = x[cu[n]+t] (normalised with mr/gamma/beta when mr != NULL) for t < len(n), zeros for padded positions
 int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const int32_t* cu, int64_t n_news, int64_t lp, int H,
                    const float* gamma, const float* beta, void* out, hipStream_t stream);
-// bf16x3: out [rows, 3K] bf16 = [hi | hi | lo] of x [rows, K] f32 (activations) or [hi | lo | hi] (weights); rows >= *m_total skipped
-int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream);
+// bf16x3 / f16x3: out [rows, 3K] of the 16-bit type `dt` = [hi | hi | lo] of x [rows, K] f32 (activations) or [hi | lo | hi] (weights); rows >= *m_total skipped
+int split3_rows(DType dt, bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream);
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int set_device_int(int32_t* p, int32_t value, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);

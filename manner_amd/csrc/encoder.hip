@@ -56,7 +56,7 @@ struct manner_hip_encoder {
   uint32_t precisions = 0;
   float *word = nullptr, *pos = nullptr, *type0 = nullptr, *embg = nullptr, *embb = nullptr;
   std::vector<manner::LayerParams> params;
-  std::vector<manner::LayerWeights> w[4];   // [MANNER_HIP_PREC_*]; BF16X3: bf16 [out, 3*in] split weights
+  std::vector<manner::LayerWeights> w[5];   // [MANNER_HIP_PREC_*]; BF16X3 / F16X3: 16-bit [out, 3*in] split weights
   int32_t* status = nullptr;                // device flag word
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
@@ -82,6 +82,9 @@ namespace {
 // activation dtype / element size of a precision mode (BF16X3 keeps f32 activations)
 inline DType act_dtype(int prec) { return prec == MANNER_HIP_PREC_BF16 ? DT_BF16 : prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_F32; }
 inline size_t act_bytes(int prec) { return (prec == MANNER_HIP_PREC_BF16 || prec == MANNER_HIP_PREC_F16) ? 2 : 4; }
+// split-operand modes: f32 activations, every GEMM on the 16-bit MFMA over [hi | hi | lo] x [hi | lo | hi]
+inline bool is_x3(int prec) { return prec == MANNER_HIP_PREC_BF16X3 || prec == MANNER_HIP_PREC_F16X3; }
+inline DType x3_dtype(int prec) { return prec == MANNER_HIP_PREC_F16X3 ? DT_F16 : DT_BF16; }
 
 int dev_alloc(manner_hip_encoder* e, size_t bytes, void** out) {
   MANNER_HIP_TRY(hipMalloc(out, bytes));
@@ -160,7 +163,7 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   p = take((size_t)m_cap * 8); if (ws) ws->mr_in = p;
   p = take((size_t)m_cap * 8); if (ws) ws->mr_mid = p;
   p = take((size_t)m_cap * (H / 64) * 8); if (ws) ws->part = p;
-  if (prec == MANNER_HIP_PREC_BF16X3) { p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p; }
+  if (is_x3(prec)) { p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p; }
   const int64_t cls_cap = m_cap < CLS_CAP ? m_cap : CLS_CAP;     // the tail borrows pre / ffn (m_cap rows) as scratch
   if (ws) ws->cls_cap = cls_cap;
   p = take((size_t)(cls_cap + 256) * H * es); if (ws) ws->acc_x = p;
@@ -246,13 +249,14 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
   }
   // BF16X3: f32 activations everywhere; each GEMM first splits its A operand into [hi | hi | lo] bf16 (ws.a3) and
   // runs on the bf16 MFMA against the [hi | lo | hi] split weight, depth 3K, f32 residual / output
-  const bool x3 = prec == MANNER_HIP_PREC_BF16X3;
+  const bool x3 = is_x3(prec);
+  const DType xdt = x3_dtype(prec);
   auto gemm = [&](DType out_dt, Epilogue epi, const void* A, const void* Wm, const float* bias, const void* res, void* Y,
                   int64_t mb, int N, int K, const int* mt) -> int {
     if (!x3) return gemm_tn(dt, out_dt, epi, A, Wm, bias, res, Y, mb, N, K, mt, s);
-    int r = split3_rows(false, static_cast<const float*>(A), ws.a3, K, mb, mt, s);
+    int r = split3_rows(xdt, false, static_cast<const float*>(A), ws.a3, K, mb, mt, s);
     if (r) return r;
-    return gemm_tn(DT_BF16, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, mb, N, 3 * K, mt, s);
+    return gemm_tn(xdt, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, mb, N, 3 * K, mt, s);
   };
   const int full_layers = hidden_layers >= 0 ? hidden_layers : c.layers - 1;
   for (int l = 0; l < full_layers; ++l) {
@@ -299,7 +303,8 @@ int run_cls_tail(manner_hip_encoder* e, int prec, const Workspace& ws, int64_t r
   const manner_hip_encoder_config& c = e->cfg;
   const DType dt = act_dtype(prec);
   const int H = c.hidden, I = c.intermediate;
-  const bool x3 = prec == MANNER_HIP_PREC_BF16X3;
+  const bool x3 = is_x3(prec);
+  const DType xdt = x3_dtype(prec);
   const LayerWeights& w = e->w[prec][c.layers - 1];
   const LayerParams& p = e->params[c.layers - 1];
   const int64_t bound = round_up(rows, 256);
@@ -307,9 +312,9 @@ int run_cls_tail(manner_hip_encoder* e, int prec, const Workspace& ws, int64_t r
   if ((rc = set_device_int(ws.cls_total, (int32_t)rows, s))) return rc;
   auto gemm = [&](DType out_dt, Epilogue epi, const void* A, const void* Wm, const float* bias, const void* res, void* Y, int N, int K) -> int {
     if (!x3) return gemm_tn(dt, out_dt, epi, A, Wm, bias, res, Y, bound, N, K, ws.cls_total, s);
-    int r = split3_rows(false, static_cast<const float*>(A), ws.a3, K, bound, ws.cls_total, s);
+    int r = split3_rows(xdt, false, static_cast<const float*>(A), ws.a3, K, bound, ws.cls_total, s);
     if (r) return r;
-    return gemm_tn(DT_BF16, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, bound, N, 3 * K, ws.cls_total, s);
+    return gemm_tn(xdt, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, bound, N, 3 * K, ws.cls_total, s);
   };
   PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, gemm(DT_F32, EPI_BIAS_RES, ws.acc_ctx, w.wo, p.bo, ws.acc_x, ws.pre, H, H))
   PROF_STEP(MANNER_HIP_PROF_CLS_TAIL, layernorm_rows(dt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, ws.acc_x1, bound, ws.cls_total, s))
@@ -371,8 +376,8 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
   if (I <= 0 || I % 128 || L <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: intermediate=%d layers=%d unsupported", I, L);
   if (cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->type_vocab <= 0) return fail(MANNER_HIP_E_INVALID, "encoder_create: bad table sizes");
   if (n_weights != MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT) return fail(MANNER_HIP_E_INVALID, "encoder_create: expected %d weight pointers, got %d", MANNER_HIP_W_EMB_COUNT + L * MANNER_HIP_WL_COUNT, n_weights);
-  if (!(precisions & 15u) || (precisions & ~15u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
-  if ((precisions & (1u << MANNER_HIP_PREC_BF16X3)) && (H % 256 || I % 256)) return fail(MANNER_HIP_E_INVALID, "encoder_create: BF16X3 needs hidden and intermediate sizes that are multiples of 256 (H=%d I=%d)", H, I);
+  if (!(precisions & 31u) || (precisions & ~31u)) return fail(MANNER_HIP_E_INVALID, "encoder_create: precisions mask 0x%x", precisions);
+  if ((precisions & ((1u << MANNER_HIP_PREC_BF16X3) | (1u << MANNER_HIP_PREC_F16X3))) && (H % 256 || I % 256)) return fail(MANNER_HIP_E_INVALID, "encoder_create: BF16X3 / F16X3 need hidden and intermediate sizes that are multiples of 256 (H=%d I=%d)", H, I);
   for (int i = 0; i < n_weights; ++i)
     if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "encoder_create: weight pointer %d is null", i);
 
@@ -406,7 +411,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     }
     if (rc) break;
     e->params.resize(L);
-    for (int p = 0; p < 4; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
+    for (int p = 0; p < 5; ++p) if (precisions & (1u << p)) e->w[p].resize(L);
     for (int l = 0; l < L && !rc; ++l) {
       const float* const* wl = weights + MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT;
       LayerParams& P = e->params[l];
@@ -421,7 +426,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
       guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_G], H, &P.ln2g, s));
       guard(dev_copy_f32(e, wl[MANNER_HIP_WL_OLN_B], H, &P.ln2b, s));
       for (int p = 0; p < 4 && !rc; ++p) {
-        if (p == MANNER_HIP_PREC_BF16X3 || !(precisions & (1u << p))) continue;
+        if (is_x3(p) || !(precisions & (1u << p))) continue;
         const size_t es = act_bytes(p);
         LayerWeights& W = e->w[p][l];
         if (!guard(dev_alloc(e, 3 * HH * es, &W.wqkv))) break;
@@ -433,15 +438,17 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF1_W], HI, W.w1, 0, s));
         guard(pack_matrix(p, wl[MANNER_HIP_WL_FF2_W], HI, W.w2, 0, s));
       }
-      if ((precisions & (1u << MANNER_HIP_PREC_BF16X3)) && !rc) {       // [out, 3 in] bf16 split weights
-        LayerWeights& W = e->w[MANNER_HIP_PREC_BF16X3][l];
+      for (int p : {MANNER_HIP_PREC_BF16X3, MANNER_HIP_PREC_F16X3}) {     // [out, 3 in] split weights of the 16-bit type
+        if (!(precisions & (1u << p)) || rc) continue;
+        const DType sdt = x3_dtype(p);
+        LayerWeights& W = e->w[p][l];
         if (!guard(dev_alloc(e, 3 * HH * 6, &W.wqkv)) || !guard(dev_alloc(e, HH * 6, &W.wo)) ||
             !guard(dev_alloc(e, HI * 6, &W.w1)) || !guard(dev_alloc(e, HI * 6, &W.w2))) break;
         for (int j = 0; j < 3; ++j)
-          guard(split3_rows(true, wl[MANNER_HIP_WL_Q_W + 2 * j], static_cast<bf16_t*>(W.wqkv) + (size_t)j * HH * 3, H, H, nullptr, s));
-        guard(split3_rows(true, wl[MANNER_HIP_WL_AO_W], W.wo, H, H, nullptr, s));
-        guard(split3_rows(true, wl[MANNER_HIP_WL_FF1_W], W.w1, H, I, nullptr, s));
-        guard(split3_rows(true, wl[MANNER_HIP_WL_FF2_W], W.w2, I, H, nullptr, s));
+          guard(split3_rows(sdt, true, wl[MANNER_HIP_WL_Q_W + 2 * j], static_cast<char*>(W.wqkv) + (size_t)j * HH * 6, H, H, nullptr, s));
+        guard(split3_rows(sdt, true, wl[MANNER_HIP_WL_AO_W], W.wo, H, H, nullptr, s));
+        guard(split3_rows(sdt, true, wl[MANNER_HIP_WL_FF1_W], W.w1, H, I, nullptr, s));
+        guard(split3_rows(sdt, true, wl[MANNER_HIP_WL_FF2_W], W.w2, I, H, nullptr, s));
       }
       if (e->defer_ln && !rc) {
         // fold the LayerNorm that feeds each GEMM into its weight: the embedding LayerNorm (layer 0) or the
@@ -474,7 +481,7 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
 }
 
 size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_news, int64_t max_tokens, int32_t precision) {
-  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 3) return 0;
+  if (!enc || max_news <= 0 || max_tokens <= 0 || precision < 0 || precision > 4) return 0;
   return enc->n_streams * carve(enc, max_news, round_up(max_tokens, 256), precision, nullptr, nullptr);
 }
 
@@ -485,7 +492,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   if (!enc) return fail(MANNER_HIP_E_INVALID, "encode_cls: null handle");
   if (n_news == 0) return MANNER_HIP_OK;
   if (!ids || !mask || !out || !workspace || n_news < 0) return fail(MANNER_HIP_E_INVALID, "encode_cls: null pointer");
-  if (precision < 0 || precision > 3 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
+  if (precision < 0 || precision > 4 || !(enc->precisions & (1u << precision))) return fail(MANNER_HIP_E_INVALID, "encode_cls: precision %d was not requested at encoder_create", precision);
   if (padded_len < 1 || padded_len > MANNER_HIP_MAX_LEN) return fail(MANNER_HIP_E_INVALID, "encode_cls: padded_len %lld outside [1, %d]", (long long)padded_len, MANNER_HIP_MAX_LEN);
   if ((uintptr_t)workspace % 256) return fail(MANNER_HIP_E_INVALID, "encode_cls: workspace must be 256-byte aligned");
   const int H = enc->cfg.hidden;
@@ -495,7 +502,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   const size_t ws_each = (workspace_bytes / enc->n_streams) / 256 * 256;   // same chunk size with or without profiling
   const size_t es = act_bytes(precision);
   const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es +
-                         (precision == MANNER_HIP_PREC_BF16X3 ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) : 0);
+                         (is_x3(precision) ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) : 0);
   int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;
   int64_t n_cap = 0;
   while (m_cap >= 256) {

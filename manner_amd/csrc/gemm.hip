@@ -1065,11 +1065,11 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
       hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
     case EPI_BIAS_RES_F32:
-      if constexpr (sizeof(TOut) == 4 && std::is_same<TE, bf16_t>::value) {
+      if constexpr (sizeof(TOut) == 4) {
         hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
         break;
       }
-      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 takes bf16 operands and writes f32");
+      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 writes f32");
     default:
       return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
   }
@@ -1185,8 +1185,8 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   if (N % BN || (K * esz) % ROW_BYTES || m_bound % BM)
     return fail(MANNER_HIP_E_INVALID, "gemm shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if ((epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_F32) && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
-  if (epi == EPI_BIAS_RES_F32 && !(in == DT_BF16 && out == DT_F32 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
-    return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 needs bf16 operands, f32 output and 256-tileable shapes");
+  if (epi == EPI_BIAS_RES_F32 && !(is_16bit(in) && out == DT_F32 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
+    return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 needs 16-bit operands, f32 output and 256-tileable shapes");
   if (out != DT_F32 && out != in) return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {

@@ -310,21 +310,21 @@ __global__ __launch_bounds__(256) void scatter_hidden_kernel(const TIn* __restri
 
 // ---- bf16x3 operand splits.  Activations: out[m] = [hi(x[m]) | hi(x[m]) | lo(x[m])], weights: [hi | lo | hi] with
 // hi = bf16(v), lo = bf16(v - hi): the depth-3K dot product of the two is hi.hi + hi.lo + lo.hi.
-template <bool WEIGHT>
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int K,
+template <typename TE, bool WEIGHT>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, TE* __restrict__ out, int K,
                                                      int64_t rows, const int* __restrict__ m_total) {
   const int64_t row = blockIdx.x;
   if (row >= rows || (m_total && row >= *m_total)) return;
   const float* src = x + (size_t)row * K;
-  bf16_t* dst = out + (size_t)row * 3 * K;
+  TE* dst = out + (size_t)row * 3 * K;
   for (int c = threadIdx.x * 4; c < K; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
-    bf16x4 hi, lo;
+    typename E16<TE>::v4 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = (bf16_t)(v[e] - (float)hi[e]); }
-    *reinterpret_cast<bf16x4*>(dst + c) = hi;
-    *reinterpret_cast<bf16x4*>(dst + K + c) = WEIGHT ? lo : hi;
-    *reinterpret_cast<bf16x4*>(dst + 2 * K + c) = WEIGHT ? hi : lo;
+    for (int e = 0; e < 4; ++e) { hi[e] = (TE)v[e]; lo[e] = (TE)(v[e] - (float)hi[e]); }
+    *reinterpret_cast<typename E16<TE>::v4*>(dst + c) = hi;
+    *reinterpret_cast<typename E16<TE>::v4*>(dst + K + c) = WEIGHT ? lo : hi;
+    *reinterpret_cast<typename E16<TE>::v4*>(dst + 2 * K + c) = WEIGHT ? hi : lo;
   }
 }
 
@@ -453,10 +453,16 @@ int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const 
   return MANNER_HIP_OK;
 }
 
-int split3_rows(bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream) {
+int split3_rows(DType dt, bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream) {
   if (K % 4) return fail(MANNER_HIP_E_INVALID, "split3: K=%d", K);
-  if (weight) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)rows), dim3(256), 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
-  else hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)rows), dim3(256), 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
+  const dim3 g((unsigned)rows), b(256);
+  if (dt == DT_F16) {
+    if (weight) hipLaunchKernelGGL((split3_kernel<f16_t, true>), g, b, 0, stream, x, static_cast<f16_t*>(out), K, rows, m_total);
+    else hipLaunchKernelGGL((split3_kernel<f16_t, false>), g, b, 0, stream, x, static_cast<f16_t*>(out), K, rows, m_total);
+  } else {
+    if (weight) hipLaunchKernelGGL((split3_kernel<bf16_t, true>), g, b, 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
+    else hipLaunchKernelGGL((split3_kernel<bf16_t, false>), g, b, 0, stream, x, static_cast<bf16_t*>(out), K, rows, m_total);
+  }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
