@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Development aid behind DESIGN.md §2: which rounding points of the 16-bit encoder modes cost how
+much ranking agreement.  A torch-CPU re-statement of the encoder with a `round` inserted exactly where the HIP kernels
+round — GEMM operands (weights and activations), the residual stream, the stored activations (Q|K|V, attention output,
+FFN intermediate) — for bf16 and f16, against the unrounded fp32 computation, on 256 title-profile news and 128
+impressions over them, for both seeded weight sets.  Uses the oracle's embedding function only; not product code.
+
+    python tools/precision_sim.py [n_news]
+"""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import torch.nn.functional as F
+from manner_amd.config import PRESETS
+from manner_amd.weights import make_plm_weights
+from manner_amd.synth import synth_news_tokens, synth_impressions
+import manner_oracle as O
+torch.set_num_threads(8)
+cfg = PRESETS['bert-base-uncased']
+def rnd(t, dt):
+    return t if dt is None else t.to(dt).float()
+def enc(ids, mask, w, op_dt, res_dt, act_dt):
+    # op_dt: GEMM operand dtype; res_dt: residual stream storage; act_dt: stored activations qkv/ctx/ffn
+    ids, mask = torch.from_numpy(ids).long(), torch.from_numpy(mask)
+    w = {k: torch.as_tensor(v) for k, v in w.items()}
+    x = O.embeddings(ids, w, cfg)
+    add = torch.zeros(mask.shape).masked_fill(mask == 0, torch.finfo(torch.float32).min)[:, None, None, :]
+    n, s, h = x.shape; a, d = cfg.heads, cfg.head_dim
+    x = rnd(x, res_dt)
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}."
+        def lin(t, name):
+            return F.linear(rnd(t, op_dt), rnd(w[p+name+".weight"], op_dt), w[p+name+".bias"])
+        q = rnd(lin(x, "attention.self.query"), act_dt).view(n, s, a, d).transpose(1, 2)
+        k = rnd(lin(x, "attention.self.key"), act_dt).view(n, s, a, d).transpose(1, 2)
+        v = rnd(lin(x, "attention.self.value"), act_dt).view(n, s, a, d).transpose(1, 2)
+        att = F.softmax(q @ k.transpose(2, 3) * d ** -0.5 + add, -1)
+        ctx = rnd((rnd(att, op_dt) @ v).transpose(1, 2).reshape(n, s, h), act_dt)
+        x = rnd(F.layer_norm(lin(ctx, "attention.output.dense") + x, (h,), w[p+"attention.output.LayerNorm.weight"], w[p+"attention.output.LayerNorm.bias"], cfg.ln_eps), res_dt)
+        inter = rnd(F.gelu(lin(x, "intermediate.dense")), act_dt)
+        x = rnd(F.layer_norm(lin(inter, "output.dense") + x, (h,), w[p+"output.LayerNorm.weight"], w[p+"output.LayerNorm.bias"], cfg.ln_eps), res_dt)
+    return x[:, 0].contiguous()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ids, mask = synth_news_tokens(N, cfg, seed=42, max_len=96, profile='title')
+imp = synth_impressions(128, N, seed=5)
+def scores(tab):
+    out = []
+    for i in range(128):
+        h = tab[imp['hist_idx'][imp['hist_off'][i]:imp['hist_off'][i+1]].astype(np.int64)].mean(0)
+        c = tab[imp['cand_idx'][imp['cand_off'][i]:imp['cand_off'][i+1]].astype(np.int64)]
+        out.append(c @ h)
+    return out
+for std in (0.02, 0.05):
+    w = make_plm_weights(cfg, seed=42, std=std)
+    with torch.no_grad():
+        ref = enc(ids, mask, w, None, None, None)
+        sref = scores(ref)
+        for name, (o, r, a_) in {"bf16 all": (torch.bfloat16,)*3, "bf16 ops, f32 resid": (torch.bfloat16, None, torch.bfloat16),
+                                 "bf16 ops only (f32 resid+acts)": (torch.bfloat16, None, None),
+                                 "f16 all": (torch.float16,)*3, "f16 ops, f32 resid": (torch.float16, None, torch.float16)}.items():
+            t = enc(ids, mask, w, o, r, a_)
+            s = scores(t)
+            agree = np.mean([torch.equal(torch.argsort(x, descending=True, stable=True)[:10], torch.argsort(y, descending=True, stable=True)[:10]) for x, y in zip(s, sref)])
+            serr = max(float((x-y).abs().max()) for x, y in zip(s, sref))
+            print(f"std {std} {name:34s} emb max err {float((t-ref).abs().max()):.3e}  score err {serr:.3e} (scale {float(sref[0].abs().max()):.0f}) top10 agree {agree:.3f}", flush=True)
