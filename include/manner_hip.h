@@ -125,7 +125,10 @@ size_t manner_hip_encoder_workspace_bytes(manner_hip_encoder_t enc, int64_t max_
  *               see manner_hip_encoder_status);
  *   host_lengths : optional host int32 [n_news] copy of the row sums of `mask`.  With it the
  *               launch grids are exact; without it (NULL) grids cover n_news*padded_len tokens
- *               and surplus workgroups exit early.  No host synchronisation either way;
+ *               and surplus workgroups exit early.  No host synchronisation either way.  The lengths only
+ *               size the chunks: the device derives its own from `mask`, and if the two disagree it raises
+ *               MANNER_HIP_STATUS_LENGTHS and drops the tokens beyond the chunk's bound instead of writing
+ *               past the workspace;
  *   out       : float32 [n_news, H].
  * News are processed in internal chunks that fit the workspace; padding tokens cost no FLOPs
  * (tokens are packed; SURVEY.md Q5 makes this equivalent to the padded reference computation). */
