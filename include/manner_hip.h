@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 2
+#define MANNER_HIP_ABI_VERSION 3
 
 enum {
   MANNER_HIP_OK = 0,
@@ -331,6 +331,51 @@ int manner_hip_collate_aspects(const int32_t* category, const int32_t* sentiment
  * scores / labels f32 [cand_off[B]], cand_off int64 [B+1], losses f32 [B]. */
 int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t mode,
                          float temperature, int64_t c_max, float* losses, manner_hip_stream_t stream);
+
+/* ---- the training path of MannerTextEncoder (train.hip) -------------------------------------------------
+ * Replaces, for the CR-/A-Module training step (manner/models/cr_module.py:140-171 -> news_encoder.py:29-37 in train()
+ * mode, then loss.backward()): the HF BertModel / RobertaModel forward WITH its dropouts (embeddings, attention
+ * probabilities, attention output, FFN output: modeling_bert.py:107,140,183,351), MannerTextEncoder's own dropout on the
+ * [CLS] vector (news_encoder.py:35), and the autograd backward down to the parameter gradients.
+ *
+ *   weights : HOST array of n_weights device pointers (f32, the order of manner_hip_encoder_create) — the live master
+ *             parameters, read at every call (nothing is cached between optimiser steps);
+ *   ids / mask / n_news / padded_len : as manner_hip_encode_cls (padded_len <= 256);
+ *   m_bound : rows every activation buffer holds: a multiple of 256, >= the number of real tokens (n_news * padded_len
+ *             rounded up always works; a device-side check raises MANNER_HIP_STATUS_LENGTHS otherwise);
+ *   precision : MANNER_HIP_PREC_F32 (f32 MFMA GEMMs) or _F16 / _BF16 (GEMM operands rounded to 16 bits, f32 accumulation,
+ *             f32 activations — "16-mixed"); activations, gradients and everything that is not a GEMM are f32;
+ *   start_layer / prefix_hidden : 0 / NULL runs embeddings + all layers in training mode.  start_layer = f > 0 starts
+ *             from prefix_hidden = hidden_states[f] ([n_news, padded_len, H] f32, e.g. manner_hip_encode_hidden of the
+ *             frozen layers) — valid when no tensor below layer f receives a gradient;
+ *   p_hidden / p_attn / p_out : hidden_dropout_prob, attention_probs_dropout_prob, MannerTextEncoder.dropout.p; 0 = off;
+ *   seed    : dropout masks are a pure function of (seed, site, element index); the backward call must repeat the
+ *             forward call's seed and probabilities.  manner_hip_dropout_mask returns the keep-bits of one site
+ *             (site 0: embeddings over [m, H]; 1: [CLS] output over [n_news, H]; 8*(layer+1)+0: attention
+ *             probabilities over [(m*heads + head)*256 + key]; +1: attention output; +2: FFN output, over [m, H]);
+ *   saved   : manner_hip_train_saved_bytes(cfg, n_news, m_bound, start_layer) bytes that carry the activations from the
+ *             forward to the backward call;  workspace: manner_hip_train_workspace_bytes(cfg, m_bound) bytes of scratch;
+ *   cls_out : f32 [n_news, H].
+ * Backward: grad_cls f32 [n_news, H]; grads = HOST array of n_weights device pointers, NULL where no gradient is
+ * wanted (requires_grad = False; a LayerNorm's weight and bias come together); each non-NULL tensor is OVERWRITTEN with
+ * d loss / d parameter.  The activation gradient travels as far down as a requested gradient needs — through frozen
+ * layers into the embedding tables when an embedding tensor is trainable, which is the reference's default
+ * (news_encoder.py:24-27 freezes "layer.N." parameters only).  grad_prefix (optional, start_layer > 0): f32
+ * [n_news, padded_len, H] gradient of prefix_hidden.  Embedding-table gradients use f32 atomics (summation order, hence
+ * the last bits, vary between runs — as torch's CUDA embedding backward). */
+size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer);
+size_t manner_hip_train_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t m_bound);
+int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
+                             const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
+                             int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
+                             float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
+                             size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream);
+int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
+                              const int64_t* ids, int64_t n_news, int64_t padded_len, int64_t m_bound, int32_t precision,
+                              int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed,
+                              const float* grad_cls, void* saved, size_t saved_bytes, float* const* grads /*host*/,
+                              float* grad_prefix, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
+int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, manner_hip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -759,7 +759,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     // every read of this step's stages has completed; the NEXT step's tiles have landed: waves 0-3 wait
     // for all their DMA, waves 4-7 leave the 8 newest pieces (two steps ahead) in flight
     if (MODE <= 1) {
-      if (is_w) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // (the last tile's second-to-last step has no younger DMA behind the pieces the last step reads: wait for all)
+      if (is_w || (MODE == 1 && !has_next)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

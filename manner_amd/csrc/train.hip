@@ -1,0 +1,902 @@
+// the TRAINING path of MannerTextEncoder — forward in train() mode (HF BertModel/RobertaModel with its three
+// dropouts per layer, reference manner/models/components/news_encoder.py:24-37; the model_step that drives it is
+// manner/models/cr_module.py:140-171, a_module.py:102-108) and the backward pass down to the parameter gradients.
+//
+// Layout: the same packed-token layout as the inference engine (row m = cu[n] + t for the real tokens of news n; padded
+// positions never influence a [CLS] output or a gradient, so they are not computed).  Activations and gradients are
+// f32; the twelve GEMMs of a layer (4 forward, 4 data-gradient, 4 weight-gradient) go through gemm.hip's MFMA kernels
+// — on f32 operands in the "fp32" mode (what the gradient-parity tests use) or on f16 / bf16 copies of the operands with
+// f32 accumulation and f32 outputs ("16-mixed", the reference's trainer precision, configs/trainer/default.yaml:12).
+// Everything else is an HBM-bound elementwise / row-reduction kernel written here.  Dropout masks come from a
+// counter-based generator keyed by (seed, site, element index): the backward pass regenerates them instead of storing
+// them, and manner_hip_dropout_mask hands the very same bits to the tests' oracle.
+//
+// Parameter gradients are produced for the tensors whose entry in the `grads` table is non-NULL; activation gradients
+// are propagated exactly as far down as some requested gradient needs them (to the embeddings when an embedding
+// tensor is trainable — the reference freezes "layer.N." parameters only, news_encoder.py:24-27, so by default the
+// backward pass runs through the frozen layers into the embedding tables — or to `start_layer` when the caller
+// supplies cached hidden states of a frozen prefix).
+#include <math.h>
+
+#include "common.h"
+
+namespace manner {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ dropout bits
+// splitmix64 over (seed, site, index): 32 uniform bits; an element is KEPT when bits >= thr, thr = p * 2^32.
+__host__ __device__ __forceinline__ uint32_t drop_bits(uint64_t seed, uint32_t site, uint64_t idx) {
+  uint64_t z = (seed ^ ((uint64_t)site * 0xD6E8FEB86659FD93ull)) + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+struct Drop {
+  uint64_t seed;
+  uint32_t site, thr;
+  float scale;          // 1 / (1 - p)
+  __host__ __device__ __forceinline__ float apply(float v, uint64_t idx) const {
+    return (thr == 0 || drop_bits(seed, site, idx) >= thr) ? v * scale : 0.f;
+  }
+};
+Drop make_drop(uint64_t seed, uint32_t site, float p) {
+  Drop d;
+  d.seed = seed;
+  d.site = site;
+  const double t = (double)p * 4294967296.0;
+  d.thr = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
+  d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
+  return d;
+}
+// dropout sites of a layer (site = 8 * (layer + 1) + k; site 0..7 belong to the embeddings / the [CLS] output)
+enum { SITE_EMB = 0, SITE_CLS = 1, SITE_ATTN = 0, SITE_PROJ = 1, SITE_FFN = 2 };
+__host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (uint32_t)(layer + 1) + (uint32_t)k; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// e[cu[n]+t] = word[id] + pos[t + pos_offset] + type[0]            (modeling_bert.py:68-108 without LN / dropout)
+__global__ __launch_bounds__(256) void embed_sum_kernel(const int64_t* __restrict__ ids, int64_t n_news, int lp,
+                                                        const int32_t* __restrict__ cu, const float* __restrict__ word,
+                                                        const float* __restrict__ pos, const float* __restrict__ type0, int H,
+                                                        int pos_offset, int vocab, int max_pos, float* __restrict__ e,
+                                                        int32_t* __restrict__ status) {
+  const int64_t idx = blockIdx.x;
+  const int64_t n = idx / lp;
+  const int t = (int)(idx - n * lp);
+  const int len = cu[n + 1] - cu[n];
+  if (t >= len) return;
+  int64_t id = ids[n * lp + t];
+  int p = t + pos_offset;
+  if (id < 0 || id >= vocab) { if (threadIdx.x == 0 && status) atomicOr(status, MANNER_HIP_STATUS_TOKEN); id = 0; }
+  if (p >= max_pos) { if (threadIdx.x == 0 && status) atomicOr(status, MANNER_HIP_STATUS_TOKEN); p = max_pos - 1; }
+  float* dst = e + (size_t)(cu[n] + t) * H;
+  const float* w = word + (size_t)id * H;
+  const float* ps = pos + (size_t)p * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[c] = w[c] + ps[c] + type0[c];
+}
+
+// d word[id] += de[m], d pos[p] += de[m]   (f32 atomics: rows repeat across news; the token-type row is a column sum)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t n_news, int lp,
+                                                        const int32_t* __restrict__ cu, const float* __restrict__ de, int H,
+                                                        int pos_offset, int vocab, int max_pos, float* __restrict__ dword,
+                                                        float* __restrict__ dpos) {
+  const int64_t idx = blockIdx.x;
+  const int64_t n = idx / lp;
+  const int t = (int)(idx - n * lp);
+  const int len = cu[n + 1] - cu[n];
+  if (t >= len) return;
+  int64_t id = ids[n * lp + t];
+  int p = t + pos_offset;
+  if (id < 0 || id >= vocab) id = 0;
+  if (p >= max_pos) p = max_pos - 1;
+  const float* src = de + (size_t)(cu[n] + t) * H;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = src[c];
+    if (dword) atomicAdd(dword + (size_t)id * H + c, g);
+    if (dpos) atomicAdd(dpos + (size_t)p * H + c, g);
+  }
+}
+
+// x[cu[n]+t] = hidden[n, t]  (cached frozen-prefix activations, [N, Lp, H] f32 -> packed rows) and its inverse for the
+// gradient of the prefix
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ padded, float* __restrict__ packed,
+                                                        int64_t n_news, int lp, const int32_t* __restrict__ cu, int H,
+                                                        int to_padded) {
+  const int64_t idx = blockIdx.x;
+  const int64_t n = idx / lp;
+  const int t = (int)(idx - n * lp);
+  const int len = cu[n + 1] - cu[n];
+  if (to_padded) {
+    float* dst = const_cast<float*>(padded) + (size_t)idx * H;
+    const float* src = packed + (size_t)(cu[n] + t) * H;
+    for (int c = threadIdx.x; c < H; c += 256) dst[c] = t < len ? src[c] : 0.f;
+  } else if (t < len) {
+    const float* src = padded + (size_t)idx * H;
+    float* dst = packed + (size_t)(cu[n] + t) * H;
+    for (int c = threadIdx.x; c < H; c += 256) dst[c] = src[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; H <= 64 * LN_MAX
+constexpr int LN_MAX = 16;
+
+// y = dropout( LN(x) ), stats = {mean, rstd}
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int H, float eps, float* __restrict__ y,
+                                                     float2* __restrict__ stats, const int* __restrict__ m_total, Drop drop) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= m_total[0]) return;
+  const float* row = x + (size_t)m * H;
+  float v[LN_MAX];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < H ? row[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < H ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);      // biased variance, as F.layer_norm
+  if (lane == 0) stats[m] = float2{mean, rstd};
+  float* out = y + (size_t)m * H;
+#pragma unroll
+  for (int i = 0; i < LN_MAX; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H) out[c] = drop.apply(fmaf((v[i] - mean) * rstd, gamma[c], beta[c]), (uint64_t)m * H + c);
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial sums of dgamma = dy * xhat and
+// dbeta = dy over the rows this block visits (deterministic second stage: reduce_partials_kernel).
+// `dy` may alias `dx`.
+constexpr int LN_BWD_BLOCKS = 256;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ x,
+                                                     const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
+                                                     float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
+                                                     const int* __restrict__ m_total) {
+  __shared__ float red[4][64 * LN_MAX + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t M = m_total[0];
+  float ag[LN_MAX], ab[LN_MAX], gm[LN_MAX];
+#pragma unroll
+  for (int i = 0; i < LN_MAX; ++i) {
+    ag[i] = ab[i] = 0.f;
+    const int c = lane + 64 * i;
+    gm[i] = c < H ? gamma[c] : 0.f;
+  }
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < M; m += (int64_t)gridDim.x * 4) {
+    const float2 st = stats[m];
+    const float* xr = x + (size_t)m * H;
+    const float* gr = dy + (size_t)m * H;
+    float xh[LN_MAX], g[LN_MAX];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < H ? gr[c] : 0.f;
+      xh[i] = c < H ? (xr[c] - st.x) * st.y : 0.f;
+      g[i] = d * gm[i];
+      ag[i] = fmaf(d, xh[i], ag[i]);
+      ab[i] += d;
+      s1 += g[i];
+      s2 = fmaf(g[i], xh[i], s2);
+    }
+    const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+    float* out = dx + (size_t)m * H;
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H) out[c] = st.y * (g[i] - c1 - xh[i] * c2);
+    }
+  }
+  if (!pgamma) return;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i) red[wave][lane + 64 * i] = pass ? ab[i] : ag[i];
+    __syncthreads();
+    float* dst = (pass ? pbeta : pgamma) + (size_t)blockIdx.x * H;
+    for (int c = threadIdx.x; c < H; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// out[c] = sum_b partial[b][c]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int width,
+                                                              float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * width + c];
+  out[c] = s;
+}
+
+// partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
+constexpr int COLSUM_BLOCKS = 128;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int width, float* __restrict__ partial,
+                                                     const int* __restrict__ m_total) {
+  const int64_t M = m_total[0];
+  for (int c = threadIdx.x; c < width; c += 256) {
+    float s = 0.f;
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) s += y[(size_t)m * width + c];
+    partial[(size_t)blockIdx.x * width + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+// out = dropout(a) [+ res]; rows >= *m_total untouched
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* a, const float* res, float* out, int width,
+                                                          const int* __restrict__ m_total, Drop drop) {
+  const int64_t total = (int64_t)m_total[0] * width;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = drop.apply(a[i], (uint64_t)i);
+    out[i] = res ? v + res[i] : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* a, const float* b, float* out, int width,
+                                                       const int* __restrict__ m_total) {
+  const int64_t total = (int64_t)m_total[0] * width;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}
+// mode 0: out = gelu(a); mode 1: out = b * gelu'(a)
+__global__ __launch_bounds__(256) void gelu_kernel(const float* a, const float* b, float* out, int width,
+                                                   const int* __restrict__ m_total, int mode) {
+  const int64_t total = (int64_t)m_total[0] * width;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    out[i] = mode ? b[i] * gelu_grad(a[i]) : gelu_exact(a[i]);
+}
+
+// out[n] = dropout(x[cu[n]])  ([CLS] rows; news_encoder.py:34-35) — and the scatter of its gradient
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu, int H,
+                                                  float* __restrict__ out, Drop drop) {
+  const int64_t n = blockIdx.x;
+  const float* src = x + (size_t)cu[n] * H;
+  for (int c = threadIdx.x; c < H; c += 256) out[(size_t)n * H + c] = drop.apply(src[c], (uint64_t)n * H + c);
+}
+__global__ __launch_bounds__(256) void cls_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ cu, int H,
+                                                      float* __restrict__ dx, Drop drop) {
+  const int64_t n = blockIdx.x;
+  float* dst = dx + (size_t)cu[n] * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[c] = drop.apply(g[(size_t)n * H + c], (uint64_t)n * H + c);
+}
+
+// out[c][r] = T(in[r][c]) for r < rows_valid, 0 for rows_valid <= r < rows_out  (operands of the gradient GEMMs)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t cols, T* __restrict__ out,
+                                                        int64_t rows_out, const int* __restrict__ rows_valid_dev,
+                                                        int64_t rows_valid_host) {
+  __shared__ float tile[32][33];
+  const int64_t rv = rows_valid_dev ? (int64_t)rows_valid_dev[0] : rows_valid_host;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < rv && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < cols && r < rows_out) out[(size_t)c * rows_out + r] = (T)tile[tx][ty + 8 * k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention (train)
+// qkv [m, 3H] = [Q | K | V]; one workgroup per (head, news), thread i owns query row i (S <= 256), keys in chunks of
+// KC through LDS.  P = softmax(q k^T / 8), Pd = dropout(P) (modeling_bert.py:128-140: dropout on the probabilities),
+// ctx = Pd v.  The forward keeps {row max, row sum} so the backward rebuilds P without a reduction pass.
+constexpr int AD = 64, KC = 32, AT = 256;
+
+__global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                            float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
+                                                            int H, Drop drop) {
+  __shared__ float ks[KC][AD], vs[KC][AD];
+  const int h = blockIdx.x;
+  const int64_t n = blockIdx.y;
+  const int base = cu[n], S = cu[n + 1] - base;
+  const int i = threadIdx.x;
+  const bool active = i < S;
+  const size_t ld = (size_t)3 * H;
+  float q[AD], o[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { q[d] = active ? qkv[(size_t)(base + i) * ld + h * AD + d] * 0.125f : 0.f; o[d] = 0.f; }
+  float mx = -INFINITY, l = 0.f;
+  for (int j0 = 0; j0 < S; j0 += KC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < KC * AD; e += AT) {
+      const int j = e / AD, d = e - j * AD;
+      const bool ok = j0 + j < S;
+      ks[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + H + h * AD + d] : 0.f;
+      vs[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + 2 * H + h * AD + d] : 0.f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int cnt = min(KC, S - j0);
+    for (int j = 0; j < cnt; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) s = fmaf(q[d], ks[j][d], s);
+      if (s > mx) {
+        const float f = expf(mx - s);
+        l *= f;
+#pragma unroll
+        for (int d = 0; d < AD; ++d) o[d] *= f;
+        mx = s;
+      }
+      const float p = expf(s - mx);
+      l += p;
+      const float pd = drop.apply(p, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
+#pragma unroll
+      for (int d = 0; d < AD; ++d) o[d] = fmaf(pd, vs[j][d], o[d]);
+    }
+  }
+  if (!active) return;
+  const float inv = 1.f / l;
+  float* dst = ctx + (size_t)(base + i) * H + h * AD;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) dst[d] = o[d] * inv;
+  ml[(size_t)(base + i) * heads + h] = float2{mx, l};
+}
+
+// query-row owner: D_i = sum_j dP_ij P_ij, then dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
+__global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                              const float2* __restrict__ ml, float* __restrict__ dqkv,
+                                                              float* __restrict__ dsum, const int32_t* __restrict__ cu,
+                                                              int heads, int H, Drop drop) {
+  __shared__ float ks[KC][AD], vs[KC][AD];
+  const int h = blockIdx.x;
+  const int64_t n = blockIdx.y;
+  const int base = cu[n], S = cu[n + 1] - base;
+  const int i = threadIdx.x;
+  const bool active = i < S;
+  const size_t ld = (size_t)3 * H;
+  float q[AD], go[AD], dq[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) {
+    q[d] = active ? qkv[(size_t)(base + i) * ld + h * AD + d] * 0.125f : 0.f;
+    go[d] = active ? dctx[(size_t)(base + i) * H + h * AD + d] : 0.f;
+    dq[d] = 0.f;
+  }
+  const float2 st = active ? ml[(size_t)(base + i) * heads + h] : float2{0.f, 1.f};
+  const float inv = 1.f / st.y;
+  float D = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int j0 = 0; j0 < S; j0 += KC) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < KC * AD; e += AT) {
+        const int j = e / AD, d = e - j * AD;
+        const bool ok = j0 + j < S;
+        ks[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + H + h * AD + d] : 0.f;
+        vs[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + 2 * H + h * AD + d] : 0.f;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int cnt = min(KC, S - j0);
+      for (int j = 0; j < cnt; ++j) {
+        float s = 0.f, gv = 0.f;
+#pragma unroll
+        for (int d = 0; d < AD; ++d) { s = fmaf(q[d], ks[j][d], s); gv = fmaf(go[d], vs[j][d], gv); }
+        const float p = expf(s - st.x) * inv;
+        const float dp = drop.apply(gv, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
+        if (pass == 0) {
+          D = fmaf(dp, p, D);
+        } else {
+          const float ds = p * (dp - D) * 0.125f;
+#pragma unroll
+          for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, ks[j][d], dq[d]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  float* dst = dqkv + (size_t)(base + i) * ld + h * AD;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) dst[d] = dq[d];
+  dsum[(size_t)(base + i) * heads + h] = D;
+}
+
+// key-row owner: dk_j = sum_i dS_ij q_i / 8, dv_j = sum_i Pd_ij dctx_i
+__global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                               const float2* __restrict__ ml, const float* __restrict__ dsum,
+                                                               float* __restrict__ dqkv, const int32_t* __restrict__ cu,
+                                                               int heads, int H, Drop drop) {
+  __shared__ float qs[KC][AD], gs[KC][AD];
+  __shared__ float sm[KC], sl[KC], sd[KC];
+  const int h = blockIdx.x;
+  const int64_t n = blockIdx.y;
+  const int base = cu[n], S = cu[n + 1] - base;
+  const int j = threadIdx.x;
+  const bool active = j < S;
+  const size_t ld = (size_t)3 * H;
+  float k[AD], v[AD], dk[AD], dv[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) {
+    k[d] = active ? qkv[(size_t)(base + j) * ld + H + h * AD + d] : 0.f;
+    v[d] = active ? qkv[(size_t)(base + j) * ld + 2 * H + h * AD + d] : 0.f;
+    dk[d] = dv[d] = 0.f;
+  }
+  for (int i0 = 0; i0 < S; i0 += KC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < KC * AD; e += AT) {
+      const int i = e / AD, d = e - i * AD;
+      const bool ok = i0 + i < S;
+      qs[i][d] = ok ? qkv[(size_t)(base + i0 + i) * ld + h * AD + d] * 0.125f : 0.f;
+      gs[i][d] = ok ? dctx[(size_t)(base + i0 + i) * H + h * AD + d] : 0.f;
+    }
+    if (threadIdx.x < KC) {
+      const bool ok = i0 + threadIdx.x < S;
+      const float2 st = ok ? ml[(size_t)(base + i0 + threadIdx.x) * heads + h] : float2{0.f, 1.f};
+      sm[threadIdx.x] = st.x;
+      sl[threadIdx.x] = 1.f / st.y;
+      sd[threadIdx.x] = ok ? dsum[(size_t)(base + i0 + threadIdx.x) * heads + h] : 0.f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int cnt = min(KC, S - i0);
+    for (int i = 0; i < cnt; ++i) {
+      float s = 0.f, gv = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { s = fmaf(qs[i][d], k[d], s); gv = fmaf(gs[i][d], v[d], gv); }
+      const float p = expf(s - sm[i]) * sl[i];
+      const uint64_t idx = ((uint64_t)(base + i0 + i) * heads + h) * 256 + (uint64_t)j;
+      const float dp = drop.apply(gv, idx);
+      const float pd = drop.apply(p, idx);
+      const float ds = p * (dp - sd[i]);         // qs already carries the 1/8
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { dk[d] = fmaf(ds, qs[i][d], dk[d]); dv[d] = fmaf(pd, gs[i][d], dv[d]); }
+    }
+  }
+  if (!active) return;
+  float* dkp = dqkv + (size_t)(base + j) * ld + H + h * AD;
+  float* dvp = dqkv + (size_t)(base + j) * ld + 2 * H + h * AD;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
+}
+
+__global__ void mask_kernel(uint8_t* out, int64_t n, Drop drop) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = (drop.thr == 0 || drop_bits(drop.seed, drop.site, (uint64_t)i) >= drop.thr) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Bump {
+  char* base;
+  size_t off = 0;
+  explicit Bump(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (size_t)round_up((int64_t)off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct LayerSaved {
+  float *x_in, *qkv, *ctx, *r1, *h1, *inter, *g, *r2;
+  float2 *st1, *st2, *ml;
+};
+struct Saved {
+  int32_t *lens, *cu, *m_total;
+  float* esum;      // start_layer == 0 only
+  float2* st0;
+  LayerSaved l[64];
+};
+void plan_saved(Bump& b, Saved& s, const manner_hip_encoder_config& c, int64_t N, int64_t Mb, int start) {
+  const size_t H = c.hidden, I = c.intermediate;
+  s.lens = b.take<int32_t>(N);
+  s.cu = b.take<int32_t>(N + 1);
+  s.m_total = b.take<int32_t>(4);
+  s.esum = start == 0 ? b.take<float>(Mb * H) : nullptr;
+  s.st0 = start == 0 ? b.take<float2>(Mb) : nullptr;
+  for (int l = start; l < c.layers; ++l) {
+    LayerSaved& L = s.l[l];
+    L.x_in = b.take<float>(Mb * H);
+    L.qkv = b.take<float>(Mb * 3 * H);
+    L.ctx = b.take<float>(Mb * H);
+    L.r1 = b.take<float>(Mb * H);
+    L.h1 = b.take<float>(Mb * H);
+    L.inter = b.take<float>(Mb * I);
+    L.g = b.take<float>(Mb * I);
+    L.r2 = b.take<float>(Mb * H);
+    L.st1 = b.take<float2>(Mb);
+    L.st2 = b.take<float2>(Mb);
+    L.ml = b.take<float2>(Mb * c.heads);
+  }
+}
+
+struct Work {
+  void *a16, *b16;                 // operand copies (16-bit modes) / transposed operands (all modes): each max(I,3H) * max(Mb, H) elements of 4 bytes
+  float *wcat, *bcat, *zero, *tmp; // [3H, H] concatenated Q|K|V weight, its bias, a zero bias, one [Mb, max(I,3H)] temporary
+  float *dx, *dr, *dbig, *dqkv, *dsum, *dw, *part;
+  int32_t* dims;                   // device ints holding row counts of the weight-gradient GEMMs
+};
+void plan_work(Bump& b, Work& w, const manner_hip_encoder_config& c, int64_t Mb) {
+  const size_t H = c.hidden, I = c.intermediate;
+  const size_t wide = I > 3 * H ? I : 3 * H;
+  const size_t rows = (size_t)Mb > wide ? (size_t)Mb : wide;
+  w.a16 = b.take<float>(wide * rows);
+  w.b16 = b.take<float>(wide * rows);
+  w.wcat = b.take<float>(3 * H * H);
+  w.bcat = b.take<float>(3 * H);
+  w.zero = b.take<float>(wide);
+  w.tmp = b.take<float>(Mb * wide);
+  w.dx = b.take<float>(Mb * H);
+  w.dr = b.take<float>(Mb * H);
+  w.dbig = b.take<float>(Mb * wide);
+  w.dqkv = b.take<float>(Mb * 3 * H);
+  w.dsum = b.take<float>(Mb * c.heads);
+  w.dw = b.take<float>(wide * (I > H ? I : H));
+  w.part = b.take<float>(2 * (size_t)LN_BWD_BLOCKS * wide);
+  w.dims = b.take<int32_t>(16);
+}
+
+int check_cfg(const manner_hip_encoder_config* c, int64_t N, int64_t Lp, int64_t Mb, int32_t precision, int start) {
+  if (!c) return fail(MANNER_HIP_E_INVALID, "train: null config");
+  if (c->hidden % 128 || c->intermediate % 128 || c->hidden / c->heads != AD || c->hidden % c->heads || c->hidden > 64 * LN_MAX ||
+      c->layers <= 0 || c->layers > 64)
+    return fail(MANNER_HIP_E_INVALID, "train: unsupported architecture H=%d I=%d heads=%d layers=%d", c->hidden, c->intermediate,
+                c->heads, c->layers);
+  if (N <= 0 || Lp <= 0 || Lp > 256) return fail(MANNER_HIP_E_INVALID, "train: n_news=%lld padded_len=%lld (padded_len <= 256)", (long long)N, (long long)Lp);
+  if (Mb <= 0 || Mb % 256 || Mb > 0x7fffff00ll / (3 * (int64_t)c->hidden)) return fail(MANNER_HIP_E_INVALID, "train: m_bound=%lld must be a positive multiple of 256 within int range", (long long)Mb);
+  if (precision != MANNER_HIP_PREC_F32 && precision != MANNER_HIP_PREC_BF16 && precision != MANNER_HIP_PREC_F16)
+    return fail(MANNER_HIP_E_INVALID, "train: precision %d (fp32, bf16, f16)", precision);
+  if (start < 0 || start >= c->layers) return fail(MANNER_HIP_E_INVALID, "train: start_layer %d of %d layers", start, c->layers);
+  return MANNER_HIP_OK;
+}
+
+struct Ctx {
+  const manner_hip_encoder_config* c;
+  const float* const* w;
+  int64_t N, Lp, Mb;
+  int prec;
+  hipStream_t s;
+  Saved sv;
+  Work wk;
+  const float* emb(int i) const { return w[i]; }
+  const float* lw(int l, int i) const { return w[MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + i]; }
+  DType dt() const { return prec == MANNER_HIP_PREC_F32 ? DT_F32 : prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_BF16; }
+  unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
+};
+
+// Y [Mb, Nout] = X [Mb, K] . W [Nout, K]^T + bias      (f32 in / out; operands rounded to the 16-bit type in the mixed modes)
+int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float* Y, int Nout, int K) {
+  int rc;
+  if (t.dt() == DT_F32) return gemm_tn(DT_F32, DT_F32, EPI_BIAS, X, W, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
+  if ((rc = convert_f32_to_16(t.dt(), X, t.wk.a16, t.Mb * K, t.s))) return rc;
+  if ((rc = convert_f32_to_16(t.dt(), W, t.wk.b16, (int64_t)Nout * K, t.s))) return rc;
+  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, t.wk.a16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
+}
+
+template <typename T>
+void launch_transpose(const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host,
+                      hipStream_t s) {
+  (void)rows_in;
+  dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows_out + 31) / 32));
+  hipLaunchKernelGGL(transpose_kernel<T>, g, dim3(256), 0, s, in, cols, static_cast<T*>(out), rows_out, rv_dev, rv_host);
+}
+int transpose_to(Ctx& t, const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host) {
+  if (t.dt() == DT_F32) launch_transpose<float>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
+  else if (t.dt() == DT_F16) launch_transpose<f16_t>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
+  else launch_transpose<bf16_t>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+// dX [Mb, K] = dY [Mb, Nout] . W [Nout, K]
+int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, int K) {
+  int rc;
+  if ((rc = transpose_to(t, W, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc;       // W^T [K, Nout]
+  const void* x = dY;
+  if (t.dt() != DT_F32) {
+    if ((rc = convert_f32_to_16(t.dt(), dY, t.wk.a16, t.Mb * Nout, t.s))) return rc;
+    x = t.wk.a16;
+  }
+  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, x, t.wk.b16, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
+}
+
+// dW [Nout, K] = dY [Mb, Nout]^T . X [Mb, K]   (the reduction runs over the token rows; rows >= *m_total contribute zeros)
+int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, int K, int dim_slot) {
+  int rc;
+  if ((rc = transpose_to(t, dY, t.Mb, Nout, t.wk.a16, t.Mb, t.sv.m_total, 0))) return rc;  // dY^T [Nout, Mb]
+  if ((rc = transpose_to(t, X, t.Mb, K, t.wk.b16, t.Mb, t.sv.m_total, 0))) return rc;      // X^T  [K, Mb]
+  if ((rc = set_device_int(t.wk.dims + dim_slot, Nout, t.s))) return rc;
+  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, t.wk.a16, t.wk.b16, t.wk.zero, nullptr, dW, Nout, K, (int)t.Mb, t.wk.dims + dim_slot, t.s);
+}
+
+int bias_grad(Ctx& t, const float* dY, int width, float* db) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(COLSUM_BLOCKS), dim3(256), 0, t.s, dY, width, t.wk.part, t.sv.m_total);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.part, COLSUM_BLOCKS, width, db);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int ln_forward(Ctx& t, const float* x, const float* g, const float* b, float* y, float2* st, Drop drop) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)(t.Mb / 4)), dim3(256), 0, t.s, x, g, b, t.c->hidden, t.c->ln_eps, y, st, t.sv.m_total, drop);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const float* gamma, float* dx, float* dgamma, float* dbeta) {
+  const int H = t.c->hidden;
+  float* pg = dgamma ? t.wk.part : nullptr;
+  float* pb = dgamma ? t.wk.part + (size_t)LN_BWD_BLOCKS * H : nullptr;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total);
+  MANNER_LAUNCH_CHECK();
+  if (dgamma) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, t.s, pg, LN_BWD_BLOCKS, H, dgamma);
+    MANNER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, t.s, pb, LN_BWD_BLOCKS, H, dbeta);
+    MANNER_LAUNCH_CHECK();
+  }
+  return MANNER_HIP_OK;
+}
+int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop) {
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+int add_rows(Ctx& t, const float* a, const float* b, float* out, int width) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, b, out, width, t.sv.m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int pack_qkv_weights(Ctx& t, int l) {
+  const size_t H = t.c->hidden;
+  for (int k = 0; k < 3; ++k) {
+    MANNER_HIP_TRY(hipMemcpyAsync(t.wk.wcat + k * H * H, t.lw(l, MANNER_HIP_WL_Q_W + 2 * k), H * H * sizeof(float), hipMemcpyDeviceToDevice, t.s));
+    MANNER_HIP_TRY(hipMemcpyAsync(t.wk.bcat + k * H, t.lw(l, MANNER_HIP_WL_Q_B + 2 * k), H * sizeof(float), hipMemcpyDeviceToDevice, t.s));
+  }
+  return MANNER_HIP_OK;
+}
+
+int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, int64_t N, int64_t Lp, int64_t Mb,
+          int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s) {
+  int rc;
+  if ((rc = check_cfg(cfg, N, Lp, Mb, precision, start))) return rc;
+  if (!weights || n_weights != MANNER_HIP_W_EMB_COUNT + cfg->layers * MANNER_HIP_WL_COUNT)
+    return fail(MANNER_HIP_E_INVALID, "train: weight table has %d entries, the architecture needs %d", n_weights,
+                MANNER_HIP_W_EMB_COUNT + cfg->layers * MANNER_HIP_WL_COUNT);
+  for (int i = 0; i < n_weights; ++i)
+    if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "train: weight %d is NULL", i);
+  if (!saved || !ws) return fail(MANNER_HIP_E_INVALID, "train: null buffer");
+  t.c = cfg; t.w = weights; t.N = N; t.Lp = Lp; t.Mb = Mb; t.prec = precision; t.s = s;
+  Bump bs(saved), bw(ws);
+  plan_saved(bs, t.sv, *cfg, N, Mb, start);
+  plan_work(bw, t.wk, *cfg, Mb);
+  if (bs.off > saved_bytes) return fail(MANNER_HIP_E_WORKSPACE, "train: saved buffer %zu < %zu bytes", saved_bytes, bs.off);
+  if (bw.off > ws_bytes) return fail(MANNER_HIP_E_WORKSPACE, "train: workspace %zu < %zu bytes", ws_bytes, bw.off);
+  const size_t wide = (size_t)(cfg->intermediate > 3 * cfg->hidden ? cfg->intermediate : 3 * cfg->hidden);
+  MANNER_HIP_TRY(hipMemsetAsync(t.wk.zero, 0, wide * sizeof(float), s));
+  return MANNER_HIP_OK;
+}
+
+}  // namespace
+}  // namespace manner
+
+using namespace manner;
+
+extern "C" {
+
+size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer) {
+  if (!cfg || n_news <= 0 || m_bound <= 0 || start_layer < 0 || start_layer >= cfg->layers || cfg->layers > 64) return 0;
+  Bump b(nullptr);
+  Saved s;
+  plan_saved(b, s, *cfg, n_news, m_bound, start_layer);
+  return b.off + 256;
+}
+
+size_t manner_hip_train_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t m_bound) {
+  if (!cfg || m_bound <= 0) return 0;
+  Bump b(nullptr);
+  Work w;
+  plan_work(b, w, *cfg, m_bound);
+  return b.off + 256;
+}
+
+int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, manner_hip_stream_t stream) {
+  if (n < 0 || (n > 0 && !keep)) return fail(MANNER_HIP_E_INVALID, "dropout_mask: null pointer");
+  if (!(p >= 0.f && p < 1.f)) return fail(MANNER_HIP_E_INVALID, "dropout_mask: p=%f outside [0, 1)", p);
+  if (n == 0) return MANNER_HIP_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(mask_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, keep, n,
+                     make_drop(seed, site, p));
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                             const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
+                             int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
+                             float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
+                             size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+  Ctx t;
+  int rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
+                  workspace_bytes, s)))
+    return rc;
+  if (!ids || !mask || !cls_out) return fail(MANNER_HIP_E_INVALID, "train_forward: null pointer");
+  if ((start_layer > 0) != (prefix_hidden != nullptr))
+    return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
+  for (float p : {p_hidden, p_attn, p_out})
+    if (!(p >= 0.f && p < 1.f)) return fail(MANNER_HIP_E_INVALID, "train_forward: dropout probability %f outside [0, 1)", p);
+  const int H = cfg->hidden, I = cfg->intermediate, N = (int)n_news;
+  (void)N;
+  Saved& sv = t.sv;
+  if ((rc = lengths_and_offsets(mask, n_news, padded_len, sv.lens, sv.cu, sv.m_total, m_bound, -1, status, s))) return rc;
+  float* x0 = sv.l[start_layer].x_in;
+  const unsigned tok_blocks = (unsigned)(n_news * padded_len);
+  if (start_layer == 0) {
+    const int pos_offset = cfg->arch == MANNER_HIP_ARCH_ROBERTA ? cfg->pad_id + 1 : 0;
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu,
+                       t.emb(MANNER_HIP_W_WORD_EMB), t.emb(MANNER_HIP_W_POS_EMB), t.emb(MANNER_HIP_W_TYPE_EMB), H, pos_offset,
+                       cfg->vocab, cfg->max_pos, sv.esum, status);
+    MANNER_LAUNCH_CHECK();
+    if ((rc = ln_forward(t, sv.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), x0, sv.st0,
+                         make_drop(seed, SITE_EMB, p_hidden))))
+      return rc;
+  } else {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(tok_blocks), dim3(256), 0, s, prefix_hidden, x0, n_news, (int)padded_len, sv.cu, H, 0);
+    MANNER_LAUNCH_CHECK();
+  }
+  for (int l = start_layer; l < cfg->layers; ++l) {
+    LayerSaved& L = sv.l[l];
+    if ((rc = pack_qkv_weights(t, l))) return rc;
+    if ((rc = linear_fwd(t, L.x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, L.ctx, L.ml, sv.cu,
+                       cfg->heads, H, make_drop(seed, layer_site(l, SITE_ATTN), p_attn));
+    MANNER_LAUNCH_CHECK();
+    if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
+    if ((rc = dropout_add(t, t.wk.tmp, L.x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
+    if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f)))) return rc;
+    if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H))) return rc;
+    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, sv.m_total, 0);
+    MANNER_LAUNCH_CHECK();
+    if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I))) return rc;
+    if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
+    float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : t.wk.dx;      // the last layer's output is only needed for its [CLS] rows
+    if ((rc = ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_next, L.st2, make_drop(0, 0, 0.f)))) return rc;
+  }
+  hipLaunchKernelGGL(cls_kernel, dim3((unsigned)n_news), dim3(256), 0, s, t.wk.dx, sv.cu, H, cls_out, make_drop(seed, SITE_CLS, p_out));
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                              const int64_t* ids, int64_t n_news, int64_t padded_len, int64_t m_bound, int32_t precision,
+                              int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed, const float* grad_cls,
+                              void* saved, size_t saved_bytes, float* const* grads, float* grad_prefix, void* workspace,
+                              size_t workspace_bytes, manner_hip_stream_t stream) {
+  Ctx t;
+  int rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
+                  workspace_bytes, s)))
+    return rc;
+  if (!ids || !grad_cls || !grads) return fail(MANNER_HIP_E_INVALID, "train_backward: null pointer");
+  if (grad_prefix && start_layer == 0) return fail(MANNER_HIP_E_INVALID, "train_backward: grad_prefix goes with start_layer > 0");
+  const int H = cfg->hidden, I = cfg->intermediate;
+  Saved& sv = t.sv;
+  Work& wk = t.wk;
+  auto gemb = [&](int i) { return grads[i]; };
+  auto gl = [&](int l, int i) { return grads[MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + i]; };
+  // how far down the activation gradient has to travel
+  bool emb_grads = false;
+  for (int i = 0; i < MANNER_HIP_W_EMB_COUNT; ++i) emb_grads |= gemb(i) != nullptr;
+  if (emb_grads && start_layer > 0) return fail(MANNER_HIP_E_INVALID, "train_backward: embedding gradients need start_layer == 0");
+  int lowest = cfg->layers;
+  for (int l = start_layer; l < cfg->layers; ++l) {
+    bool any = false;
+    for (int i = 0; i < MANNER_HIP_WL_COUNT; ++i) any |= gl(l, i) != nullptr;
+    if (any) { lowest = l; break; }
+  }
+  for (int l = 0; l < start_layer; ++l)
+    for (int i = 0; i < MANNER_HIP_WL_COUNT; ++i)
+      if (gl(l, i)) return fail(MANNER_HIP_E_INVALID, "train_backward: gradient requested for layer %d below start_layer %d", l, start_layer);
+  const int stop = (emb_grads || grad_prefix) ? start_layer : lowest;     // layers >= stop are walked
+  bool ln_pairs = (gemb(MANNER_HIP_W_EMB_LN_G) != nullptr) == (gemb(MANNER_HIP_W_EMB_LN_B) != nullptr);
+  for (int l = start_layer; l < cfg->layers; ++l)
+    ln_pairs = ln_pairs && (gl(l, MANNER_HIP_WL_ALN_G) != nullptr) == (gl(l, MANNER_HIP_WL_ALN_B) != nullptr) &&
+               (gl(l, MANNER_HIP_WL_OLN_G) != nullptr) == (gl(l, MANNER_HIP_WL_OLN_B) != nullptr);
+  if (!ln_pairs) return fail(MANNER_HIP_E_INVALID, "train_backward: a LayerNorm's weight and bias gradients come together");
+  // d x_L: only the [CLS] rows carry gradient
+  MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
+  hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, grad_cls, sv.cu, H, wk.dx, make_drop(seed, SITE_CLS, p_out));
+  MANNER_LAUNCH_CHECK();
+  for (int l = cfg->layers - 1; l >= stop; --l) {
+    LayerSaved& L = sv.l[l];
+    const bool below = l > stop || emb_grads || grad_prefix;       // is d x_in needed?
+    // LN2: dx -> d r2 (wk.dr)
+    if ((rc = ln_backward(t, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
+    // r2 = dropout(y2) + h1: d y2 = dropout(d r2) (wk.tmp), d h1 starts as d r2
+    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(t, wk.tmp, L.g, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
+    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I))) return rc;                // d g
+    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, sv.m_total, 1);       // d inter
+    MANNER_LAUNCH_CHECK();
+    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(t, wk.dbig, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(t, wk.dbig, L.h1, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
+    if ((rc = linear_dgrad(t, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H))) return rc;
+    if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d h1
+    // LN1: d h1 -> d r1 (wk.dr)
+    if ((rc = ln_backward(t, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
+    // r1 = dropout(proj) + x_in
+    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;    // d proj
+    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_AO_W) && (rc = linear_wgrad(t, wk.tmp, L.ctx, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+    const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
+                       gl(l, MANNER_HIP_WL_K_B) || gl(l, MANNER_HIP_WL_V_B);
+    if (!below && !qkv_w) break;
+    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H))) return rc;                 // d ctx
+    const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+    hipLaunchKernelGGL(attn_train_bwd_q_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv,
+                       wk.dsum, sv.cu, cfg->heads, H, da);
+    MANNER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_train_bwd_kv_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, wk.dx, L.ml, wk.dsum,
+                       wk.dqkv, sv.cu, cfg->heads, H, da);
+    MANNER_LAUNCH_CHECK();
+    if (qkv_w) {
+      if ((rc = bias_grad(t, wk.dqkv, 3 * H, wk.dw))) return rc;
+      for (int k = 0; k < 3; ++k)
+        if (gl(l, MANNER_HIP_WL_Q_B + 2 * k))
+          MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_B + 2 * k), wk.dw + (size_t)k * H, H * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if ((rc = linear_wgrad(t, wk.dqkv, L.x_in, wk.dw, 3 * H, H, 3))) return rc;
+      for (int k = 0; k < 3; ++k)
+        if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
+          MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (!below) break;
+    if ((rc = pack_qkv_weights(t, l))) return rc;
+    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.tmp, 3 * H, H))) return rc;
+    if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d x_in
+  }
+  const unsigned tok_blocks = (unsigned)(n_news * padded_len);
+  if (grad_prefix) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(tok_blocks), dim3(256), 0, s, grad_prefix, wk.dx, n_news, (int)padded_len, sv.cu, H, 1);
+    MANNER_LAUNCH_CHECK();
+  }
+  if (emb_grads) {
+    // x0 = dropout(LN(esum))
+    if ((rc = dropout_add(t, wk.dx, nullptr, wk.dx, H, make_drop(seed, SITE_EMB, p_hidden)))) return rc;
+    if ((rc = ln_backward(t, wk.dx, sv.esum, sv.st0, t.emb(MANNER_HIP_W_EMB_LN_G), wk.dr, gemb(MANNER_HIP_W_EMB_LN_G), gemb(MANNER_HIP_W_EMB_LN_B)))) return rc;
+    const int pos_offset = cfg->arch == MANNER_HIP_ARCH_ROBERTA ? cfg->pad_id + 1 : 0;
+    if (gemb(MANNER_HIP_W_WORD_EMB)) MANNER_HIP_TRY(hipMemsetAsync(gemb(MANNER_HIP_W_WORD_EMB), 0, (size_t)cfg->vocab * H * sizeof(float), s));
+    if (gemb(MANNER_HIP_W_POS_EMB)) MANNER_HIP_TRY(hipMemsetAsync(gemb(MANNER_HIP_W_POS_EMB), 0, (size_t)cfg->max_pos * H * sizeof(float), s));
+    if (gemb(MANNER_HIP_W_WORD_EMB) || gemb(MANNER_HIP_W_POS_EMB)) {
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu, wk.dr, H, pos_offset,
+                         cfg->vocab, cfg->max_pos, gemb(MANNER_HIP_W_WORD_EMB), gemb(MANNER_HIP_W_POS_EMB));
+      MANNER_LAUNCH_CHECK();
+    }
+    if (gemb(MANNER_HIP_W_TYPE_EMB)) {
+      MANNER_HIP_TRY(hipMemsetAsync(gemb(MANNER_HIP_W_TYPE_EMB), 0, (size_t)cfg->type_vocab * H * sizeof(float), s));
+      if ((rc = bias_grad(t, wk.dr, H, gemb(MANNER_HIP_W_TYPE_EMB)))) return rc;      // every token is of type 0
+    }
+  }
+  return MANNER_HIP_OK;
+}
+
+}  // extern "C"

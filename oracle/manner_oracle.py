@@ -136,6 +136,52 @@ def encode_cls(ids, mask, w, cfg) -> Tensor:
         return encode_tokens(ids, mask, w, cfg)[:, 0, :].contiguous()
 
 
+def encode_cls_train(ids, mask, w: Dict[str, Tensor], cfg, p_hidden: float = 0.0, p_attn: float = 0.0, p_out: float = 0.0,
+                     keep=None, start_layer: int = 0, prefix: Optional[Tensor] = None) -> Tensor:
+    """MannerTextEncoder.forward in train() mode (reference news_encoder.py:29-37), differentiable: torch autograd over
+    this function is the gradient oracle of SURVEY §8f-3.  HF BertModel's dropouts sit after the embedding LayerNorm
+    (modeling_bert.py:107), on the attention probabilities (:140), after attention.output.dense (:183) and after
+    output.dense (:351); the reference adds one on the [CLS] vector (news_encoder.py:35).  ``keep(site, kind)`` supplies
+    the 0/1 keep masks (float, padded layout: kind "rows" [N, L, H], "attn" [N, heads, L, L], "cls" [N, H]) so that a
+    test can replay the masks of the implementation under test; site numbering: 0 embeddings, 1 [CLS], 8*(layer+1)+{0
+    attention probabilities, 1 attention output, 2 FFN output}.  ``w`` tensors may require grad.
+    ``start_layer`` / ``prefix``: start from hidden_states[start_layer] = prefix [N, L, H]."""
+    ids, mask = _t(ids).long(), _t(mask)
+    w = bert_named(dict(w), cfg)
+    n, s = ids.shape
+    h, a, d = cfg.hidden, cfg.heads, cfg.head_dim
+
+    def drop(x, p, site, kind):
+        if p <= 0.0:
+            return x
+        return x * keep(site, kind) / (1.0 - p)
+
+    if start_layer == 0:
+        x = drop(embeddings(ids, w, cfg), p_hidden, 0, "rows")
+    else:
+        x = prefix
+    add_mask = torch.zeros(mask.shape, dtype=torch.float32)
+    add_mask = add_mask.masked_fill(mask == 0, torch.finfo(torch.float32).min)[:, None, None, :]
+    for l in range(start_layer, cfg.layers):
+        p = f"encoder.layer.{l}."
+
+        def lin(t, name):
+            return F.linear(t, w[p + name + ".weight"], w[p + name + ".bias"])
+
+        q = lin(x, "attention.self.query").view(n, s, a, d).transpose(1, 2)
+        k = lin(x, "attention.self.key").view(n, s, a, d).transpose(1, 2)
+        v = lin(x, "attention.self.value").view(n, s, a, d).transpose(1, 2)
+        att = F.softmax(torch.matmul(q, k.transpose(2, 3)) * (d ** -0.5) + add_mask, dim=-1)
+        att = drop(att, p_attn, 8 * (l + 1), "attn")
+        ctx = torch.matmul(att, v).transpose(1, 2).reshape(n, s, h)
+        x = F.layer_norm(drop(lin(ctx, "attention.output.dense"), p_hidden, 8 * (l + 1) + 1, "rows") + x, (h,),
+                         w[p + "attention.output.LayerNorm.weight"], w[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
+        inter = F.gelu(lin(x, "intermediate.dense"))
+        x = F.layer_norm(drop(lin(inter, "output.dense"), p_hidden, 8 * (l + 1) + 2, "rows") + x, (h,),
+                         w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], cfg.ln_eps)
+    return drop(x[:, 0, :], p_out, 1, "cls")
+
+
 # --------------------------------------------------------------------------- entity branch (K8)
 
 def entity_encoder(entity_ids: Tensor, w: Dict[str, Tensor], heads: int) -> Tensor:

@@ -42,9 +42,9 @@ from manner.models.components.user_encoder import NAMLUserEncoder  # noqa: E402
 torch.set_grad_enabled(False)
 
 
-def hf_model_dir(cfg, weights, tmp):
+def hf_model_dir(cfg, weights, tmp, no_dropout=False):
     from transformers import BertConfig, BertModel, RobertaConfig, RobertaModel
-    kw = dict(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+    kw = dict(**({"hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0} if no_dropout else {}), vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
               num_attention_heads=cfg.heads, intermediate_size=cfg.intermediate,
               max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
               layer_norm_eps=cfg.ln_eps, pad_token_id=cfg.pad_id, hidden_act="gelu")
@@ -260,7 +260,55 @@ def gen_pipeline(seed=42):
     print("pipeline", lf.shape, n10, n5)
 
 
+def gen_train(name, preset, n, lp, seed, std, lengths, frozen_layers, matrix_rows=None):
+    """gradients of the reference's MannerTextEncoder in train() mode (news_encoder.py:11-37: HF model,
+    "layer.N." parameters of `frozen_layers` frozen, dropout on the [CLS] vector) with every dropout probability 0 (the
+    only way to make train mode reproducible): loss = sum(out * R).  Matrices keep `matrix_rows` leading rows (None = all);
+    the word-embedding gradient keeps the rows of the ids that occur and the sum of |.| of all other rows (0)."""
+    from manner.models.components.news_encoder import MannerTextEncoder
+    from transformers import BatchEncoding
+    cfg = PRESETS[preset]
+    w = make_plm_weights(cfg, seed=seed, std=std)
+    ids, mask = synth_news_tokens(n, cfg, seed=seed, max_len=lp, lengths=lengths)
+    R = np.random.default_rng(seed).standard_normal((n, cfg.hidden)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp, torch.enable_grad():
+        enc = MannerTextEncoder(plm_model=hf_model_dir(cfg, w, tmp, no_dropout=True), frozen_layers=list(frozen_layers),
+                                dropout_probability=0.0).train()
+        out = enc(BatchEncoding({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}))
+        (out * torch.from_numpy(R)).sum().backward()
+        grads, frozen = {}, []
+        for k, p in enc.plm_model.named_parameters():
+            if k.startswith("pooler."):
+                continue
+            if p.grad is None:
+                frozen.append(k)
+                continue
+            g = p.grad.numpy()
+            if k == "embeddings.word_embeddings.weight":
+                rows = np.unique(ids[mask > 0])
+                rest = np.ones(g.shape[0], bool)
+                rest[rows] = False
+                grads["word_rows"], grads["word_rest_abs_sum"] = rows, np.float64(np.abs(g[rest]).sum())
+                g = g[rows]
+            elif g.ndim == 2 and matrix_rows is not None and not k.startswith("embeddings."):
+                g = g[:matrix_rows]
+            grads["grad:" + k] = np.ascontiguousarray(g)
+    np.savez_compressed(
+        os.path.join(HERE, f"{name}.npz"), ids=ids, mask=mask, R=R, out=out.detach().numpy(), **grads,
+        meta=json.dumps({"source": "reference MannerTextEncoder.train() (news_encoder.py:11-37) over HF transformers "
+                                   + __import__("transformers").__version__ + ", all dropout probabilities 0, loss = sum(out * R)",
+                         "preset": preset, "seed": seed, "std": std, "frozen_layers": list(frozen_layers), "frozen": frozen,
+                         "matrix_rows": matrix_rows}))
+    print(name, out.shape, len(grads), "grad tensors,", len(frozen), "frozen")
+
+
 if __name__ == "__main__":
+    if "--train-only" in sys.argv:
+        gen_train("train_tiny_bert", "tiny-bert", n=6, lp=24, seed=51, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),
+                  frozen_layers=[0])
+        gen_train("train_tiny_roberta", "tiny-roberta", n=5, lp=20, seed=52, std=0.05, lengths=np.array([2, 9, 13, 19, 20]),
+                  frozen_layers=[], matrix_rows=8)
+        sys.exit(0)
     if "--roberta-base-only" in sys.argv:
         # roberta-base is the PLM of the reference's MIND configs (configs/experiment/cr_module_mind_all_scl_lf.yaml:25)
         gen_encoder("enc_roberta_base", "roberta-base", n=16, lp=96, seed=46, std=0.02,

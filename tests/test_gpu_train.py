@@ -1,0 +1,179 @@
+"""SURVEY §8f-3 — the training path of MannerTextEncoder on the HIP engine (manner_hip_train_forward / _backward through
+manner_amd.train) against (a) the gradients the reference's own MannerTextEncoder.train() produced (tests/golden/
+train_*.npz) and (b) autograd over the oracle's train-mode forward, with the implementation's own dropout masks replayed
+into the oracle.  Run on the MI355X box: ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import manner_oracle as O  # noqa: E402
+from manner_amd import hip, train  # noqa: E402
+from manner_amd.config import PRESETS  # noqa: E402
+from manner_amd.synth import synth_news_tokens  # noqa: E402
+from manner_amd.weights import make_plm_weights  # noqa: E402
+from test_oracle_golden import compare_train_grads, golden_train_case  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _params(w, frozen=()):
+    return {k: torch.from_numpy(v).to(DEV).requires_grad_(k not in frozen) for k, v in w.items()}
+
+
+def _grads(params):
+    return {k: (None if p.grad is None else p.grad.cpu().numpy()) for k, p in params.items()}
+
+
+def _rel(a, b, floor=1e-3):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+@pytest.mark.parametrize("name", ["train_tiny_bert", "train_tiny_roberta"])
+def test_train_gradients_match_reference(golden_dir, name):
+    """fp32 mode, all dropout off: the [CLS] outputs and every parameter gradient of the reference, incl. the gradient
+    that travels through the frozen layer into the embedding tables (news_encoder.py:24-27 freezes parameters only)."""
+    cfg, w, z, meta, expect = golden_train_case(golden_dir, name)
+    params = _params(w, frozen=set(meta["frozen"]))
+    ids, mask = torch.from_numpy(z["ids"]).to(DEV), torch.from_numpy(z["mask"]).to(DEV)
+    out = train.encode_train(cfg, params, ids, mask, precision="fp32", p_hidden=0.0, p_attn=0.0, p_out=0.0)
+    assert np.abs(out.detach().cpu().numpy() - z["out"]).max() < 1e-4
+    (out * torch.from_numpy(z["R"]).to(DEV)).sum().backward()
+    hip.check_status(DEV)
+    compare_train_grads(_grads(params), z, meta, expect, rel=1e-3)
+
+
+def _replay_keep(seed, p_hidden, p_attn, p_out, cfg, mask_np):
+    """The implementation's keep-bits (manner_hip_dropout_mask) rearranged into the oracle's padded layout."""
+    lens = mask_np.sum(1)
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    n, lp = mask_np.shape
+    m, h, a = int(cu[-1]), cfg.hidden, cfg.heads
+
+    def keep(site, kind):
+        if kind == "cls":
+            return train.dropout_mask(seed, site, p_out, n * h, DEV).cpu().view(n, h).float()
+        if kind == "rows":
+            bits = train.dropout_mask(seed, site, p_hidden, m * h, DEV).cpu().view(m, h).float()
+            out = torch.ones(n, lp, h)
+            for i in range(n):
+                out[i, :lens[i]] = bits[cu[i]:cu[i + 1]]
+            return out
+        bits = train.dropout_mask(seed, site, p_attn, m * a * 256, DEV).cpu().view(m, a, 256).float()
+        out = torch.ones(n, a, lp, lp)
+        for i in range(n):
+            out[i, :, :lens[i], :lp] = bits[cu[i]:cu[i + 1], :, :lp].permute(1, 0, 2)
+        return out
+
+    return keep
+
+
+@pytest.mark.parametrize("preset,frozen_layers", [("tiny-bert", (0,)), ("tiny-roberta", ())])
+def test_train_with_dropout_matches_oracle_on_replayed_masks(preset, frozen_layers):
+    """All five dropout sites on (HF 0.1 / 0.1, MannerTextEncoder 0.2): forward and backward against torch autograd
+    over the oracle that is fed the very masks the kernels drew."""
+    cfg = PRESETS[preset]
+    w = make_plm_weights(cfg, seed=61, std=0.05, with_pooler=False)
+    frozen = {k for k in w for l in frozen_layers if f"layer.{l}." in k}
+    ids_np, mask_np = synth_news_tokens(7, cfg, seed=61, max_len=20, lengths=np.array([2, 2, 5, 11, 17, 20, 20]))
+    R = torch.from_numpy(np.random.default_rng(0).standard_normal((7, cfg.hidden)).astype(np.float32))
+    seed, ph, pa, po = 1234567, 0.1, 0.1, 0.2
+    params = _params(w, frozen)
+    out = train.encode_train(cfg, params, torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV), precision="fp32",
+                             p_hidden=ph, p_attn=pa, p_out=po, seed=seed)
+    (out * R.to(DEV)).sum().backward()
+    wt = {k: torch.from_numpy(v).requires_grad_(k not in frozen) for k, v in w.items()}
+    ref = O.encode_cls_train(ids_np, mask_np, wt, cfg, p_hidden=ph, p_attn=pa, p_out=po, keep=_replay_keep(seed, ph, pa, po, cfg, mask_np))
+    (ref * R).sum().backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 2e-4
+    assert float((out == 0).float().mean()) > 0.1                      # the [CLS] dropout really dropped
+    g = _grads(params)
+    for k, v in wt.items():
+        if v.grad is None:
+            assert g[k] is None, k
+        else:
+            assert _rel(g[k], v.grad.numpy()) < 2e-3, (k, _rel(g[k], v.grad.numpy()))
+    # another seed gives another network
+    out2 = train.encode_train(cfg, params, torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV), precision="fp32",
+                              p_hidden=ph, p_attn=pa, p_out=po, seed=seed + 1)
+    assert (out2 - out).abs().max() > 1e-2
+
+
+def test_dropout_mask_statistics():
+    for p in (0.1, 0.2, 0.5):
+        bits = train.dropout_mask(99, 10, p, 1 << 20, DEV).float()
+        assert abs(float(bits.mean()) - (1 - p)) < 3e-3
+    a, b = train.dropout_mask(99, 10, 0.5, 1 << 16, DEV), train.dropout_mask(99, 11, 0.5, 1 << 16, DEV)
+    assert 0.45 < float((a == b).float().mean()) < 0.55                # sites are independent streams
+    assert bool(train.dropout_mask(5, 0, 0.0, 1000, DEV).all())
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_train_mixed_precision_tracks_fp32(precision):
+    """'16-mixed': GEMM operands rounded to 16 bits, everything else f32 — gradients stay aligned with the f32 mode."""
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=62, std=0.05, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(9, cfg, seed=62, max_len=24)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(1).standard_normal((9, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for prec in ("fp32", precision):
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=prec, p_hidden=0.0, p_attn=0.0, p_out=0.0)
+        (out * R).sum().backward()
+        res[prec] = (out.detach().cpu().numpy(), _grads(params))
+    tol = 2e-2 if precision == "f16" else 1e-1
+    assert np.abs(res[precision][0] - res["fp32"][0]).max() < tol
+    for k, g in res["fp32"][1].items():
+        a, b = res[precision][1][k].ravel().astype(np.float64), g.ravel().astype(np.float64)
+        if np.abs(b).max() < 1e-6:
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > (0.999 if precision == "f16" else 0.99), (k, cos)
+
+
+def test_train_from_cached_frozen_prefix():
+    """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
+    starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=63, std=0.05, with_pooler=False)
+    frozen = {k for k in w if k.startswith("embeddings.") or "layer.0." in k}
+    ids_np, mask_np = synth_news_tokens(6, cfg, seed=63, max_len=16)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(2).standard_normal((6, cfg.hidden)).astype(np.float32))
+    full = _params(w, frozen)
+    out_full = train.encode_train(cfg, full, ids, mask, precision="fp32", p_hidden=0.0, p_attn=0.0, p_out=0.0)
+    (out_full * R.to(DEV)).sum().backward()
+    engine = hip.HipEncoder(cfg, w, precisions=("fp32",), device=DEV)
+    cached = _params(w, frozen)
+    out_c = train.encode_train(cfg, cached, ids, mask, precision="fp32", p_hidden=0.0, p_attn=0.0, p_out=0.0, prefix_engine=engine)
+    (out_c * R.to(DEV)).sum().backward()
+    assert (out_c - out_full).abs().max() < 5e-5
+    gf, gc = _grads(full), _grads(cached)
+    for k in w:
+        if k in frozen:
+            assert gf[k] is None and gc[k] is None
+        else:
+            assert _rel(gc[k], gf[k]) < 1e-3, k
+    # explicit prefix tensor that requires grad: its gradient against the oracle
+    prefix = engine.encode_hidden(ids, mask, 1, precision="fp32").requires_grad_(True)
+    out_p = train.encode_train(cfg, _params(w, frozen), ids, mask, precision="fp32", p_hidden=0.0, p_attn=0.0, p_out=0.0,
+                               prefix_hidden=prefix, start_layer=1)
+    (out_p * R.to(DEV)).sum().backward()
+    pref_o = prefix.detach().cpu().clone().requires_grad_(True)
+    ref = O.encode_cls_train(ids_np, mask_np, {k: torch.from_numpy(v) for k, v in w.items()}, cfg, start_layer=1, prefix=pref_o)
+    (ref * R).sum().backward()
+    real = torch.from_numpy(mask_np).bool()
+    assert _rel(prefix.grad.cpu().numpy()[real.numpy()], pref_o.grad.numpy()[real.numpy()]) < 1e-3
+    assert float(prefix.grad.cpu()[~real].abs().max()) == 0.0
+
+
+def test_train_rejects_what_it_cannot_do():
+    cfg = PRESETS["tiny-bert"]
+    w = _params(make_plm_weights(cfg, seed=1, std=0.05, with_pooler=False))
+    ids = torch.zeros((2, 300), dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError, match="padded_len"):
+        train.encode_train(cfg, w, ids, torch.ones_like(ids), precision="fp32")
+    with pytest.raises(ValueError, match="precision"):
+        train.encode_train(cfg, w, ids[:, :8], torch.ones_like(ids[:, :8]), precision="f16x3")

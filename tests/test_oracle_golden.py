@@ -280,3 +280,65 @@ def test_zscore_against_numpy():
         mean, std = row.sum() / c, row[:c].std(ddof=1)
         assert np.abs(z[i] - (row - mean) / std).max() < 1e-5
         assert c == max(sizes) or abs(z[i, c] - (-mean / std)) < 1e-5            # padded slot: not zero
+
+
+def golden_train_case(golden_dir, name):
+    """Inputs and reference gradients of a train-mode golden: (cfg, numpy weights, z, meta, {param name: expected grad})."""
+    z, meta = _load(golden_dir, name)
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"], with_pooler=False)
+    expect = {k[len("grad:"):]: z[k] for k in z.files if k.startswith("grad:")}
+    return cfg, w, z, meta, expect
+
+
+def compare_train_grads(grads, z, meta, expect, rel):
+    """`grads`: {param name: numpy grad or None}.  Relative to each tensor's own largest reference entry."""
+    for k in meta["frozen"]:
+        assert grads.get(k) is None, f"{k} is frozen in the reference"
+    for k, ref in expect.items():
+        g = grads[k]
+        assert g is not None, k
+        if k == "embeddings.word_embeddings.weight":
+            rows = z["word_rows"]
+            rest = np.ones(g.shape[0], bool)
+            rest[rows] = False
+            assert np.abs(g[rest]).sum() == 0.0 == float(z["word_rest_abs_sum"])      # rows of ids that do not occur
+            g = g[rows]
+        elif g.ndim == 2 and meta["matrix_rows"] is not None and not k.startswith("embeddings."):
+            g = g[:meta["matrix_rows"]]
+        assert g.shape == ref.shape, k
+        # floor: the key-bias gradient is analytically zero (softmax is shift-invariant), i.e. rounding noise of ~1e-8
+        assert np.abs(g - ref).max() <= rel * max(np.abs(ref).max(), 1e-3), (k, float(np.abs(g - ref).max()), float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", ["train_tiny_bert", "train_tiny_roberta"])
+def test_train_mode_gradients_match_reference(golden_dir, name):
+    """autograd over the oracle's train-mode forward reproduces the gradients the reference's own
+    MannerTextEncoder.train() produced (all dropout probabilities 0) — incl. which tensors `frozen_layers` leaves
+    without a gradient while the activation gradient still reaches the embeddings through them."""
+    cfg, w, z, meta, expect = golden_train_case(golden_dir, name)
+    frozen = set(meta["frozen"])
+    wt = {k: torch.from_numpy(v).requires_grad_(k not in frozen) for k, v in w.items()}
+    out = O.encode_cls_train(z["ids"], z["mask"], wt, cfg)
+    assert np.abs(out.detach().numpy() - z["out"]).max() < 2e-5
+    (out * torch.from_numpy(z["R"])).sum().backward()
+    compare_train_grads({k: (None if v.grad is None else v.grad.numpy()) for k, v in wt.items()}, z, meta, expect, rel=2e-4)
+
+
+def test_train_mode_dropout_masks_are_replayable():
+    """The oracle's dropout hook: a keep mask of ones with p > 0 is a pure rescale, and masks change the output."""
+    cfg = PRESETS["tiny-bert"]
+    w = {k: torch.from_numpy(v) for k, v in make_plm_weights(cfg, seed=3, std=0.05).items()}
+    from manner_amd.synth import synth_news_tokens
+    ids, mask = synth_news_tokens(3, cfg, seed=3, max_len=12)
+    base = O.encode_cls_train(ids, mask, w, cfg)
+    g = torch.Generator().manual_seed(0)
+
+    def keep(site, kind):
+        shape = {"rows": (3, 12, cfg.hidden), "attn": (3, cfg.heads, 12, 12), "cls": (3, cfg.hidden)}[kind]
+        return (torch.rand(shape, generator=g) >= 0.1).float()
+
+    dropped = O.encode_cls_train(ids, mask, w, cfg, p_hidden=0.1, p_attn=0.1, p_out=0.1, keep=keep)
+    assert (dropped - base).abs().max() > 1e-3
+    ones = O.encode_cls_train(ids, mask, w, cfg, p_out=0.5, keep=lambda s, k: torch.ones(3, cfg.hidden))
+    assert torch.allclose(ones, base * 2.0, atol=1e-5)
