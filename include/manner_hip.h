@@ -377,6 +377,28 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
                               float* grad_prefix, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
 int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, manner_hip_stream_t stream);
 
+/* The rest of the training step (cr_module.py:105-171), f32, ragged order:
+ *  - late-fusion scorer on the vectors of every occurrence (training encodes x_hist / x_cand per impression, :107-113):
+ *    user_i = mean(hist rows of i) (:116-123), scores_j = <user_i, cand_j> (:127-129); backward: d hist, d cand.
+ *    hist f32 [hist_off[B], D], cand f32 [cand_off[B], D], user f32 [B, D] (kept for the backward), scores f32 [cand_off[B]];
+ *  - DotProduct backward for the drop-in click predictor (click_predictors.py:9-12): grad_user [B, D], grad_cand
+ *    CONTIGUOUS [B, D, C] (the shape of the permuted view the reference passes);
+ *  - the loss of model_step (:140-171) with its gradient: mode / temperature / c_max as manner_hip_eval_loss;
+ *    losses f32 [B]; loss_and_scale f32 [2] = {batch loss, reducer factor} — SupCon: mean over the non-zero
+ *    per-impression losses (pytorch_metric_learning AvgNonZeroReducer); CE: mean; grad_scores f32 [cand_off[B]] =
+ *    d loss / d scores (ragged order). */
+int manner_hip_late_fusion_train_forward(const float* hist, const int64_t* hist_off, const float* cand, const int64_t* cand_off,
+                                         int64_t B, int32_t D, float* user, float* scores, manner_hip_stream_t stream);
+int manner_hip_late_fusion_train_backward(const float* grad_scores, const float* user, const int64_t* hist_off, const float* cand,
+                                          const int64_t* cand_off, int64_t B, int32_t D, float* grad_hist, float* grad_cand,
+                                          manner_hip_stream_t stream);
+int manner_hip_dot_backward(const float* grad_out, const float* user, const float* cand, int64_t B, int64_t C, int32_t D,
+                            int64_t cand_stride_b, int64_t cand_stride_d, int64_t cand_stride_c, float* grad_user,
+                            float* grad_cand, manner_hip_stream_t stream);
+int manner_hip_train_loss(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t mode,
+                          float temperature, int64_t c_max, float* losses, float* loss_and_scale, float* grad_scores,
+                          manner_hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,10 @@ SIGNATURES = {
     "manner_hip_train_backward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _I64, _I64, _I64, _I32, _I32,
                                             C.c_float, C.c_float, C.c_float, C.c_uint64, _P, _P, _SZ, C.POINTER(_P), _P, _P, _SZ, _P]),
     "manner_hip_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, _I64, _P, _P]),
+    "manner_hip_late_fusion_train_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "manner_hip_late_fusion_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "manner_hip_dot_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P, _P]),
+    "manner_hip_train_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P, _P, _P]),
     "manner_hip_collate_segments": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "manner_hip_collate_text": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_collate_entities": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),

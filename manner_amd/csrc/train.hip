@@ -474,6 +474,138 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
   for (int d = 0; d < AD; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
 }
 
+// ------------------------------------------------------------------------------------------------ scorer + loss (train)
+// CRModule.forward with late_fusion=True in training (cr_module.py:105-131): every occurrence is encoded, so the
+// history / candidate vectors arrive in ragged order.  user_i = mean(hist rows of i); s_j = <user_i, cand_j>.
+__global__ __launch_bounds__(256) void lf_train_fwd_kernel(const float* __restrict__ hist, const int64_t* __restrict__ hoff,
+                                                           const float* __restrict__ cand, const int64_t* __restrict__ coff, int D,
+                                                           float* __restrict__ user, float* __restrict__ scores) {
+  extern __shared__ float us[];
+  const int64_t b = blockIdx.x;
+  const int64_t h0 = hoff[b], h1 = hoff[b + 1], c0 = coff[b], c1 = coff[b + 1];
+  const float inv = 1.f / (float)(h1 - h0);                 // an empty history divides by zero, as torch.div does
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f;
+    for (int64_t r = h0; r < h1; ++r) s += hist[(size_t)r * D + c];
+    us[c] = s * inv;
+    user[(size_t)b * D + c] = us[c];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t j = c0 + wave; j < c1; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a = fmaf(us[c], cand[(size_t)j * D + c], a);
+    a = wave_sum(a);
+    if (lane == 0) scores[j] = a;
+  }
+}
+// d cand_j = g_j user_i;  d user_i = sum_j g_j cand_j;  d hist_r = d user_i / h_i
+__global__ __launch_bounds__(256) void lf_train_bwd_kernel(const float* __restrict__ g, const float* __restrict__ user,
+                                                           const int64_t* __restrict__ hoff, const float* __restrict__ cand,
+                                                           const int64_t* __restrict__ coff, int D, float* __restrict__ dhist,
+                                                           float* __restrict__ dcand) {
+  const int64_t b = blockIdx.x;
+  const int64_t h0 = hoff[b], h1 = hoff[b + 1], c0 = coff[b], c1 = coff[b + 1];
+  const float inv = 1.f / (float)(h1 - h0);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float u = user[(size_t)b * D + c];
+    float du = 0.f;
+    for (int64_t j = c0; j < c1; ++j) {
+      const float gj = g[j];
+      du = fmaf(gj, cand[(size_t)j * D + c], du);
+      dcand[(size_t)j * D + c] = gj * u;
+    }
+    du *= inv;
+    for (int64_t r = h0; r < h1; ++r) dhist[(size_t)r * D + c] = du;
+  }
+}
+
+// DotProduct backward (click_predictors.py:9-12: torch.bmm(user [B,1,D], cand [B,D,C])), strided cand / d cand
+__global__ __launch_bounds__(256) void dot_bwd_kernel(const float* __restrict__ g, const float* __restrict__ user,
+                                                      const float* __restrict__ cand, int64_t C, int D, int64_t sb, int64_t sd,
+                                                      int64_t sc, float* __restrict__ duser, float* __restrict__ dcand) {
+  const int64_t b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float u = user[(size_t)b * D + d];
+    float du = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float gc = g[b * C + c];
+      du = fmaf(gc, cand[b * sb + d * sd + c * sc], du);
+      dcand[(b * D + d) * C + c] = gc * u;          // contiguous [B, D, C], the layout of the reference's permuted view
+    }
+    duser[(size_t)b * D + d] = du;
+  }
+}
+
+// per-impression loss (as eval_loss_kernel in metrics.hip) and its UNSCALED gradient wrt the ragged scores:
+// mode 0 SupCon (losses.py:12-40): l_i = -(sum_pos (v_j - lse)) / (n_pos + tiny), v = s / T (the detached row maximum
+//   drops out); d l_i / d s_j = -(y_j - n_pos softmax_j) / (T (n_pos + tiny)) over the real candidates;
+// mode 1 CrossEntropyLoss with probability targets over the dense zero-padded row: d l_i / d s_j = softmax_j sum(y) - y_j.
+__global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                                         const int64_t* __restrict__ off, int64_t B, int mode, float inv_t,
+                                                         int64_t c_max, float tiny, float* __restrict__ losses,
+                                                         float* __restrict__ grad) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  const int64_t c0 = off[i], c1 = off[i + 1];
+  const int64_t pad = mode == 1 ? c_max - (c1 - c0) : 0;
+  float mx = pad > 0 ? 0.f : -INFINITY;
+  for (int64_t j = c0 + lane; j < c1; j += 64) mx = fmaxf(mx, scores[j] * inv_t);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.f, sp = 0.f, np = 0.f;
+  for (int64_t j = c0 + lane; j < c1; j += 64) {
+    const float v = scores[j] * inv_t - mx;
+    se += expf(v);
+    const float y = labels[j];
+    if (mode == 1) { sp = fmaf(y, v, sp); np += y; }
+    else if (y > 0.5f) { sp += v; np += 1.f; }
+  }
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sp += __shfl_xor(sp, o, 64); np += __shfl_xor(np, o, 64); }
+  if (pad > 0) se += (float)pad * expf(-mx);
+  const float lse = logf(se);
+  const float loss = mode == 1 ? -(sp - np * lse) : -(sp - np * lse) / (np + tiny);
+  if (lane == 0) losses[i] = loss;
+  for (int64_t j = c0 + lane; j < c1; j += 64) {
+    const float sm = expf(scores[j] * inv_t - mx - lse);
+    const float y = labels[j];
+    if (mode == 1) grad[j] = sm * np - y;
+    else grad[j] = -((y > 0.5f ? 1.f : 0.f) - np * sm) * inv_t / (np + tiny);
+  }
+}
+// batch value and the factor that turns the unscaled gradient into d L / d s: mode 0 mean over the NON-ZERO losses
+// (pytorch_metric_learning's AvgNonZeroReducer, the default of SupConLoss; zero-loss impressions get no gradient),
+// mode 1 mean over the batch.  One workgroup, fixed order.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ losses, int64_t B, int mode,
+                                                          float* __restrict__ out /*[2]: loss, scale*/) {
+  __shared__ float ss[256], sn[256];
+  float s = 0.f, n = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += 256) {
+    const float l = losses[i];
+    if (mode == 1 || l > 0.f) { s += l; n += 1.f; }
+  }
+  ss[threadIdx.x] = s; sn[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sn[threadIdx.x] += sn[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sn[0] > 0.f ? ss[0] / sn[0] : 0.f;
+    out[1] = sn[0] > 0.f ? 1.f / sn[0] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void loss_scale_kernel(float* __restrict__ grad, const float* __restrict__ losses,
+                                                         const int64_t* __restrict__ off, int64_t B, int mode,
+                                                         const float* __restrict__ red) {
+  const int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  const float f = (mode == 1 || losses[i] > 0.f) ? red[1] : 0.f;
+  for (int64_t j = off[i] + lane; j < off[i + 1]; j += 64) grad[j] *= f;
+}
+
 __global__ void mask_kernel(uint8_t* out, int64_t n, Drop drop) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = (drop.thr == 0 || drop_bits(drop.seed, drop.site, (uint64_t)i) >= drop.thr) ? 1 : 0;
@@ -896,6 +1028,59 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
       if ((rc = bias_grad(t, wk.dr, H, gemb(MANNER_HIP_W_TYPE_EMB)))) return rc;      // every token is of type 0
     }
   }
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_late_fusion_train_forward(const float* hist, const int64_t* hist_off, const float* cand, const int64_t* cand_off,
+                                         int64_t B, int32_t D, float* user, float* scores, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!hist || !hist_off || !cand || !cand_off || !user || !scores || B < 0 || D <= 0 || D > 8192)
+    return fail(MANNER_HIP_E_INVALID, "late_fusion_train_forward: bad argument");
+  hipLaunchKernelGGL(lf_train_fwd_kernel, dim3((unsigned)B), dim3(256), D * sizeof(float), (hipStream_t)stream, hist, hist_off, cand,
+                     cand_off, D, user, scores);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_late_fusion_train_backward(const float* grad_scores, const float* user, const int64_t* hist_off, const float* cand,
+                                          const int64_t* cand_off, int64_t B, int32_t D, float* grad_hist, float* grad_cand,
+                                          manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!grad_scores || !user || !hist_off || !cand || !cand_off || !grad_hist || !grad_cand || B < 0 || D <= 0)
+    return fail(MANNER_HIP_E_INVALID, "late_fusion_train_backward: bad argument");
+  hipLaunchKernelGGL(lf_train_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, grad_scores, user, hist_off, cand,
+                     cand_off, D, grad_hist, grad_cand);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_dot_backward(const float* grad_out, const float* user, const float* cand, int64_t B, int64_t C, int32_t D,
+                            int64_t cand_stride_b, int64_t cand_stride_d, int64_t cand_stride_c, float* grad_user,
+                            float* grad_cand, manner_hip_stream_t stream) {
+  if (B == 0 || C == 0) return MANNER_HIP_OK;
+  if (!grad_out || !user || !cand || !grad_user || !grad_cand || B < 0 || C < 0 || D <= 0)
+    return fail(MANNER_HIP_E_INVALID, "dot_backward: bad argument");
+  hipLaunchKernelGGL(dot_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, grad_out, user, cand, C, D, cand_stride_b,
+                     cand_stride_d, cand_stride_c, grad_user, grad_cand);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_train_loss(const float* scores, const float* labels, const int64_t* cand_off, int64_t B, int32_t mode,
+                          float temperature, int64_t c_max, float* losses, float* loss_and_scale, float* grad_scores,
+                          manner_hip_stream_t stream) {
+  if (!scores || !labels || !cand_off || !losses || !loss_and_scale || !grad_scores || B <= 0 || mode < 0 || mode > 1 ||
+      !(temperature > 0.f) || (mode == 1 && c_max < 1))
+    return fail(MANNER_HIP_E_INVALID, "train_loss: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, scores, labels, cand_off, B, (int)mode,
+                     1.0f / temperature, c_max, 1.17549435e-38f, losses, grad_scores);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, losses, B, (int)mode, loss_and_scale);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_scale_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, grad_scores, losses, cand_off, B, (int)mode,
+                     loss_and_scale);
+  MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
 

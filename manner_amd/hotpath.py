@@ -16,7 +16,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 import torch
 
-from . import hip
+from . import hip, train
 
 Tensor = torch.Tensor
 
@@ -77,6 +77,22 @@ def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder
         cidx = torch.arange(cand_vec.shape[0], dtype=torch.int32, device=cand_vec.device)
         ragged = hip.score_user(cand_vec, user, cidx, cand_off)
     return hip.to_dense(ragged, cand_off, _width(batch, "cand_max", cand_off)) if dense else ragged
+
+
+def cr_train_step(news_encoder, batch: Dict, supcon: bool = True, temperature: float = 0.1):
+    """CRModule.model_step for training (cr_module.py:140-171 with late_fusion=True, the shipped MANNeR setting): the
+    encoder in train() mode, the fused late-fusion scorer and the loss, all with autograd on the HIP engine.
+    Returns (loss, ragged scores [sum c_i] detached, cand_off) — call ``loss.backward()`` and step the reference's optimiser."""
+    nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
+    hist_vec = news_encoder(batch["x_hist"])
+    cand_vec = news_encoder(batch["x_cand"])
+    hist_off = segment_offsets(batch["batch_hist"], nb)
+    cand_off = segment_offsets(batch["batch_cand"], nb)
+    scores = train.late_fusion_scores(hist_vec, hist_off, cand_vec, cand_off)
+    c_max = None if supcon else _width(batch, "cand_max", cand_off)
+    loss, _ = train.model_step_loss(scores, batch["labels"].to(torch.float32), cand_off, supcon=supcon, temperature=temperature,
+                                    c_max=c_max)
+    return loss, scores.detach(), cand_off
 
 
 def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[float], dense: bool = True) -> Tensor:

@@ -3,11 +3,12 @@ manner/models/components/news_encoder.py:11-129.
 
 Same constructor arguments, forward signature and state_dict keys (``text_encoder.plm_model.*`` are
 the HF BertModel / RobertaModel names), so reference checkpoints load with
-``load_state_dict``.  ``forward`` (eval mode, GPU tensors) runs K1-K7 through libmanner_hip.so;
-there is no CPU or autograd path.
+``load_state_dict``.  ``forward`` (GPU tensors) runs K1-K7 through libmanner_hip.so in eval mode and, in train() mode,
+the training path of SURVEY §8f-3 (``manner_amd.train``: dropouts + autograd into the parameters); there is no CPU path.
 """
 from __future__ import annotations
 
+import json
 import os
 import warnings
 from typing import Any, Dict, List, Optional
@@ -15,7 +16,7 @@ from typing import Any, Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from manner_amd import hip
+from manner_amd import hip, train
 from manner_amd.config import EncoderConfig, resolve
 from manner_amd.models.components.attention import AdditiveAttention
 from manner_amd.weights import plm_param_shapes
@@ -34,9 +35,12 @@ def _set_nested_parameter(root: nn.Module, dotted: str, param: nn.Parameter) -> 
 class HipPLM(nn.Module):
     """Parameter tree with HF BertModel/RobertaModel names; the arithmetic lives in the HIP library."""
 
-    def __init__(self, cfg: EncoderConfig) -> None:
+    def __init__(self, cfg: EncoderConfig, hidden_dropout_prob: float = 0.1, attention_probs_dropout_prob: float = 0.1) -> None:
         super().__init__()
         self.cfg = cfg
+        # HF BertConfig / RobertaConfig defaults (DistilBertConfig: dropout / attention_dropout, also 0.1): train() mode only
+        self.hidden_dropout_prob = hidden_dropout_prob
+        self.attention_probs_dropout_prob = attention_probs_dropout_prob
         for name, shape in plm_param_shapes(cfg, with_pooler=True):
             t = torch.empty(shape, dtype=torch.float32)
             if name.endswith(("LayerNorm.weight", "layer_norm.weight")):
@@ -58,6 +62,10 @@ class HipPLM(nn.Module):
         checkpoint to be loaded afterwards (as EnsembleModule does, ensemble_module.py:33-46)."""
         model = cls(resolve(plm_model))
         if os.path.isdir(plm_model):
+            with open(os.path.join(plm_model, "config.json")) as f:
+                hf = json.load(f)
+            model.hidden_dropout_prob = float(hf.get("hidden_dropout_prob", hf.get("dropout", 0.1)))
+            model.attention_probs_dropout_prob = float(hf.get("attention_probs_dropout_prob", hf.get("attention_dropout", 0.1)))
             sd = None
             st, pt = os.path.join(plm_model, "model.safetensors"), os.path.join(plm_model, "pytorch_model.bin")
             if os.path.exists(st):
@@ -121,10 +129,24 @@ class MannerTextEncoder(nn.Module):
             self._hip_key = key
         return self._hip
 
+    #: GEMM arithmetic of the training path: "f16" / "bf16" ("16-mixed": 16-bit GEMM operands, f32 accumulation, f32
+    #: activations and gradients) or "fp32"
+    train_precision: str = os.environ.get("MANNER_HIP_TRAIN_PRECISION", "f16")
+
+    def _forward_train(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """train() mode (reference news_encoder.py:29-37 under model.train()): HF's dropouts, the [CLS] dropout and autograd
+        into every parameter with requires_grad — through the frozen layers into the embeddings when those train (the
+        reference's default); with the embeddings frozen too, the frozen prefix runs once on the inference engine."""
+        plm = self.plm_model
+        params = {k: v for k, v in plm.named_parameters() if not k.startswith("pooler.")}
+        emb_frozen = not any(p.requires_grad for k, p in params.items() if k.startswith("embeddings."))
+        first_frozen = not any(p.requires_grad for k, p in params.items() if "layer.0." in k)
+        engine = self._encoder(ids.device) if (emb_frozen and first_frozen) else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch's CPU generator: reproducible under manual_seed
+        return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=plm.hidden_dropout_prob,
+                                  p_attn=plm.attention_probs_dropout_prob, p_out=self.dropout.p, seed=seed, prefix_engine=engine)
+
     def forward(self, tokenized_text) -> torch.Tensor:
-        if self.training:
-            raise RuntimeError("manner_amd MannerTextEncoder is inference-only: dropout/backward of the reference's "
-                               "training mode are out of scope (SURVEY.md Q6); call .eval()")
         ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
         if not ids.is_cuda:
             raise RuntimeError("MannerTextEncoder.forward needs GPU tensors — the HIP hot path has no CPU fallback")
@@ -137,6 +159,8 @@ class MannerTextEncoder(nn.Module):
         # the device; its flag word is snapshotted behind an event after every call and the completed snapshots are
         # examined before the next one — an invalid batch raises at the following forward (or at check_inputs()),
         # never passes silently, and the fast path has no host synchronisation.
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(ids, mask)
         enc = self._encoder(ids.device)
         enc.status_poll()
         out = enc.encode_cls(ids, mask, precision=self.precision)
@@ -188,7 +212,8 @@ class MannerEntityEncoder(nn.Module):
 
     def forward(self, entity_sequence: torch.Tensor) -> torch.Tensor:
         if self.training:
-            raise RuntimeError("manner_amd MannerEntityEncoder is inference-only; call .eval()")
+            raise RuntimeError("manner_amd MannerEntityEncoder has no training path (SURVEY §8f-3 covers the text encoder, "
+                               "i.e. the use_entities=False configs); call .eval()")
         mha, pool = self.multihead_attention, self.additive_attention
         return hip.entity_encode(entity_sequence, self.pretrained_embedding.weight.detach(), mha.in_proj_weight.detach(),
                                  mha.in_proj_bias.detach(), mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),

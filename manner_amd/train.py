@@ -135,3 +135,101 @@ def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mas
     opts = dict(cfg=cfg, precision=precision, p_hidden=float(p_hidden), p_attn=float(p_attn), p_out=float(p_out),
                 seed=int(seed) & (2 ** 64 - 1), start_layer=int(start_layer))
     return _EncodeTrain.apply(ids, mask, prefix_hidden, opts, *table)
+
+
+# ---------------------------------------------------------------------------------------------- scorer and loss
+class _LateFusion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hist: Tensor, hist_off: Tensor, cand: Tensor, cand_off: Tensor):
+        b, d = hist_off.numel() - 1, hist.shape[1]
+        user = torch.empty((b, d), dtype=torch.float32, device=hist.device)
+        scores = torch.empty(cand.shape[0], dtype=torch.float32, device=hist.device)
+        with torch.cuda.device(hist.device):
+            _lib.check(_lib.load().manner_hip_late_fusion_train_forward(hip._ptr(hist), hip._ptr(hist_off), hip._ptr(cand), hip._ptr(cand_off),
+                                                                        b, d, hip._ptr(user), hip._ptr(scores), hip._stream()))
+        ctx.save_for_backward(user, hist_off, cand, cand_off)
+        ctx.n_hist = hist.shape[0]
+        return scores
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        user, hist_off, cand, cand_off = ctx.saved_tensors
+        b, d = user.shape
+        dhist = torch.empty((ctx.n_hist, d), dtype=torch.float32, device=user.device)
+        dcand = torch.empty_like(cand)
+        with torch.cuda.device(user.device):
+            g = g.to(torch.float32).contiguous()
+            _lib.check(_lib.load().manner_hip_late_fusion_train_backward(hip._ptr(g), hip._ptr(user), hip._ptr(hist_off), hip._ptr(cand),
+                                                                         hip._ptr(cand_off), b, d, hip._ptr(dhist), hip._ptr(dcand), hip._stream()))
+        return dhist, None, dcand, None
+
+
+def late_fusion_scores(hist: Tensor, hist_off: Tensor, cand: Tensor, cand_off: Tensor) -> Tensor:
+    """Ragged scores of CRModule.forward(late_fusion=True) on per-occurrence vectors (cr_module.py:105-131), differentiable:
+    hist [sum h_i, D], cand [sum c_i, D] f32, offsets int64 [B+1] on the GPU -> scores [sum c_i]."""
+    hist, cand = hip._dev(hist, torch.float32, "hist").contiguous(), hip._dev(cand, torch.float32, "cand").contiguous()
+    hist_off, cand_off = hip._dev(hist_off, torch.int64, "hist_off").contiguous(), hip._dev(cand_off, torch.int64, "cand_off").contiguous()
+    if hist.shape[1] != cand.shape[1] or hist_off.numel() != cand_off.numel():
+        raise ValueError("late_fusion_scores: mismatching shapes")
+    return _LateFusion.apply(hist, hist_off, cand, cand_off)
+
+
+class _Dot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, user: Tensor, cand: Tensor):
+        ctx.save_for_backward(user, cand)
+        return hip.dot(user.detach(), cand.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        user, cand = ctx.saved_tensors
+        b, _, d = user.shape
+        c = cand.shape[2]
+        du = torch.empty((b, 1, d), dtype=torch.float32, device=user.device)
+        dc = torch.empty((b, d, c), dtype=torch.float32, device=user.device)
+        with torch.cuda.device(user.device):
+            g = g.to(torch.float32).contiguous()
+            uc = user.contiguous()
+            _lib.check(_lib.load().manner_hip_dot_backward(hip._ptr(g), hip._ptr(uc), hip._ptr(cand), b, c, d, cand.stride(0), cand.stride(1),
+                                                           cand.stride(2), hip._ptr(du), hip._ptr(dc), hip._stream()))
+        return du, dc
+
+
+def dot(user: Tensor, cand: Tensor) -> Tensor:
+    """DotProduct.forward (click_predictors.py:9-12) with autograd: user [B, 1, D], cand [B, D, C] (any strides)."""
+    return _Dot.apply(hip._dev(user, torch.float32, "user_vector"), hip._dev(cand, torch.float32, "candidate_news_vector"))
+
+
+class _Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores: Tensor, labels: Tensor, cand_off: Tensor, mode: int, temperature: float, c_max: int):
+        b = cand_off.numel() - 1
+        losses = torch.empty(b, dtype=torch.float32, device=scores.device)
+        red = torch.empty(2, dtype=torch.float32, device=scores.device)
+        grad = torch.empty_like(scores)
+        with torch.cuda.device(scores.device):
+            _lib.check(_lib.load().manner_hip_train_loss(hip._ptr(scores), hip._ptr(labels), hip._ptr(cand_off), b, mode, C.c_float(temperature),
+                                                         c_max, hip._ptr(losses), hip._ptr(red), hip._ptr(grad), hip._stream()))
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(losses)
+        return red[0], losses
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _g_losses):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None
+
+
+def model_step_loss(scores: Tensor, labels: Tensor, cand_off: Tensor, supcon: bool = True, temperature: float = 0.1,
+                    c_max: Optional[int] = None):
+    """The loss of CRModule.model_step (cr_module.py:140-171) on ragged scores, with autograd: SupConLoss on the score matrix
+    (losses.py:12-40, mean over the non-zero per-impression losses) or nn.CrossEntropyLoss over the dense zero-padded rows
+    (``c_max`` = the batch's largest candidate count, e.g. ``batch["cand_max"]`` from DeviceCollate).
+    Returns (batch loss scalar, per-impression losses [B])."""
+    scores = hip._dev(scores, torch.float32, "scores").contiguous()
+    labels = hip._dev(labels, torch.float32, "labels").contiguous()
+    cand_off = hip._dev(cand_off, torch.int64, "cand_off").contiguous()
+    if not supcon and c_max is None:
+        raise ValueError("cross-entropy mode needs c_max (the dense row width of the reference)")
+    # nn.CrossEntropyLoss has no temperature (cr_module.py:169)
+    return _Loss.apply(scores, labels, cand_off, 0 if supcon else 1, float(temperature) if supcon else 1.0, int(c_max or 1))

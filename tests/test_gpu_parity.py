@@ -315,9 +315,13 @@ def test_module_surface_matches_reference(golden_dir):
     with torch.no_grad():
         out = enc(news).cpu().numpy()
     assert np.abs(out - z["out"]).max() < FP32_TOL
-    enc.train()
-    with pytest.raises(RuntimeError, match="inference-only"):
-        enc(news)
+    enc.train()                                   # train() mode is the training path (tests/test_gpu_train.py): grads flow
+    enc.text_encoder.train_precision = "fp32"
+    enc.text_encoder.dropout.p = 0.0
+    enc.text_encoder.plm_model.hidden_dropout_prob = enc.text_encoder.plm_model.attention_probs_dropout_prob = 0.0
+    out_t = enc(news)
+    assert out_t.requires_grad and np.abs(out_t.detach().cpu().numpy() - z["out"]).max() < FP32_TOL
+    enc.eval()
     za, ma = _load(golden_dir, "additive_attention")
     ue = NAMLUserEncoder(news_embedding_dim=ma["input_dim"], query_vector_dim=ma["query_dim"])
     ue.load_state_dict({k: torch.from_numpy(v) for k, v in

@@ -177,3 +177,114 @@ def test_train_rejects_what_it_cannot_do():
         train.encode_train(cfg, w, ids, torch.ones_like(ids), precision="fp32")
     with pytest.raises(ValueError, match="precision"):
         train.encode_train(cfg, w, ids[:, :8], torch.ones_like(ids[:, :8]), precision="f16x3")
+
+
+def _ragged_case(seed, b=9, d=64):
+    rng = np.random.default_rng(seed)
+    h = rng.integers(1, 7, b)
+    c = rng.integers(1, 6, b)
+    c[0], c[1] = 1, 5
+    hoff, coff = np.concatenate([[0], np.cumsum(h)]), np.concatenate([[0], np.cumsum(c)])
+    hist = rng.standard_normal((hoff[-1], d)).astype(np.float32)
+    cand = rng.standard_normal((coff[-1], d)).astype(np.float32)
+    labels = np.zeros(coff[-1], np.float32)
+    for i in range(b):
+        labels[coff[i] + rng.integers(0, c[i])] = 1.0            # one click per impression ...
+    labels[coff[1]:coff[1] + 2] = 1.0                              # ... two in impression 1
+    labels[coff[2]:coff[3]] = 0.0                                  # ... none in impression 2 (zero loss, excluded by the reducer)
+    return hist, hoff, cand, coff, labels
+
+
+@pytest.mark.parametrize("supcon", [True, False])
+def test_scorer_and_loss_gradients_match_oracle(supcon):
+    """late-fusion scorer + model_step loss (SupCon on the score matrix / CE over the dense zero-padded rows) with autograd,
+    against torch autograd over the oracle's restatement of cr_module.py:105-171."""
+    hist, hoff, cand, coff, labels = _ragged_case(5)
+    th, tc = torch.from_numpy(hist).to(DEV).requires_grad_(True), torch.from_numpy(cand).to(DEV).requires_grad_(True)
+    scores = train.late_fusion_scores(th, torch.from_numpy(hoff).to(DEV), tc, torch.from_numpy(coff).to(DEV))
+    loss, per = train.model_step_loss(scores, torch.from_numpy(labels).to(DEV), torch.from_numpy(coff).to(DEV), supcon=supcon,
+                                      temperature=0.36, c_max=int(np.diff(coff).max()))
+    loss.backward()
+    oh, oc = torch.from_numpy(hist).requires_grad_(True), torch.from_numpy(cand).requires_grad_(True)
+    seg = lambda off: torch.repeat_interleave(torch.arange(len(off) - 1), torch.from_numpy(np.diff(off)))   # noqa: E731
+    dense = O.cr_scores(oh, seg(hoff), oc, seg(coff))
+    ref_scores = O.ragged(dense, seg(coff))
+    assert (scores.detach().cpu() - ref_scores.detach()).abs().max() < 1e-4
+    ref_loss, ref_per = O.model_step_loss(ref_scores, torch.from_numpy(labels), list(coff), supcon=supcon, temperature=0.36)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-5 * max(1.0, abs(float(ref_loss.detach())))
+    assert (per.cpu() - ref_per.detach()).abs().max() < 1e-4
+    if supcon:
+        assert float(per[2]) == 0.0                                 # the impression without a click
+    assert _rel(th.grad.cpu().numpy(), oh.grad.numpy()) < 1e-4
+    assert _rel(tc.grad.cpu().numpy(), oc.grad.numpy()) < 1e-4
+
+
+def test_dot_product_backward_matches_bmm():
+    rng = np.random.default_rng(8)
+    user = torch.from_numpy(rng.standard_normal((5, 1, 96)).astype(np.float32))
+    cand_rows = torch.from_numpy(rng.standard_normal((5, 7, 96)).astype(np.float32))      # [B, C, D]: the reference permutes it
+    g = torch.from_numpy(rng.standard_normal((5, 7)).astype(np.float32))
+    u1, c1 = user.clone().to(DEV).requires_grad_(True), cand_rows.clone().to(DEV).requires_grad_(True)
+    from manner_amd.models.components.click_predictors import DotProduct
+    out = DotProduct()(u1, c1.permute(0, 2, 1))
+    (out * g.to(DEV)).sum().backward()
+    u2, c2 = user.clone().requires_grad_(True), cand_rows.clone().requires_grad_(True)
+    ref = torch.bmm(u2, c2.permute(0, 2, 1)).squeeze(1)
+    (ref * g).sum().backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 1e-4
+    assert (u1.grad.cpu() - u2.grad).abs().max() < 1e-4 and (c1.grad.cpu() - c2.grad).abs().max() < 1e-5
+
+
+def test_cr_train_step_end_to_end_matches_oracle():
+    """One CR-Module training step through the module mirror (train() mode, frozen_layers=[0], embeddings trainable as in
+    the reference): loss and the gradients of every trainable tensor against autograd over the oracle pipeline; then an
+    AdamW step of the reference's optimiser type actually lowers the loss."""
+    import warnings
+    from manner_amd import hotpath
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder
+    from manner_amd.synth import segment_ids, synth_impressions
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=70, std=0.05, with_pooler=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder(plm_model="tiny-bert", frozen_layers=[0], dropout_probability=0.0, use_entities=False,
+                                entity_embeddings=None, entity_embedding_dim=100, num_attention_heads=10, query_vector_dim=200,
+                                text_embedding_dim=cfg.hidden)
+    enc.load_state_dict({"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    te = enc.text_encoder
+    te.train_precision = "fp32"
+    te.plm_model.hidden_dropout_prob = te.plm_model.attention_probs_dropout_prob = 0.0
+    ids_np, mask_np = synth_news_tokens(40, cfg, seed=70, max_len=16)
+    imp = synth_impressions(6, 40, seed=70, max_hist=5, max_cand=4)
+    hist_idx, hist_off, cand_idx, cand_off = imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"]
+    labels = imp["labels"].astype(np.float32)
+    batch = {"x_hist": {"text": {"input_ids": torch.from_numpy(ids_np[hist_idx]).to(DEV), "attention_mask": torch.from_numpy(mask_np[hist_idx]).to(DEV)}},
+             "x_cand": {"text": {"input_ids": torch.from_numpy(ids_np[cand_idx]).to(DEV), "attention_mask": torch.from_numpy(mask_np[cand_idx]).to(DEV)}},
+             "batch_hist": torch.from_numpy(segment_ids(hist_off)).to(DEV), "batch_cand": torch.from_numpy(segment_ids(cand_off)).to(DEV),
+             "labels": torch.from_numpy(labels).to(DEV), "users": torch.arange(6, device=DEV)}
+    loss, scores, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)
+    loss.backward()
+    frozen = {k for k in w if "layer.0." in k or k.startswith("pooler.")}
+    wt = {k: torch.from_numpy(v).requires_grad_(k not in frozen) for k, v in w.items() if not k.startswith("pooler.")}
+    hv = O.encode_cls_train(ids_np[hist_idx], mask_np[hist_idx], wt, cfg)
+    cv = O.encode_cls_train(ids_np[cand_idx], mask_np[cand_idx], wt, cfg)
+    dense = O.cr_scores(hv, torch.from_numpy(segment_ids(hist_off)), cv, torch.from_numpy(segment_ids(cand_off)))
+    ref_scores = O.ragged(dense, torch.from_numpy(segment_ids(cand_off)))
+    ref_loss, _ = O.model_step_loss(ref_scores, torch.from_numpy(labels), list(cand_off), supcon=True, temperature=0.36)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * max(1.0, abs(float(ref_loss.detach())))
+    for k, p in te.plm_model.named_parameters():
+        if k in frozen:
+            assert p.grad is None, k
+        else:
+            assert _rel(p.grad.cpu().numpy(), wt[k].grad.numpy()) < 2e-3, (k, _rel(p.grad.cpu().numpy(), wt[k].grad.numpy()))
+    opt = torch.optim.AdamW([p for p in enc.parameters() if p.requires_grad], lr=1e-3)
+    first = float(loss.detach())
+    for _ in range(5):
+        opt.step()
+        opt.zero_grad()
+        loss, _, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)
+        loss.backward()
+    assert float(loss.detach()) < first
