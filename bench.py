@@ -88,6 +88,7 @@ def parse():
     p.add_argument("--no-table", action="store_true", help="skip the table-mode (encode pool once + all-gather) leg")
     p.add_argument("--no-scale-parity", action="store_true", help="skip the at-scale bf16-vs-fp32 ranking comparison")
     p.add_argument("--no-small-ops", action="store_true", help="skip the pooler / dot / z-score kernel legs")
+    p.add_argument("--no-train", action="store_true", help="skip the training-step leg (SURVEY §8f-3)")
     return p.parse_args()
 
 
@@ -344,6 +345,67 @@ def small_ops_leg(dev, B=4096, S=50, D=768, Q=200, C=37):
         nbytes = cvec.numel() * 4 + nb * width * D * 4
         out["to_dense"] = {"shape": {"B": nb, "width": width, "D": D, "rows": int(cvec.shape[0])}, "ms": ms,
                            "algorithmic_bytes": nbytes, "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+    return out
+
+
+def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4, 5, 6, 7), steps=3):
+    """one CR-Module training step (cr_module.py:140-171) on the HIP engine — encoder in train() mode with its
+    dropouts (0.1 / 0.1 / 0.2), fused late-fusion scorer, SupCon loss, backward into every trainable tensor, then
+    torch.optim.AdamW (the optimiser stays the reference's).  Batch: `impressions` users with a history of <= 50 news and
+    1 + `neg` candidates (neg_sampling_ratio 4), title-length news, `frozen` layers frozen as in configs/model/cr_module.yaml:10.
+    Two variants: the reference's default (embeddings trainable: the backward runs through all layers) and embeddings
+    frozen as well (the frozen prefix is run once by the inference engine, training starts at layer 8)."""
+    from manner_amd import hotpath, train
+    from manner_amd.weights import make_plm_weights
+    rng = np.random.default_rng(11)
+    h = np.clip(np.rint(rng.lognormal(np.log(22.0), 0.9, impressions)), 1, 50).astype(np.int64)
+    c = np.full(impressions, 1 + neg, np.int64)
+    n_hist, n_cand = int(h.sum()), int(c.sum())
+    ids_np, mask_np = synth_news_tokens(n_hist + n_cand, cfg, seed=11, max_len=32)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    seg = lambda cnt: torch.repeat_interleave(torch.arange(impressions), torch.from_numpy(cnt)).to(dev)      # noqa: E731
+    labels = torch.zeros(n_cand, device=dev)
+    labels[:: 1 + neg] = 1.0
+    batch = {"x_hist": {"input_ids": ids[:n_hist], "attention_mask": mask[:n_hist]},
+             "x_cand": {"input_ids": ids[n_hist:], "attention_mask": mask[n_hist:]},
+             "batch_hist": seg(h), "batch_cand": seg(c), "labels": labels, "users": torch.arange(impressions, device=dev)}
+    tokens = int(mask_np.sum())
+    w = make_plm_weights(cfg, seed=42, std=0.02, with_pooler=False)
+    out = {"what": train_leg.__doc__.split("  Batch")[0].strip(), "precision": precision + " GEMM operands, f32 accumulation / activations / gradients",
+           "impressions_per_step": impressions, "news_per_step": n_hist + n_cand, "tokens_per_step": tokens, "frozen_layers": list(frozen)}
+    for variant, emb_trainable in (("reference_default_embeddings_trainable", True), ("embeddings_frozen_cached_prefix", False)):
+        params = {k: torch.from_numpy(v).to(dev).requires_grad_((emb_trainable or not k.startswith("embeddings.")) and
+                                                                   not any(f"layer.{l}." in k for l in frozen)) for k, v in w.items()}
+        engine = None if emb_trainable else hip.HipEncoder(cfg, w, precisions=(precision,), device=dev)
+        opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-5)
+        step_no = [0]
+
+        def enc(x):
+            step_no[0] += 1
+            return train.encode_train(cfg, params, x["input_ids"], x["attention_mask"], precision=precision, p_hidden=0.1, p_attn=0.1,
+                                      p_out=0.2, seed=step_no[0], prefix_engine=engine)
+
+        def step():
+            loss, _, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+
+        first = float(step().detach())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[variant] = {"ms_per_step": dt * 1e3, "tokens_per_s": tokens / dt, "news_per_s": (n_hist + n_cand) / dt,
+                        "impressions_per_s": impressions / dt, "loss_first_step": first, "loss_last_step": float(last.detach()),
+                        "peak_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+        if engine is not None:
+            engine.close()
+        del params, opt
+        torch.cuda.empty_cache()
     return out
 
 
@@ -713,6 +775,9 @@ def main():
         cpu, par = cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
         result["cpu_baseline"] = cpu
         result["parity"] = par
+    if rank == 0 and world == 1 and not args.no_train and cfg.head_dim == 64:
+        log("training-step leg (train() mode encoder + scorer + SupCon + backward + AdamW)")
+        result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

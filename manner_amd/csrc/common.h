@@ -80,6 +80,11 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
             const void* residual, void* Y, int64_t m_bound, int N, int K, const int* m_total,
             hipStream_t stream);
 
+// `batch` independent problems Y_b [rows, N] f32 = X_b [rows, K] . W_b [N, K]^T + bias (16-bit operands `in`; rows, N
+// multiples of 256, K % 64 == 0, K >= 128) in ONE launch; problem b lives at element offsets b * {xs, ws, ys}.
+int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias, float* Y, int batch, int64_t xs, int64_t ws,
+                      int64_t ys, int rows, int N, int K, const int* m_total, hipStream_t stream);
+
 // Deferred-LayerNorm GEMMs (16-bit elements `dt` in/out, 256x256 tiles: N % 256 == 0, m_bound % 256 == 0, K >= 128).  The residual
 // stream holds pre-LayerNorm sums `raw` plus per-row {mean, rstd} (`mr`, float2 [m_bound]):
 //   EPI_NORM / EPI_NORM_GELU : Y = [gelu]( rstd * (X W'^T - mean * vec) + bias ),  X = raw, W' = gamma-folded weight,

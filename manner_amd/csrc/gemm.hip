@@ -619,6 +619,9 @@ struct DlnAux {
                           // a wave's 16 rows per store instruction are one contiguous 128-byte line)
   int64_t part_stride;    // m_bound
   int col_group;          // column tiles per pass over the rows (0 = all): see the tile order in the kernel
+  // EPI_BIAS only: gridDim.y independent problems of the same shape (problem y reads X + y * batch_x, W + y * batch_w
+  // and writes Y + y * batch_y, elements) — the split-K slices of the training path's weight-gradient GEMMs
+  int64_t batch_x, batch_w, batch_y;
 };
 
 template <typename TE, typename TOut, int EPI, int ABL = 0>
@@ -635,6 +638,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
   constexpr int XB = 2 * G_OP_BYTES;                                        // base of the activation ring
 
+  if constexpr (EPI == EPI_BIAS) {
+    X += (size_t)blockIdx.y * dln.batch_x;
+    W += (size_t)blockIdx.y * dln.batch_w;
+    Y += (size_t)blockIdx.y * dln.batch_y;
+  }
   const int G = gridDim.x, b = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
   const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
@@ -1177,6 +1185,28 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group};
   if (dt == DT_F16) return launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
   return launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+}
+
+// `batch` independent Y_b [rows, N] (f32) = X_b [rows, K] . W_b [N, K]^T + bias on 16-bit operands, problem b at element
+// offsets b * {xs, ws, ys}; rows, N multiples of 256, K a multiple of 64 and >= 128.  One launch, gridDim.y = batch.
+int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias, float* Y, int batch, int64_t xs, int64_t ws,
+                      int64_t ys, int rows, int N, int K, const int* m_total, hipStream_t stream) {
+  if (!is_16bit(in) || rows % G_BM || N % G_BN || K % 64 || K < 128 || batch < 1 || batch > 65535)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_batched16: rows=%d N=%d K=%d batch=%d", rows, N, K, batch);
+  const int n_tiles = N / G_BN;
+  const int tiles = (rows / G_BM) * n_tiles;
+  const int n_cus = device_cus();
+  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus), (unsigned)batch), b(512);
+  DlnAux aux{};
+  aux.batch_x = xs; aux.batch_w = ws; aux.batch_y = ys;
+  if (in == DT_F16)
+    hipLaunchKernelGGL((gemm_tn_x16_kernel<f16_t, float, EPI_BIAS>), g, b, 0, stream, static_cast<const f16_t*>(X),
+                       static_cast<const f16_t*>(W), bias, static_cast<const f16_t*>(nullptr), Y, N, K, m_total, n_tiles, aux);
+  else
+    hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, float, EPI_BIAS>), g, b, 0, stream, static_cast<const bf16_t*>(X),
+                       static_cast<const bf16_t*>(W), bias, static_cast<const bf16_t*>(nullptr), Y, N, K, m_total, n_tiles, aux);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
 }
 
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,

@@ -281,10 +281,12 @@ __global__ __launch_bounds__(256) void cls_bwd_kernel(const float* __restrict__ 
 }
 
 // out[c][r] = T(in[r][c]) for r < rows_valid, 0 for rows_valid <= r < rows_out  (operands of the gradient GEMMs)
+// `ks` < rows_out: slice-major output for the split weight-gradient GEMMs — slice s = rows [s * ks, (s + 1) * ks) is its own
+// contiguous [cols, ks] matrix at offset s * cols * ks.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t cols, T* __restrict__ out,
                                                         int64_t rows_out, const int* __restrict__ rows_valid_dev,
-                                                        int64_t rows_valid_host) {
+                                                        int64_t rows_valid_host, int64_t ks) {
   __shared__ float tile[32][33];
   const int64_t rv = rows_valid_dev ? (int64_t)rows_valid_dev[0] : rows_valid_host;
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
@@ -298,7 +300,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
-    if (c < cols && r < rows_out) out[(size_t)c * rows_out + r] = (T)tile[tx][ty + 8 * k];
+    if (c < cols && r < rows_out) {
+      const int64_t sl = r / ks, rr = r - sl * ks;
+      out[((size_t)sl * cols + c) * ks + rr] = (T)tile[tx][ty + 8 * k];
+    }
   }
 }
 
@@ -306,8 +311,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // qkv [m, 3H] = [Q | K | V]; one workgroup per (head, news), thread i owns query row i (S <= 256), keys in chunks of
 // KC through LDS.  P = softmax(q k^T / 8), Pd = dropout(P) (modeling_bert.py:128-140: dropout on the probabilities),
 // ctx = Pd v.  The forward keeps {row max, row sum} so the backward rebuilds P without a reduction pass.
-constexpr int AD = 64, KC = 32, AT = 256;
+constexpr int AD = 64, KC = 32;        // AT = threads per workgroup = rows it can own: 64 / 128 / 256, picked from padded_len
 
+template <int AT>
 __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
                                                             int H, Drop drop) {
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
 }
 
 // query-row owner: D_i = sum_j dP_ij P_ij, then dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
+template <int AT>
 __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                               const float2* __restrict__ ml, float* __restrict__ dqkv,
                                                               float* __restrict__ dsum, const int32_t* __restrict__ cu,
@@ -417,6 +424,7 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
 }
 
 // key-row owner: dk_j = sum_i dS_ij q_i / 8, dv_j = sum_i Pd_ij dctx_i
+template <int AT>
 __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                const float2* __restrict__ ml, const float* __restrict__ dsum,
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
@@ -658,16 +666,18 @@ void plan_saved(Bump& b, Saved& s, const manner_hip_encoder_config& c, int64_t N
   }
 }
 
+constexpr int WGRAD_MAX_SLICES = 64;
 struct Work {
   void *a16, *b16;                 // operand copies (16-bit modes) / transposed operands (all modes): each max(I,3H) * max(Mb, H) elements of 4 bytes
   float *wcat, *bcat, *zero, *tmp; // [3H, H] concatenated Q|K|V weight, its bias, a zero bias, one [Mb, max(I,3H)] temporary
   float *dx, *dr, *dbig, *dqkv, *dsum, *dw, *part;
+  float* dwp;                      // partial weight gradients of the split GEMMs: [slices][Nout, K]
   int32_t* dims;                   // device ints holding row counts of the weight-gradient GEMMs
 };
 void plan_work(Bump& b, Work& w, const manner_hip_encoder_config& c, int64_t Mb) {
   const size_t H = c.hidden, I = c.intermediate;
   const size_t wide = I > 3 * H ? I : 3 * H;
-  const size_t rows = (size_t)Mb > wide ? (size_t)Mb : wide;
+  const size_t rows = ((size_t)Mb > wide ? (size_t)Mb : wide) + 64 * WGRAD_MAX_SLICES;     // + the split GEMMs' slice padding
   w.a16 = b.take<float>(wide * rows);
   w.b16 = b.take<float>(wide * rows);
   w.wcat = b.take<float>(3 * H * H);
@@ -681,6 +691,7 @@ void plan_work(Bump& b, Work& w, const manner_hip_encoder_config& c, int64_t Mb)
   w.dsum = b.take<float>(Mb * c.heads);
   w.dw = b.take<float>(wide * (I > H ? I : H));
   w.part = b.take<float>(2 * (size_t)LN_BWD_BLOCKS * wide);
+  w.dwp = b.take<float>((size_t)1024 * 65536 + wide * (I > H ? I : H));    // slices * Nout * K <= (#CUs <= 1024) * 256 * 256 + Nout * K
   w.dims = b.take<int32_t>(16);
 }
 
@@ -722,16 +733,19 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
 }
 
 template <typename T>
-void launch_transpose(const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host,
+void launch_transpose(const float* in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host, int64_t ks,
                       hipStream_t s) {
-  (void)rows_in;
   dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows_out + 31) / 32));
-  hipLaunchKernelGGL(transpose_kernel<T>, g, dim3(256), 0, s, in, cols, static_cast<T*>(out), rows_out, rv_dev, rv_host);
+  hipLaunchKernelGGL(transpose_kernel<T>, g, dim3(256), 0, s, in, cols, static_cast<T*>(out), rows_out, rv_dev, rv_host, ks);
 }
-int transpose_to(Ctx& t, const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host) {
-  if (t.dt() == DT_F32) launch_transpose<float>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
-  else if (t.dt() == DT_F16) launch_transpose<f16_t>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
-  else launch_transpose<bf16_t>(in, rows_in, cols, out, rows_out, rv_dev, rv_host, t.s);
+// rows_in is documentation: `in` is [rows_in, cols]; ks = 0: one slice
+int transpose_to(Ctx& t, const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host,
+                 int64_t ks = 0) {
+  (void)rows_in;
+  if (ks <= 0) ks = rows_out;
+  if (t.dt() == DT_F32) launch_transpose<float>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  else if (t.dt() == DT_F16) launch_transpose<f16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  else launch_transpose<bf16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -751,6 +765,28 @@ int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, i
 // dW [Nout, K] = dY [Mb, Nout]^T . X [Mb, K]   (the reduction runs over the token rows; rows >= *m_total contribute zeros)
 int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, int K, int dim_slot) {
   int rc;
+  if (t.dt() != DT_F32 && Nout % 256 == 0 && K % 256 == 0) {
+    // Few output tiles, one long reduction: split the token axis into `slices` independent GEMMs of one launch
+    // (gridDim.y) so that every CU has a tile, then add the partial gradients in a fixed order.
+    const int tiles = (Nout / 256) * (K / 256);
+    int slices = (device_cus() + tiles - 1) / tiles;
+    const int64_t max_slices = t.Mb / 128;
+    if (slices > max_slices) slices = (int)max_slices;
+    if (slices > WGRAD_MAX_SLICES) slices = WGRAD_MAX_SLICES;
+    if (slices >= 2) {
+      const int64_t ks = round_up((t.Mb + slices - 1) / slices, 64), Mp = ks * slices;
+      if ((rc = transpose_to(t, dY, t.Mb, Nout, t.wk.a16, Mp, t.sv.m_total, 0, ks))) return rc;     // [slices][Nout, ks]
+      if ((rc = transpose_to(t, X, t.Mb, K, t.wk.b16, Mp, t.sv.m_total, 0, ks))) return rc;          // [slices][K, ks]
+      if ((rc = set_device_int(t.wk.dims + dim_slot, Nout, t.s))) return rc;
+      if ((rc = gemm_tn_batched16(t.dt(), t.wk.a16, t.wk.b16, t.wk.zero, t.wk.dwp, slices, (int64_t)Nout * ks, (int64_t)K * ks,
+                                  (int64_t)Nout * K, Nout, K, (int)ks, t.wk.dims + dim_slot, t.s)))
+        return rc;
+      const int64_t width = (int64_t)Nout * K;
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.dwp, slices, (int)width, dW);
+      MANNER_LAUNCH_CHECK();
+      return MANNER_HIP_OK;
+    }
+  }
   if ((rc = transpose_to(t, dY, t.Mb, Nout, t.wk.a16, t.Mb, t.sv.m_total, 0))) return rc;  // dY^T [Nout, Mb]
   if ((rc = transpose_to(t, X, t.Mb, K, t.wk.b16, t.Mb, t.sv.m_total, 0))) return rc;      // X^T  [K, Mb]
   if ((rc = set_device_int(t.wk.dims + dim_slot, Nout, t.s))) return rc;
@@ -898,9 +934,14 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
     LayerSaved& L = sv.l[l];
     if ((rc = pack_qkv_weights(t, l))) return rc;
     if ((rc = linear_fwd(t, L.x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, L.ctx, L.ml, sv.cu,
-                       cfg->heads, H, make_drop(seed, layer_site(l, SITE_ATTN), p_attn));
-    MANNER_LAUNCH_CHECK();
+    {
+      const dim3 ag((unsigned)cfg->heads, (unsigned)n_news);
+      const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+      if (padded_len <= 64) hipLaunchKernelGGL(attn_train_fwd_kernel<64>, ag, dim3(64), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
+      else if (padded_len <= 128) hipLaunchKernelGGL(attn_train_fwd_kernel<128>, ag, dim3(128), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
+      else hipLaunchKernelGGL(attn_train_fwd_kernel<256>, ag, dim3(256), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
+      MANNER_LAUNCH_CHECK();
+    }
     if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
     if ((rc = dropout_add(t, t.wk.tmp, L.x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
     if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f)))) return rc;
@@ -985,11 +1026,16 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     if (!below && !qkv_w) break;
     if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H))) return rc;                 // d ctx
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-    hipLaunchKernelGGL(attn_train_bwd_q_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv,
-                       wk.dsum, sv.cu, cfg->heads, H, da);
-    MANNER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_train_bwd_kv_kernel, dim3((unsigned)cfg->heads, (unsigned)n_news), dim3(AT), 0, s, L.qkv, wk.dx, L.ml, wk.dsum,
-                       wk.dqkv, sv.cu, cfg->heads, H, da);
+    const dim3 ag((unsigned)cfg->heads, (unsigned)n_news);
+#define MANNER_ATTN_BWD(AT_)                                                                                                      \
+  do {                                                                                                                            \
+    hipLaunchKernelGGL(attn_train_bwd_q_kernel<AT_>, ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
+    hipLaunchKernelGGL(attn_train_bwd_kv_kernel<AT_>, ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da); \
+  } while (0)
+    if (padded_len <= 64) MANNER_ATTN_BWD(64);
+    else if (padded_len <= 128) MANNER_ATTN_BWD(128);
+    else MANNER_ATTN_BWD(256);
+#undef MANNER_ATTN_BWD
     MANNER_LAUNCH_CHECK();
     if (qkv_w) {
       if ((rc = bias_grad(t, wk.dqkv, 3 * H, wk.dw))) return rc;

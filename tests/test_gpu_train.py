@@ -288,3 +288,30 @@ def test_cr_train_step_end_to_end_matches_oracle():
         loss, _, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)
         loss.backward()
     assert float(loss.detach()) < first
+
+
+def test_train_at_base_width_exercises_the_256_tile_and_split_gemms():
+    """Two layers of bert-base WIDTH (H = 768, 12 heads, I = 3072): the 256x256 GEMM kernels, the batched (split over the
+    token axis) weight-gradient GEMMs of the 16-bit modes, 3-vector LayerNorm rows.  fp32 against the oracle's autograd,
+    f16 against fp32."""
+    from manner_amd.config import EncoderConfig
+    cfg = EncoderConfig(hidden=768, layers=2, heads=12, intermediate=3072, vocab=1024, max_pos=64)
+    w = make_plm_weights(cfg, seed=64, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(40, cfg, seed=64, max_len=24)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(3).standard_normal((40, cfg.hidden)).astype(np.float32))
+    res = {}
+    for prec in ("fp32", "f16"):
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=prec, p_hidden=0.0, p_attn=0.0, p_out=0.0)
+        (out * R.to(DEV)).sum().backward()
+        res[prec] = (out.detach().cpu().numpy(), _grads(params))
+    wt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    ref = O.encode_cls_train(ids_np, mask_np, wt, cfg)
+    (ref * R).sum().backward()
+    assert np.abs(res["fp32"][0] - ref.detach().numpy()).max() < 1e-4
+    for k, v in wt.items():
+        assert _rel(res["fp32"][1][k], v.grad.numpy()) < 2e-3, (k, _rel(res["fp32"][1][k], v.grad.numpy()))
+        a, b = res["f16"][1][k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
+        if np.abs(b).max() > 1e-6:
+            assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.999, k
