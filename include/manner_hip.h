@@ -340,7 +340,7 @@ int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t
  *
  *   weights : HOST array of n_weights device pointers (f32, the order of manner_hip_encoder_create) — the live master
  *             parameters, read at every call (nothing is cached between optimiser steps);
- *   ids / mask / n_news / padded_len : as manner_hip_encode_cls (padded_len <= 256);
+ *   ids / mask / n_news / padded_len : as manner_hip_encode_cls (padded_len <= MANNER_HIP_MAX_LEN);
  *   m_bound : rows every activation buffer holds: a multiple of 256, >= the number of real tokens (n_news * padded_len
  *             rounded up always works; a device-side check raises MANNER_HIP_STATUS_LENGTHS otherwise);
  *   precision : MANNER_HIP_PREC_F32 (f32 MFMA GEMMs) or _F16 / _BF16 (GEMM operands rounded to 16 bits, f32 accumulation,

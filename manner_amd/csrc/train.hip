@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial sums of dgamma = dy * xhat and
 // dbeta = dy over the rows this block visits (deterministic second stage: reduce_partials_kernel).
 // `dy` may alias `dx`.
-constexpr int LN_BWD_BLOCKS = 256;
+constexpr int LN_BWD_BLOCKS = 128;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
                                                      float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
@@ -220,21 +220,32 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
                                                               float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= width) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * width + c];
-  out[c] = s;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};                  // four loads in flight per thread; the order of the sum stays fixed
+  int b = 0;
+  for (; b + 4 <= blocks; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += partial[(size_t)(b + u) * width + c];
+  }
+  for (; b < blocks; ++b) s[0] += partial[(size_t)b * width + c];
+  out[c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 // partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
-constexpr int COLSUM_BLOCKS = 128;
+// grid (ceil(width / 256), COLSUM_BLOCKS): block (x, b) sums 256 columns over the rows b, b + COLSUM_BLOCKS, ...
+constexpr int COLSUM_BLOCKS = 64;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int width, float* __restrict__ partial,
                                                      const int* __restrict__ m_total) {
   const int64_t M = m_total[0];
-  for (int c = threadIdx.x; c < width; c += 256) {
-    float s = 0.f;
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) s += y[(size_t)m * width + c];
-    partial[(size_t)blockIdx.x * width + c] = s;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t m = blockIdx.y;
+  for (; m + 3 * COLSUM_BLOCKS < M; m += 4 * COLSUM_BLOCKS) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += y[(size_t)(m + u * COLSUM_BLOCKS) * width + c];
   }
+  for (; m < M; m += COLSUM_BLOCKS) s[0] += y[(size_t)m * width + c];
+  partial[(size_t)blockIdx.y * width + c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
@@ -308,41 +319,58 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ attention (train)
-// qkv [m, 3H] = [Q | K | V]; one workgroup per (head, news), thread i owns query row i (S <= 256), keys in chunks of
-// KC through LDS.  P = softmax(q k^T / 8), Pd = dropout(P) (modeling_bert.py:128-140: dropout on the probabilities),
-// ctx = Pd v.  The forward keeps {row max, row sum} so the backward rebuilds P without a reduction pass.
-constexpr int AD = 64, KC = 32;        // AT = threads per workgroup = rows it can own: 64 / 128 / 256, picked from padded_len
+// qkv [m, 3H] = [Q | K | V].  A workgroup of AT threads serves one news and HPB heads: thread (hs, i) owns query row i of
+// head blockIdx.x * HPB + hs, so short sequences (news titles: <= 32 tokens) still fill a 64-lane wave; keys go through
+// LDS in chunks of KC = 32 / HPB per head (each head's chunk is offset by one word so that the HPB lane groups, which
+// read the same (key, d) of different heads, hit different banks).  P = softmax(q k^T / 8), Pd = dropout(P)
+// (modeling_bert.py:128-140: dropout on the probabilities), ctx = Pd v.  The forward keeps {row max, row sum} so the
+// backward rebuilds P without a reduction pass.
+constexpr int AD = 64;
+template <int HPB> struct AttnGeom {
+  static constexpr int KC = 32 / HPB;                 // keys per chunk and head
+  static constexpr int HS = KC * AD + 1;              // words between two heads' chunks
+};
 
-template <int AT>
+template <int AT, int HPB>
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, size_t ld, int col0, int row0, int S, float scale) {
+  // dst[hs][r][d] = src[(row0 + r) * ld + col0 + hs * AD + d] * scale for r < KC (0 beyond S)
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS;
+  for (int e = threadIdx.x; e < HPB * KC * AD; e += AT) {
+    const int hs = e / (KC * AD), rem = e - hs * (KC * AD), r = rem / AD, d = rem - r * AD;
+    dst[hs * HS + r * AD + d] = row0 + r < S ? src[(size_t)(row0 + r) * ld + col0 + hs * AD + d] * scale : 0.f;
+  }
+}
+
+template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
                                                             int H, Drop drop) {
-  __shared__ float ks[KC][AD], vs[KC][AD];
-  const int h = blockIdx.x;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  __shared__ float ks[HPB * HS], vs[HPB * HS];
+  const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
+  const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
-  const int i = threadIdx.x;
   const bool active = i < S;
   const size_t ld = (size_t)3 * H;
+  const float* rows = qkv + (size_t)base * ld;
   float q[AD], o[AD];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { q[d] = active ? qkv[(size_t)(base + i) * ld + h * AD + d] * 0.125f : 0.f; o[d] = 0.f; }
+  for (int d = 0; d < AD; ++d) { q[d] = active ? rows[(size_t)i * ld + h * AD + d] * 0.125f : 0.f; o[d] = 0.f; }
   float mx = -INFINITY, l = 0.f;
+  const float* kh = ks + hs * HS;
+  const float* vh = vs + hs * HS;
   for (int j0 = 0; j0 < S; j0 += KC) {
     __syncthreads();
-    for (int e = threadIdx.x; e < KC * AD; e += AT) {
-      const int j = e / AD, d = e - j * AD;
-      const bool ok = j0 + j < S;
-      ks[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + H + h * AD + d] : 0.f;
-      vs[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + 2 * H + h * AD + d] : 0.f;
-    }
+    stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
+    stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, S, 1.f);
     __syncthreads();
     if (!active) continue;
     const int cnt = min(KC, S - j0);
     for (int j = 0; j < cnt; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) s = fmaf(q[d], ks[j][d], s);
+      for (int d = 0; d < AD; ++d) s = fmaf(q[d], kh[j * AD + d], s);
       if (s > mx) {
         const float f = expf(mx - s);
         l *= f;
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
       l += p;
       const float pd = drop.apply(p, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
 #pragma unroll
-      for (int d = 0; d < AD; ++d) o[d] = fmaf(pd, vs[j][d], o[d]);
+      for (int d = 0; d < AD; ++d) o[d] = fmaf(pd, vh[j * AD + d], o[d]);
     }
   }
   if (!active) return;
@@ -366,44 +394,44 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
 }
 
 // query-row owner: D_i = sum_j dP_ij P_ij, then dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
-template <int AT>
+template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                               const float2* __restrict__ ml, float* __restrict__ dqkv,
                                                               float* __restrict__ dsum, const int32_t* __restrict__ cu,
                                                               int heads, int H, Drop drop) {
-  __shared__ float ks[KC][AD], vs[KC][AD];
-  const int h = blockIdx.x;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  __shared__ float ks[HPB * HS], vs[HPB * HS];
+  const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
+  const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
-  const int i = threadIdx.x;
   const bool active = i < S;
   const size_t ld = (size_t)3 * H;
+  const float* rows = qkv + (size_t)base * ld;
   float q[AD], go[AD], dq[AD];
 #pragma unroll
   for (int d = 0; d < AD; ++d) {
-    q[d] = active ? qkv[(size_t)(base + i) * ld + h * AD + d] * 0.125f : 0.f;
+    q[d] = active ? rows[(size_t)i * ld + h * AD + d] * 0.125f : 0.f;
     go[d] = active ? dctx[(size_t)(base + i) * H + h * AD + d] : 0.f;
     dq[d] = 0.f;
   }
   const float2 st = active ? ml[(size_t)(base + i) * heads + h] : float2{0.f, 1.f};
   const float inv = 1.f / st.y;
+  const float* kh = ks + hs * HS;
+  const float* vh = vs + hs * HS;
   float D = 0.f;
   for (int pass = 0; pass < 2; ++pass) {
     for (int j0 = 0; j0 < S; j0 += KC) {
       __syncthreads();
-      for (int e = threadIdx.x; e < KC * AD; e += AT) {
-        const int j = e / AD, d = e - j * AD;
-        const bool ok = j0 + j < S;
-        ks[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + H + h * AD + d] : 0.f;
-        vs[j][d] = ok ? qkv[(size_t)(base + j0 + j) * ld + 2 * H + h * AD + d] : 0.f;
-      }
+      stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
+      stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, S, 1.f);
       __syncthreads();
       if (!active) continue;
       const int cnt = min(KC, S - j0);
       for (int j = 0; j < cnt; ++j) {
         float s = 0.f, gv = 0.f;
 #pragma unroll
-        for (int d = 0; d < AD; ++d) { s = fmaf(q[d], ks[j][d], s); gv = fmaf(go[d], vs[j][d], gv); }
+        for (int d = 0; d < AD; ++d) { s = fmaf(q[d], kh[j * AD + d], s); gv = fmaf(go[d], vh[j * AD + d], gv); }
         const float p = expf(s - st.x) * inv;
         const float dp = drop.apply(gv, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
         if (pass == 0) {
@@ -411,7 +439,7 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
         } else {
           const float ds = p * (dp - D) * 0.125f;
 #pragma unroll
-          for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, ks[j][d], dq[d]);
+          for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, kh[j * AD + d], dq[d]);
         }
       }
     }
@@ -424,40 +452,41 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
 }
 
 // key-row owner: dk_j = sum_i dS_ij q_i / 8, dv_j = sum_i Pd_ij dctx_i
-template <int AT>
+template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                const float2* __restrict__ ml, const float* __restrict__ dsum,
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
                                                                int heads, int H, Drop drop) {
-  __shared__ float qs[KC][AD], gs[KC][AD];
-  __shared__ float sm[KC], sl[KC], sd[KC];
-  const int h = blockIdx.x;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  __shared__ float qs[HPB * HS], gs[HPB * HS];
+  __shared__ float sm[HPB][KC], sl[HPB][KC], sd[HPB][KC];
+  const int hs = threadIdx.x / RPH, j = threadIdx.x - hs * RPH;
+  const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
-  const int j = threadIdx.x;
   const bool active = j < S;
   const size_t ld = (size_t)3 * H;
+  const float* rows = qkv + (size_t)base * ld;
   float k[AD], v[AD], dk[AD], dv[AD];
 #pragma unroll
   for (int d = 0; d < AD; ++d) {
-    k[d] = active ? qkv[(size_t)(base + j) * ld + H + h * AD + d] : 0.f;
-    v[d] = active ? qkv[(size_t)(base + j) * ld + 2 * H + h * AD + d] : 0.f;
+    k[d] = active ? rows[(size_t)j * ld + H + h * AD + d] : 0.f;
+    v[d] = active ? rows[(size_t)j * ld + 2 * H + h * AD + d] : 0.f;
     dk[d] = dv[d] = 0.f;
   }
+  const float* qh = qs + hs * HS;
+  const float* gh = gs + hs * HS;
   for (int i0 = 0; i0 < S; i0 += KC) {
     __syncthreads();
-    for (int e = threadIdx.x; e < KC * AD; e += AT) {
-      const int i = e / AD, d = e - i * AD;
-      const bool ok = i0 + i < S;
-      qs[i][d] = ok ? qkv[(size_t)(base + i0 + i) * ld + h * AD + d] * 0.125f : 0.f;
-      gs[i][d] = ok ? dctx[(size_t)(base + i0 + i) * H + h * AD + d] : 0.f;
-    }
-    if (threadIdx.x < KC) {
-      const bool ok = i0 + threadIdx.x < S;
-      const float2 st = ok ? ml[(size_t)(base + i0 + threadIdx.x) * heads + h] : float2{0.f, 1.f};
-      sm[threadIdx.x] = st.x;
-      sl[threadIdx.x] = 1.f / st.y;
-      sd[threadIdx.x] = ok ? dsum[(size_t)(base + i0 + threadIdx.x) * heads + h] : 0.f;
+    stage_rows<AT, HPB>(qs, rows, ld, h0 * AD, i0, S, 0.125f);
+    stage_rows<AT, HPB>(gs, dctx + (size_t)base * H, (size_t)H, h0 * AD, i0, S, 1.f);
+    if (threadIdx.x < HPB * KC) {
+      const int sh = threadIdx.x / KC, r = threadIdx.x - sh * KC;
+      const bool ok = i0 + r < S;
+      const float2 st = ok ? ml[(size_t)(base + i0 + r) * heads + h0 + sh] : float2{0.f, 1.f};
+      sm[sh][r] = st.x;
+      sl[sh][r] = 1.f / st.y;
+      sd[sh][r] = ok ? dsum[(size_t)(base + i0 + r) * heads + h0 + sh] : 0.f;
     }
     __syncthreads();
     if (!active) continue;
@@ -465,14 +494,14 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
     for (int i = 0; i < cnt; ++i) {
       float s = 0.f, gv = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) { s = fmaf(qs[i][d], k[d], s); gv = fmaf(gs[i][d], v[d], gv); }
-      const float p = expf(s - sm[i]) * sl[i];
+      for (int d = 0; d < AD; ++d) { s = fmaf(qh[i * AD + d], k[d], s); gv = fmaf(gh[i * AD + d], v[d], gv); }
+      const float p = expf(s - sm[hs][i]) * sl[hs][i];
       const uint64_t idx = ((uint64_t)(base + i0 + i) * heads + h) * 256 + (uint64_t)j;
       const float dp = drop.apply(gv, idx);
       const float pd = drop.apply(p, idx);
-      const float ds = p * (dp - sd[i]);         // qs already carries the 1/8
+      const float ds = p * (dp - sd[hs][i]);         // qs already carries the 1/8
 #pragma unroll
-      for (int d = 0; d < AD; ++d) { dk[d] = fmaf(ds, qs[i][d], dk[d]); dv[d] = fmaf(pd, gs[i][d], dv[d]); }
+      for (int d = 0; d < AD; ++d) { dk[d] = fmaf(ds, qh[i * AD + d], dk[d]); dv[d] = fmaf(pd, gh[i * AD + d], dv[d]); }
     }
   }
   if (!active) return;
@@ -481,6 +510,15 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
 #pragma unroll
   for (int d = 0; d < AD; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
 }
+
+// launch geometry from the padded length (<= MANNER_HIP_MAX_LEN = 128): rows per head = 16 / 32 / 64 / 128, up to 4 heads per 64-lane workgroup
+#define MANNER_ATTN_DISPATCH(LP, HEADS, CALL)                   \
+  do {                                                          \
+    if ((LP) <= 16 && (HEADS) % 4 == 0) { CALL(64, 4); }        \
+    else if ((LP) <= 32 && (HEADS) % 2 == 0) { CALL(64, 2); }   \
+    else if ((LP) <= 64) { CALL(64, 1); }                       \
+    else { CALL(128, 1); }                                      \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------ scorer + loss (train)
 // CRModule.forward with late_fusion=True in training (cr_module.py:105-131): every occurrence is encoded, so the
@@ -701,7 +739,8 @@ int check_cfg(const manner_hip_encoder_config* c, int64_t N, int64_t Lp, int64_t
       c->layers <= 0 || c->layers > 64)
     return fail(MANNER_HIP_E_INVALID, "train: unsupported architecture H=%d I=%d heads=%d layers=%d", c->hidden, c->intermediate,
                 c->heads, c->layers);
-  if (N <= 0 || Lp <= 0 || Lp > 256) return fail(MANNER_HIP_E_INVALID, "train: n_news=%lld padded_len=%lld (padded_len <= 256)", (long long)N, (long long)Lp);
+  if (N <= 0 || Lp <= 0 || Lp > MANNER_HIP_MAX_LEN)
+    return fail(MANNER_HIP_E_INVALID, "train: n_news=%lld padded_len=%lld (padded_len <= %d, as the inference engine)", (long long)N, (long long)Lp, MANNER_HIP_MAX_LEN);
   if (Mb <= 0 || Mb % 256 || Mb > 0x7fffff00ll / (3 * (int64_t)c->hidden)) return fail(MANNER_HIP_E_INVALID, "train: m_bound=%lld must be a positive multiple of 256 within int range", (long long)Mb);
   if (precision != MANNER_HIP_PREC_F32 && precision != MANNER_HIP_PREC_BF16 && precision != MANNER_HIP_PREC_F16)
     return fail(MANNER_HIP_E_INVALID, "train: precision %d (fp32, bf16, f16)", precision);
@@ -794,7 +833,7 @@ int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, i
 }
 
 int bias_grad(Ctx& t, const float* dY, int width, float* db) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(COLSUM_BLOCKS), dim3(256), 0, t.s, dY, width, t.wk.part, t.sv.m_total);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((width + 255) / 256), COLSUM_BLOCKS), dim3(256), 0, t.s, dY, width, t.wk.part, t.sv.m_total);
   MANNER_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.part, COLSUM_BLOCKS, width, db);
   MANNER_LAUNCH_CHECK();
@@ -935,11 +974,12 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
     if ((rc = pack_qkv_weights(t, l))) return rc;
     if ((rc = linear_fwd(t, L.x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
     {
-      const dim3 ag((unsigned)cfg->heads, (unsigned)n_news);
       const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-      if (padded_len <= 64) hipLaunchKernelGGL(attn_train_fwd_kernel<64>, ag, dim3(64), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
-      else if (padded_len <= 128) hipLaunchKernelGGL(attn_train_fwd_kernel<128>, ag, dim3(128), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
-      else hipLaunchKernelGGL(attn_train_fwd_kernel<256>, ag, dim3(256), 0, s, L.qkv, L.ctx, L.ml, sv.cu, cfg->heads, H, da);
+#define MANNER_ATTN_FWD(AT_, HPB_)                                                                                             \
+  hipLaunchKernelGGL((attn_train_fwd_kernel<AT_, HPB_>), dim3((unsigned)(cfg->heads / HPB_), (unsigned)n_news), dim3(AT_), 0, s, L.qkv, \
+                     L.ctx, L.ml, sv.cu, cfg->heads, H, da)
+      MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_FWD);
+#undef MANNER_ATTN_FWD
       MANNER_LAUNCH_CHECK();
     }
     if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
@@ -1026,15 +1066,13 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     if (!below && !qkv_w) break;
     if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H))) return rc;                 // d ctx
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-    const dim3 ag((unsigned)cfg->heads, (unsigned)n_news);
-#define MANNER_ATTN_BWD(AT_)                                                                                                      \
+#define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
-    hipLaunchKernelGGL(attn_train_bwd_q_kernel<AT_>, ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
-    hipLaunchKernelGGL(attn_train_bwd_kv_kernel<AT_>, ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da); \
+    const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
+    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
+    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da); \
   } while (0)
-    if (padded_len <= 64) MANNER_ATTN_BWD(64);
-    else if (padded_len <= 128) MANNER_ATTN_BWD(128);
-    else MANNER_ATTN_BWD(256);
+    MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);
 #undef MANNER_ATTN_BWD
     MANNER_LAUNCH_CHECK();
     if (qkv_w) {

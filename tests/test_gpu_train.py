@@ -172,7 +172,7 @@ def test_train_from_cached_frozen_prefix():
 def test_train_rejects_what_it_cannot_do():
     cfg = PRESETS["tiny-bert"]
     w = _params(make_plm_weights(cfg, seed=1, std=0.05, with_pooler=False))
-    ids = torch.zeros((2, 300), dtype=torch.int64, device=DEV)
+    ids = torch.zeros((2, 129), dtype=torch.int64, device=DEV)
     with pytest.raises(RuntimeError, match="padded_len"):
         train.encode_train(cfg, w, ids, torch.ones_like(ids), precision="fp32")
     with pytest.raises(ValueError, match="precision"):
@@ -290,14 +290,15 @@ def test_cr_train_step_end_to_end_matches_oracle():
     assert float(loss.detach()) < first
 
 
-def test_train_at_base_width_exercises_the_256_tile_and_split_gemms():
+@pytest.mark.parametrize("max_len", [24, 12])
+def test_train_at_base_width_exercises_the_256_tile_and_split_gemms(max_len):
     """Two layers of bert-base WIDTH (H = 768, 12 heads, I = 3072): the 256x256 GEMM kernels, the batched (split over the
     token axis) weight-gradient GEMMs of the 16-bit modes, 3-vector LayerNorm rows.  fp32 against the oracle's autograd,
     f16 against fp32."""
     from manner_amd.config import EncoderConfig
     cfg = EncoderConfig(hidden=768, layers=2, heads=12, intermediate=3072, vocab=1024, max_pos=64)
     w = make_plm_weights(cfg, seed=64, std=0.03, with_pooler=False)
-    ids_np, mask_np = synth_news_tokens(40, cfg, seed=64, max_len=24)
+    ids_np, mask_np = synth_news_tokens(40, cfg, seed=64, max_len=max_len)     # 12: four heads per attention workgroup, 24: two
     ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
     R = torch.from_numpy(np.random.default_rng(3).standard_normal((40, cfg.hidden)).astype(np.float32))
     res = {}
@@ -313,5 +314,29 @@ def test_train_at_base_width_exercises_the_256_tile_and_split_gemms():
     for k, v in wt.items():
         assert _rel(res["fp32"][1][k], v.grad.numpy()) < 2e-3, (k, _rel(res["fp32"][1][k], v.grad.numpy()))
         a, b = res["f16"][1][k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
-        if np.abs(b).max() > 1e-6:
+        if np.abs(b).max() > 1e-5:          # the key-bias gradient is analytically zero: rounding noise has no direction
             assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.999, k
+
+
+@pytest.mark.parametrize("max_len", [60, 120])
+def test_train_attention_geometries(max_len):
+    """One head per 64 / 128-thread attention workgroup (padded lengths <= 64 / 128 = MANNER_HIP_MAX_LEN), dropout on."""
+    from manner_amd.config import EncoderConfig
+    cfg = EncoderConfig(hidden=128, layers=1, heads=2, intermediate=128, vocab=512, max_pos=256)
+    w = make_plm_weights(cfg, seed=65, std=0.05, with_pooler=False)
+    lengths = np.array([2, max_len // 3, max_len - 1, max_len, 33][: 5])
+    ids_np, mask_np = synth_news_tokens(5, cfg, seed=65, max_len=max_len, lengths=np.minimum(lengths, max_len))
+    R = torch.from_numpy(np.random.default_rng(4).standard_normal((5, cfg.hidden)).astype(np.float32))
+    seed, ph, pa, po = 77, 0.1, 0.1, 0.2
+    params = _params(w)
+    out = train.encode_train(cfg, params, torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV), precision="fp32",
+                             p_hidden=ph, p_attn=pa, p_out=po, seed=seed)
+    (out * R.to(DEV)).sum().backward()
+    hip.check_status(DEV)
+    wt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    ref = O.encode_cls_train(ids_np, mask_np, wt, cfg, p_hidden=ph, p_attn=pa, p_out=po, keep=_replay_keep(seed, ph, pa, po, cfg, mask_np))
+    (ref * R).sum().backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 2e-4
+    g = _grads(params)
+    for k, v in wt.items():
+        assert _rel(g[k], v.grad.numpy()) < 2e-3, (k, _rel(g[k], v.grad.numpy()))
