@@ -399,6 +399,24 @@ int manner_hip_train_loss(const float* scores, const float* labels, const int64_
                           float temperature, int64_t c_max, float* losses, float* loss_and_scale, float* grad_scores,
                           manner_hip_stream_t stream);
 
+/* ---- the PLM baseline encoders (f32 activations; not on the throughput path) ------------------------------
+ * manner_hip_encode_full replaces `self.plm_model(**tokenized_text)[0]` of PLMTextEncoder.forward
+ * (manner/models/components/news_encoder.py:158-160): HF last_hidden_state f32 [n_news, padded_len, H] INCLUDING the padded
+ * positions — they embed the pad token (RoBERTa: at position pad_id), attend over the real keys only, and the consumer
+ * below mixes them into real tokens.  weights / precision / status as manner_hip_train_forward.
+ * manner_hip_mha_axis0 replaces nn.MultiheadAttention(embed_dim=E, num_heads=heads) as the reference calls it —
+ * batch_first=False on a [batch, seq, E] tensor, no masks (news_encoder.py:163-165; user_encoder.py:35-37): attention along
+ * AXIS 0 of x [L0, B1, E] (across the news / users of the call, independently per position B1), in/out projections included.
+ * in_proj_w [3E, E], in_proj_b [3E], out_proj_w [E, E], out_proj_b [E]; out [L0, B1, E]; eval mode (no dropout). */
+size_t manner_hip_encode_full_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t padded_len);
+int manner_hip_encode_full(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
+                           const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t precision,
+                           float* hidden, void* workspace, size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream);
+size_t manner_hip_mha_axis0_workspace_bytes(int64_t L0, int64_t B1, int32_t E);
+int manner_hip_mha_axis0(const float* x, int64_t L0, int64_t B1, int32_t E, int32_t heads, const float* in_proj_w,
+                         const float* in_proj_b, const float* out_proj_w, const float* out_proj_b, float* out, void* workspace,
+                         size_t workspace_bytes, manner_hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

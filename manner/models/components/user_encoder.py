@@ -1,2 +1,2 @@
-"""reference manner/models/components/user_encoder.py:9-21 -> the HIP mirror class."""
-from manner_amd.models.components.user_encoder import NAMLUserEncoder  # noqa: F401
+"""reference manner/models/components/user_encoder.py:9-42 -> the HIP mirror classes."""
+from manner_amd.models.components.user_encoder import NAMLUserEncoder, NRMSUserEncoder  # noqa: F401

@@ -72,6 +72,10 @@ SIGNATURES = {
     "manner_hip_late_fusion_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "manner_hip_dot_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P, _P]),
     "manner_hip_train_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P, _P, _P]),
+    "manner_hip_encode_full_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64]),
+    "manner_hip_encode_full": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P, _P]),
+    "manner_hip_mha_axis0_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
+    "manner_hip_mha_axis0": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "manner_hip_collate_segments": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "manner_hip_collate_text": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_collate_entities": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),

@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 }
 
 // attention over the NEWS axis for one (entity slot, head): qkv [N, E, 3D] = [q | k | v], out [N, E, D].
-// One thread per query news, keys streamed through LDS tiles, online softmax (dh = D / heads <= 16).
-template <int DH>
+// One thread per query news, keys streamed through LDS tiles of KT keys, online softmax.
+template <int DH, int KT>
 __global__ __launch_bounds__(256) void entity_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           int64_t N, int E, int D, int heads) {
-  __shared__ float ks[256 * DH], vs[256 * DH];
+  __shared__ float ks[KT * DH], vs[KT * DH];
   const int eh = blockIdx.x, e = eh / heads, hh = eh - e * heads;
   const int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x;
   const float scale = 1.0f / sqrtf((float)DH);
@@ -63,16 +63,16 @@ __global__ __launch_bounds__(256) void entity_attn_kernel(const float* __restric
 #pragma unroll
   for (int d = 0; d < DH; ++d) { q[d] = n < N ? base[n * ld + d] * scale : 0.f; o[d] = 0.f; }   // q is scaled first, as torch does
   float mx = -INFINITY, sum = 0.f;
-  for (int64_t t0 = 0; t0 < N; t0 += 256) {
-    const int64_t kn = t0 + threadIdx.x;
+  for (int64_t t0 = 0; t0 < N; t0 += KT) {
     __syncthreads();
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-      ks[threadIdx.x * DH + d] = kn < N ? base[kn * ld + D + d] : 0.f;
-      vs[threadIdx.x * DH + d] = kn < N ? base[kn * ld + 2 * D + d] : 0.f;
+    for (int i = threadIdx.x; i < KT * DH; i += 256) {
+      const int j = i / DH, d = i - j * DH;
+      const int64_t kn = t0 + j;
+      ks[i] = kn < N ? base[kn * ld + D + d] : 0.f;
+      vs[i] = kn < N ? base[kn * ld + 2 * D + d] : 0.f;
     }
     __syncthreads();
-    const int cnt = (int)min((int64_t)256, N - t0);
+    const int cnt = (int)min((int64_t)KT, N - t0);
     for (int j = 0; j < cnt; ++j) {
       float s = 0.f;
 #pragma unroll
@@ -96,6 +96,24 @@ __global__ __launch_bounds__(256) void entity_attn_kernel(const float* __restric
 #pragma unroll
     for (int d = 0; d < DH; ++d) dst[d] = o[d] * inv;
   }
+}
+
+// nn.MultiheadAttention(batch_first=False) core on [N, E, 3D] projections: attention along axis 0
+int launch_axis0_attention(const float* qkv, float* att, int64_t N, int64_t E, int D, int heads, hipStream_t s) {
+  const int dh = D / heads;
+  dim3 g((unsigned)(E * heads), (unsigned)((N + 255) / 256)), b(256);
+  switch (dh) {
+    case 4: hipLaunchKernelGGL((entity_attn_kernel<4, 256>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 8: hipLaunchKernelGGL((entity_attn_kernel<8, 256>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 10: hipLaunchKernelGGL((entity_attn_kernel<10, 256>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 16: hipLaunchKernelGGL((entity_attn_kernel<16, 256>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 32: hipLaunchKernelGGL((entity_attn_kernel<32, 64>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 48: hipLaunchKernelGGL((entity_attn_kernel<48, 64>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    case 64: hipLaunchKernelGGL((entity_attn_kernel<64, 64>), g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
+    default: return fail(MANNER_HIP_E_INVALID, "axis-0 attention: head_dim %d unsupported (4, 8, 10, 16, 32, 48, 64)", dh);
+  }
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
 }
 
 int launch_linear(const float* x, const int64_t* gather, int64_t n_src, const float* W, const float* b, int64_t R, int K,
@@ -146,18 +164,46 @@ int manner_hip_entity_encode(const int64_t* entity_ids, int64_t N, int64_t E, co
   int rc;
   // embedding lookup fused into the in-projection (rows gathered from the table)
   if ((rc = launch_linear(table, entity_ids, n_entities, in_proj_w, in_proj_b, R, D, 3 * D, qkv, s, status))) return rc;
-  const int dh = D / heads;
-  dim3 g((unsigned)(E * heads), (unsigned)((N + 255) / 256)), b(256);
-  switch (dh) {
-    case 10: hipLaunchKernelGGL(entity_attn_kernel<10>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
-    case 8: hipLaunchKernelGGL(entity_attn_kernel<8>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
-    case 16: hipLaunchKernelGGL(entity_attn_kernel<16>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
-    case 4: hipLaunchKernelGGL(entity_attn_kernel<4>, g, b, 0, s, qkv, att, N, (int)E, D, heads); break;
-    default: return fail(MANNER_HIP_E_INVALID, "entity_encode: head_dim %d unsupported (4, 8, 10, 16)", dh);
-  }
-  MANNER_LAUNCH_CHECK();
+  if ((rc = launch_axis0_attention(qkv, att, N, E, D, heads, s))) return rc;
   if ((rc = launch_linear(att, nullptr, 0, out_proj_w, out_proj_b, R, D, D, proj, s))) return rc;
   return manner_hip_additive_pool(proj, pool_w, pool_b, pool_q, N, E, D, Q, out, scratch, stream);
+}
+
+size_t manner_hip_mha_axis0_workspace_bytes(int64_t L0, int64_t B1, int32_t E) {
+  if (L0 <= 0 || B1 <= 0 || E <= 0) return 0;
+  return (size_t)round_up(L0 * B1, 128) * (size_t)(5 * E) * sizeof(float) + 1024;
+}
+
+int manner_hip_mha_axis0(const float* x, int64_t L0, int64_t B1, int32_t E, int32_t heads, const float* in_proj_w,
+                         const float* in_proj_b, const float* out_proj_w, const float* out_proj_b, float* out, void* workspace,
+                         size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (L0 == 0 || B1 == 0) return MANNER_HIP_OK;
+  if (!x || !in_proj_w || !in_proj_b || !out_proj_w || !out_proj_b || !out || !workspace)
+    return fail(MANNER_HIP_E_INVALID, "mha_axis0: null pointer");
+  if (L0 < 0 || B1 < 0 || E <= 0 || heads <= 0 || E % heads)
+    return fail(MANNER_HIP_E_INVALID, "mha_axis0: L0=%lld B1=%lld E=%d heads=%d", (long long)L0, (long long)B1, E, heads);
+  if (workspace_bytes < manner_hip_mha_axis0_workspace_bytes(L0, B1, E)) return fail(MANNER_HIP_E_WORKSPACE, "mha_axis0: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t R = L0 * B1, Rp = round_up(R, 128);
+  float* qkv = static_cast<float*>(workspace);          // [Rp, 3E]
+  float* att = qkv + (size_t)Rp * 3 * E;                // [Rp, E]
+  int rc;
+  if (E % 128 == 0 && Rp <= 0x7fffffff / (3 * (int64_t)E)) {
+    // PLM-sized embeddings: both projections on the f32 MFMA GEMM (its tiles read whole 128-row panels: padded copy of x)
+    float* xpad = att + (size_t)Rp * E;                 // [Rp, E]
+    int32_t* mtot = reinterpret_cast<int32_t*>(xpad + (size_t)Rp * E);
+    MANNER_HIP_TRY(hipMemcpyAsync(xpad, x, (size_t)R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (Rp > R) MANNER_HIP_TRY(hipMemsetAsync(xpad + (size_t)R * E, 0, (size_t)(Rp - R) * E * sizeof(float), s));
+    if ((rc = set_device_int(mtot, (int32_t)R, s))) return rc;
+    if ((rc = gemm_tn(DT_F32, DT_F32, EPI_BIAS, xpad, in_proj_w, in_proj_b, nullptr, qkv, Rp, 3 * E, E, mtot, s))) return rc;
+    if ((rc = launch_axis0_attention(qkv, att, L0, B1, E, heads, s))) return rc;
+    if (Rp > R) MANNER_HIP_TRY(hipMemsetAsync(att + (size_t)R * E, 0, (size_t)(Rp - R) * E * sizeof(float), s));
+    // the output GEMM stores rows < R only; `out` holds exactly R rows
+    return gemm_tn(DT_F32, DT_F32, EPI_BIAS, att, out_proj_w, out_proj_b, nullptr, out, Rp, E, E, mtot, s);
+  }
+  if ((rc = launch_linear(x, nullptr, 0, in_proj_w, in_proj_b, R, E, 3 * E, qkv, s))) return rc;
+  if ((rc = launch_axis0_attention(qkv, att, L0, B1, E, heads, s))) return rc;
+  return launch_linear(att, nullptr, 0, out_proj_w, out_proj_b, R, E, E, out, s);
 }
 
 }  // extern "C"

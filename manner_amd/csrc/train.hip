@@ -61,11 +61,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ embeddings
 // e[cu[n]+t] = word[id] + pos[t + pos_offset] + type[0]            (modeling_bert.py:68-108 without LN / dropout)
+// klen != NULL ("full rows": cu[n] = n * lp, every position is a row, klen[n] = real tokens): padded positions embed
+// their pad token at position t (BERT) or at position pad_id (RoBERTa: cumsum(mask) * mask + pad_id, pad_pos >= 0).
 __global__ __launch_bounds__(256) void embed_sum_kernel(const int64_t* __restrict__ ids, int64_t n_news, int lp,
                                                         const int32_t* __restrict__ cu, const float* __restrict__ word,
                                                         const float* __restrict__ pos, const float* __restrict__ type0, int H,
                                                         int pos_offset, int vocab, int max_pos, float* __restrict__ e,
-                                                        int32_t* __restrict__ status) {
+                                                        int32_t* __restrict__ status, const int32_t* __restrict__ klen, int pad_pos) {
   const int64_t idx = blockIdx.x;
   const int64_t n = idx / lp;
   const int t = (int)(idx - n * lp);
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const int64_t* __restric
   if (t >= len) return;
   int64_t id = ids[n * lp + t];
   int p = t + pos_offset;
+  if (klen && pad_pos >= 0 && t >= klen[n]) p = pad_pos;
   if (id < 0 || id >= vocab) { if (threadIdx.x == 0 && status) atomicOr(status, MANNER_HIP_STATUS_TOKEN); id = 0; }
   if (p >= max_pos) { if (threadIdx.x == 0 && status) atomicOr(status, MANNER_HIP_STATUS_TOKEN); p = max_pos - 1; }
   float* dst = e + (size_t)(cu[n] + t) * H;
@@ -341,10 +344,12 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__
   }
 }
 
+// klen != NULL: the rows of news n are queries, only its first klen[n] rows are keys (HF's additive key mask on the
+// padded positions, which still produce outputs of their own: manner_hip_encode_full).
 template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
-                                                            int H, Drop drop) {
+                                                            int H, Drop drop, const int32_t* __restrict__ klen) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
   __shared__ float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
   const bool active = i < S;
+  const int SK = klen ? min(klen[n], S) : S;
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
   float q[AD], o[AD];
@@ -360,13 +366,13 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   float mx = -INFINITY, l = 0.f;
   const float* kh = ks + hs * HS;
   const float* vh = vs + hs * HS;
-  for (int j0 = 0; j0 < S; j0 += KC) {
+  for (int j0 = 0; j0 < SK; j0 += KC) {
     __syncthreads();
-    stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
-    stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, S, 1.f);
+    stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, SK, 1.f);
+    stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, SK, 1.f);
     __syncthreads();
     if (!active) continue;
-    const int cnt = min(KC, S - j0);
+    const int cnt = min(KC, SK - j0);
     for (int j = 0; j < cnt; ++j) {
       float s = 0.f;
 #pragma unroll
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   float* dst = ctx + (size_t)(base + i) * H + h * AD;
 #pragma unroll
   for (int d = 0; d < AD; ++d) dst[d] = o[d] * inv;
-  ml[(size_t)(base + i) * heads + h] = float2{mx, l};
+  if (ml) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
 }
 
 // query-row owner: D_i = sum_j dP_ij P_ij, then dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
@@ -900,6 +906,42 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
   return MANNER_HIP_OK;
 }
 
+
+// One BertLayer in train() arithmetic (modeling_bert.py:175-203, 289-293, 334-351); L receives what the backward needs.
+int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out, const int32_t* cu, const int32_t* klen, float p_hidden,
+                  float p_attn, uint64_t seed) {
+  int rc;
+  const manner_hip_encoder_config* cfg = t.c;
+  const int H = cfg->hidden, I = cfg->intermediate;
+  hipStream_t s = t.s;
+  if ((rc = pack_qkv_weights(t, l))) return rc;
+  if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
+  {
+    const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+#define MANNER_ATTN_FWD(AT_, HPB_)                                                                                             \
+  hipLaunchKernelGGL((attn_train_fwd_kernel<AT_, HPB_>), dim3((unsigned)(cfg->heads / HPB_), (unsigned)t.N), dim3(AT_), 0, s, L.qkv, \
+                     L.ctx, L.ml, cu, cfg->heads, H, da, klen)
+    MANNER_ATTN_DISPATCH(t.Lp, cfg->heads, MANNER_ATTN_FWD);
+#undef MANNER_ATTN_FWD
+    MANNER_LAUNCH_CHECK();
+  }
+  if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
+  if ((rc = dropout_add(t, t.wk.tmp, x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
+  if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f)))) return rc;
+  if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H))) return rc;
+  hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0);
+  MANNER_LAUNCH_CHECK();
+  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I))) return rc;
+  if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
+  return ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
+}
+
+// cu[n] = n * lp (every position is a row), m_total = {n * lp, n}
+__global__ void full_offsets_kernel(int32_t* __restrict__ cu, int32_t* __restrict__ m_total, int64_t n_news, int lp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n_news; i += (int64_t)gridDim.x * 256) cu[i] = (int32_t)(i * lp);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { m_total[0] = (int32_t)(n_news * lp); m_total[1] = (int32_t)n_news; }
+}
+
 }  // namespace
 }  // namespace manner
 
@@ -934,6 +976,89 @@ int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, ui
   return MANNER_HIP_OK;
 }
 
+// HF last_hidden_state INCLUDING the padded positions ([n_news, padded_len, H] f32), for the consumers that mix them
+// into real tokens (PLMTextEncoder, news_encoder.py:132-171: un-masked batch_first=False attention + un-masked pooler).
+struct FullPlan {
+  Work wk;
+  int32_t *lens, *cu_real, *cu_full, *m_total, *m_real;
+  float *esum, *xa, *xb;
+  float2* st0;
+  LayerSaved L;
+};
+void plan_full(Bump& b, FullPlan& f, const manner_hip_encoder_config& c, int64_t N, int64_t Mb) {
+  const size_t H = c.hidden, I = c.intermediate;
+  plan_work(b, f.wk, c, Mb);
+  f.lens = b.take<int32_t>(N);
+  f.cu_real = b.take<int32_t>(N + 1);
+  f.cu_full = b.take<int32_t>(N + 1);
+  f.m_total = b.take<int32_t>(4);
+  f.m_real = b.take<int32_t>(4);
+  f.esum = b.take<float>(Mb * H);
+  f.st0 = b.take<float2>(Mb);
+  f.xa = b.take<float>(Mb * H);
+  f.xb = b.take<float>(Mb * H);
+  f.L.x_in = nullptr;
+  f.L.qkv = b.take<float>(Mb * 3 * H);
+  f.L.ctx = b.take<float>(Mb * H);
+  f.L.r1 = b.take<float>(Mb * H);
+  f.L.h1 = b.take<float>(Mb * H);
+  f.L.inter = b.take<float>(Mb * I);
+  f.L.g = b.take<float>(Mb * I);
+  f.L.r2 = b.take<float>(Mb * H);
+  f.L.st1 = b.take<float2>(Mb);
+  f.L.st2 = b.take<float2>(Mb);
+  f.L.ml = nullptr;
+}
+
+size_t manner_hip_encode_full_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t padded_len) {
+  if (!cfg || n_news <= 0 || padded_len <= 0) return 0;
+  Bump b(nullptr);
+  FullPlan f;
+  plan_full(b, f, *cfg, n_news, round_up(n_news * padded_len, 256));
+  return b.off + 256;
+}
+
+int manner_hip_encode_full(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, const int64_t* ids,
+                           const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t precision, float* hidden,
+                           void* workspace, size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+  int rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t Mb = round_up(n_news * padded_len, 256);
+  if ((rc = check_cfg(cfg, n_news, padded_len, Mb, precision, 0))) return rc;
+  if (!weights || n_weights != MANNER_HIP_W_EMB_COUNT + cfg->layers * MANNER_HIP_WL_COUNT) return fail(MANNER_HIP_E_INVALID, "encode_full: weight table size");
+  for (int i = 0; i < n_weights; ++i)
+    if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "encode_full: weight %d is NULL", i);
+  if (!ids || !mask || !hidden || !workspace) return fail(MANNER_HIP_E_INVALID, "encode_full: null pointer");
+  Bump b(workspace);
+  FullPlan f;
+  plan_full(b, f, *cfg, n_news, Mb);
+  if (b.off > workspace_bytes) return fail(MANNER_HIP_E_WORKSPACE, "encode_full: workspace %zu < %zu bytes", workspace_bytes, b.off);
+  Ctx t;
+  t.c = cfg; t.w = weights; t.N = n_news; t.Lp = padded_len; t.Mb = Mb; t.prec = precision; t.s = s;
+  t.wk = f.wk;
+  t.sv.lens = f.lens; t.sv.cu = f.cu_full; t.sv.m_total = f.m_total;
+  const int H = cfg->hidden;
+  const size_t wide = (size_t)(cfg->intermediate > 3 * H ? cfg->intermediate : 3 * H);
+  MANNER_HIP_TRY(hipMemsetAsync(t.wk.zero, 0, wide * sizeof(float), s));
+  // real lengths (validated like every other entry point) = key counts; rows = every position
+  if ((rc = lengths_and_offsets(mask, n_news, padded_len, f.lens, f.cu_real, f.m_real, Mb, -1, status, s))) return rc;
+  hipLaunchKernelGGL(full_offsets_kernel, dim3((unsigned)((n_news + 256) / 256)), dim3(256), 0, s, f.cu_full, f.m_total, n_news, (int)padded_len);
+  MANNER_LAUNCH_CHECK();
+  const bool roberta = cfg->arch == MANNER_HIP_ARCH_ROBERTA;
+  hipLaunchKernelGGL(embed_sum_kernel, dim3((unsigned)(n_news * padded_len)), dim3(256), 0, s, ids, n_news, (int)padded_len, f.cu_full,
+                     t.emb(MANNER_HIP_W_WORD_EMB), t.emb(MANNER_HIP_W_POS_EMB), t.emb(MANNER_HIP_W_TYPE_EMB), H, roberta ? cfg->pad_id + 1 : 0,
+                     cfg->vocab, cfg->max_pos, f.esum, status, f.lens, roberta ? cfg->pad_id : -1);
+  MANNER_LAUNCH_CHECK();
+  if ((rc = ln_forward(t, f.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), f.xa, f.st0, make_drop(0, 0, 0.f)))) return rc;
+  float *x_in = f.xa, *x_out = f.xb;
+  for (int l = 0; l < cfg->layers; ++l) {
+    float* dst = l + 1 == cfg->layers ? hidden : x_out;          // LayerNorm writes rows < n_news * padded_len: exactly `hidden`
+    if ((rc = layer_forward(t, l, f.L, x_in, dst, f.cu_full, f.lens, 0.f, 0.f, 0))) return rc;
+    float* sw = x_in; x_in = x_out; x_out = sw;
+  }
+  return MANNER_HIP_OK;
+}
+
 int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
                              const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
                              int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
@@ -950,7 +1075,7 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
     return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
   for (float p : {p_hidden, p_attn, p_out})
     if (!(p >= 0.f && p < 1.f)) return fail(MANNER_HIP_E_INVALID, "train_forward: dropout probability %f outside [0, 1)", p);
-  const int H = cfg->hidden, I = cfg->intermediate, N = (int)n_news;
+  const int H = cfg->hidden, N = (int)n_news;
   (void)N;
   Saved& sv = t.sv;
   if ((rc = lengths_and_offsets(mask, n_news, padded_len, sv.lens, sv.cu, sv.m_total, m_bound, -1, status, s))) return rc;
@@ -960,7 +1085,7 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
     const int pos_offset = cfg->arch == MANNER_HIP_ARCH_ROBERTA ? cfg->pad_id + 1 : 0;
     hipLaunchKernelGGL(embed_sum_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu,
                        t.emb(MANNER_HIP_W_WORD_EMB), t.emb(MANNER_HIP_W_POS_EMB), t.emb(MANNER_HIP_W_TYPE_EMB), H, pos_offset,
-                       cfg->vocab, cfg->max_pos, sv.esum, status);
+                       cfg->vocab, cfg->max_pos, sv.esum, status, nullptr, -1);
     MANNER_LAUNCH_CHECK();
     if ((rc = ln_forward(t, sv.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), x0, sv.st0,
                          make_drop(seed, SITE_EMB, p_hidden))))
@@ -970,28 +1095,8 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
     MANNER_LAUNCH_CHECK();
   }
   for (int l = start_layer; l < cfg->layers; ++l) {
-    LayerSaved& L = sv.l[l];
-    if ((rc = pack_qkv_weights(t, l))) return rc;
-    if ((rc = linear_fwd(t, L.x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
-    {
-      const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-#define MANNER_ATTN_FWD(AT_, HPB_)                                                                                             \
-  hipLaunchKernelGGL((attn_train_fwd_kernel<AT_, HPB_>), dim3((unsigned)(cfg->heads / HPB_), (unsigned)n_news), dim3(AT_), 0, s, L.qkv, \
-                     L.ctx, L.ml, sv.cu, cfg->heads, H, da)
-      MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_FWD);
-#undef MANNER_ATTN_FWD
-      MANNER_LAUNCH_CHECK();
-    }
-    if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
-    if ((rc = dropout_add(t, t.wk.tmp, L.x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
-    if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f)))) return rc;
-    if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H))) return rc;
-    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, sv.m_total, 0);
-    MANNER_LAUNCH_CHECK();
-    if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I))) return rc;
-    if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
     float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : t.wk.dx;      // the last layer's output is only needed for its [CLS] rows
-    if ((rc = ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_next, L.st2, make_drop(0, 0, 0.f)))) return rc;
+    if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, nullptr, p_hidden, p_attn, seed))) return rc;
   }
   hipLaunchKernelGGL(cls_kernel, dim3((unsigned)n_news), dim3(256), 0, s, t.wk.dx, sv.cu, H, cls_out, make_drop(seed, SITE_CLS, p_out));
   MANNER_LAUNCH_CHECK();

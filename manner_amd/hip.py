@@ -368,6 +368,51 @@ def entity_encode(entity_ids: Tensor, table: Tensor, in_proj_w: Tensor, in_proj_
     return out
 
 
+def mha_axis0(x: Tensor, in_proj_w: Tensor, in_proj_b: Tensor, out_proj_w: Tensor, out_proj_b: Tensor, heads: int) -> Tensor:
+    """nn.MultiheadAttention(batch_first=False) exactly as the reference calls it on a [batch, seq, E] tensor without masks
+    (PLMTextEncoder news_encoder.py:163-165, NRMSUserEncoder user_encoder.py:35-37): attention along AXIS 0 of x [L0, B1, E]."""
+    x = _dev(x, torch.float32, "x").contiguous()
+    l0, b1, e = x.shape
+    ts = [_dev(t, torch.float32, nm).contiguous() for t, nm in ((in_proj_w, "in_proj_weight"), (in_proj_b, "in_proj_bias"),
+                                                                (out_proj_w, "out_proj.weight"), (out_proj_b, "out_proj.bias"))]
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    lib = _lib.load()
+    need = int(lib.manner_hip_mha_axis0_workspace_bytes(l0, b1, e))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.manner_hip_mha_axis0(_ptr(x), l0, b1, e, heads, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), _ptr(out),
+                                            _ptr(ws), need, _stream()))
+    return out
+
+
+def encode_full(cfg: EncoderConfig, weights: Dict[str, Tensor], ids: Tensor, mask: Tensor, precision: str = "fp32") -> Tensor:
+    """HF ``last_hidden_state`` [N, Lp, H] f32 INCLUDING the padded positions (what PLMTextEncoder consumes); ``weights`` is the
+    HF-named dict of float32 GPU tensors, read in place."""
+    if precision not in ("fp32", "f16", "bf16"):
+        raise ValueError("encode_full precision: fp32, f16 or bf16")
+    ids, mask = _dev(ids, torch.int64, "input_ids").contiguous(), _dev(mask, torch.int64, "attention_mask").contiguous()
+    if ids.dim() != 2 or ids.shape != mask.shape:
+        raise ValueError(f"input_ids {tuple(ids.shape)} / attention_mask {tuple(mask.shape)} must be equal 2-D")
+    canon = canonical_weights(cfg, weights)
+    table = [_dev(canon[n].detach(), torch.float32, n).contiguous() for n in weight_table_order(cfg)]
+    n, lp = ids.shape
+    out = torch.empty((n, lp, cfg.hidden), dtype=torch.float32, device=ids.device)
+    if n == 0:
+        return out
+    lib = _lib.load()
+    cc = _lib.EncoderConfigC(cfg.arch, cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate, cfg.vocab, cfg.max_pos, cfg.type_vocab,
+                             cfg.pad_id, cfg.ln_eps)
+    with torch.cuda.device(ids.device):
+        need = int(lib.manner_hip_encode_full_workspace_bytes(C.byref(cc), n, lp))
+        ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        tab = (C.c_void_p * len(table))(*[t.data_ptr() for t in table])
+        _lib.check(lib.manner_hip_encode_full(C.byref(cc), tab, len(table), _ptr(ids), _ptr(mask), n, lp, _lib.PRECISIONS[precision],
+                                              _ptr(out), _ptr(ws), need, _ptr(device_status(ids.device).word), _stream()))
+    return out
+
+
 def dot(user: Tensor, cand: Tensor) -> Tensor:
     """DotProduct contract: user [B,1,D], cand [B,D,C] (any strides, e.g. a permuted [B,C,D]) -> [B,C]."""
     user, cand = _dev(user, torch.float32, "clicked_news_vector"), _dev(cand, torch.float32, "candidate_news_vector")

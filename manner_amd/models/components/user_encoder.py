@@ -1,8 +1,9 @@
-"""NAMLUserEncoder — mirror of reference manner/models/components/user_encoder.py:9-21
-(imported by the reference as ``UserEncoder``, cr_module.py:16)."""
+"""NAMLUserEncoder / NRMSUserEncoder — mirror of reference manner/models/components/user_encoder.py:9-42
+(NAML: imported by the reference as ``UserEncoder``, cr_module.py:16; NRMS: the user encoder of the PLM baselines)."""
 import torch
 import torch.nn as nn
 
+from manner_amd import hip
 from manner_amd.models.components.attention import AdditiveAttention
 
 
@@ -14,3 +15,22 @@ class NAMLUserEncoder(nn.Module):
     def forward(self, clicked_news_vector: torch.Tensor) -> torch.Tensor:
         # batch_size, num_clicked_news_per_user, news_embedding_dim -> batch_size, news_embedding_dim
         return self.additive_attention(clicked_news_vector)
+
+
+class NRMSUserEncoder(nn.Module):
+    """reference user_encoder.py:24-42.  Batch-faithful: the un-masked batch_first=False MultiheadAttention sees the dense
+    [B, Hmax, D] history and so attends ACROSS THE USERS OF THE BATCH at each history slot (zero-padded slots included);
+    the additive pooler then runs over all Hmax slots.  Inference only."""
+
+    def __init__(self, news_embedding_dim: int, num_attention_heads: int, query_vector_dim: int) -> None:
+        super().__init__()
+        self.multihead_attention = nn.MultiheadAttention(news_embedding_dim, num_attention_heads)
+        self.additive_attention = AdditiveAttention(news_embedding_dim, query_vector_dim)
+
+    def forward(self, clicked_news_vector: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("manner_amd NRMSUserEncoder is inference-only; call .eval() / torch.no_grad()")
+        mha = self.multihead_attention
+        user_vector = hip.mha_axis0(clicked_news_vector, mha.in_proj_weight.detach(), mha.in_proj_bias.detach(),
+                                    mha.out_proj.weight.detach(), mha.out_proj.bias.detach(), mha.num_heads)
+        return self.additive_attention(user_vector)

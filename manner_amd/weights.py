@@ -155,3 +155,22 @@ def make_entity_weights(n_entities: int, dim: int = 100, query_dim: int = 200, h
         put("linear.weight", (hidden, hidden + dim), 0.03)
         put("linear.bias", (hidden,), 0.02)
     return out
+
+
+def make_mha_pool_weights(dim: int, query_dim: int, seed: int = 42, prefix: str = "") -> Dict[str, np.ndarray]:
+    """Seeded parameters of an nn.MultiheadAttention(dim, heads) + AdditiveAttention(dim, query_dim) pair, reference key
+    names (``multihead_attention.*`` / ``additive_attention.*``: PLMTextEncoder news_encoder.py:146-151, NRMSUserEncoder
+    user_encoder.py:30-31)."""
+    out: Dict[str, np.ndarray] = {}
+
+    def put(name, shape, scale):
+        out[prefix + name] = (scale * _stream(seed, prefix + name).standard_normal(shape, dtype=np.float32)).astype(np.float32)
+
+    s = 1.0 / np.sqrt(dim)
+    put("multihead_attention.in_proj_weight", (3 * dim, dim), s)
+    put("multihead_attention.in_proj_bias", (3 * dim,), 0.05)
+    put("multihead_attention.out_proj.weight", (dim, dim), s)
+    put("multihead_attention.out_proj.bias", (dim,), 0.05)
+    for k, v in make_additive_attention_weights(dim, query_dim, seed=seed, prefix=prefix + "additive_attention.").items():
+        out[k] = v
+    return out

@@ -207,6 +207,40 @@ def entity_encoder(entity_ids: Tensor, w: Dict[str, Tensor], heads: int) -> Tens
                               w["additive_attention.query"])
 
 
+def mha_axis0(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor, heads: int) -> Tensor:
+    """nn.MultiheadAttention(embed_dim, heads) in eval mode called as the reference does — batch_first=False on a
+    [batch, seq, E] tensor, no masks (news_encoder.py:163-165; user_encoder.py:35-37; torch/nn/functional.py
+    multi_head_attention_forward): the sequence axis is axis 0."""
+    x = _t(x)
+    l0, b1, e = x.shape
+    dh = e // heads
+    q, k, v = (x @ _t(in_w).T + _t(in_b)).split(e, dim=-1)
+
+    def split_heads(t):                                   # (L0, B1 * heads, dh) -> (B1 * heads, L0, dh)
+        return t.reshape(l0, b1 * heads, dh).transpose(0, 1)
+
+    att = torch.softmax((split_heads(q) * dh ** -0.5) @ split_heads(k).transpose(1, 2), dim=-1)
+    o = (att @ split_heads(v)).transpose(0, 1).reshape(l0, b1, e)
+    return o @ _t(out_w).T + _t(out_b)
+
+
+def plm_text_encoder(ids, mask, w: Dict[str, Tensor], cfg, mha: Dict[str, Tensor], pool: Tuple[Tensor, Tensor, Tensor], heads: int) -> Tensor:
+    """PLMTextEncoder.forward (reference news_encoder.py:158-171), eval mode: HF last_hidden_state (padded positions
+    included — encode_tokens computes them as HF does), un-masked axis-0 attention, un-masked additive pooler.
+    ``mha``: in_proj_weight / in_proj_bias / out_proj.weight / out_proj.bias."""
+    with torch.no_grad():
+        hidden = encode_tokens(ids, mask, w, cfg)
+        mixed = mha_axis0(hidden, mha["in_proj_weight"], mha["in_proj_bias"], mha["out_proj.weight"], mha["out_proj.bias"], heads)
+        return additive_attention(mixed, *pool)
+
+
+def nrms_user_encoder(clicked: Tensor, mha: Dict[str, Tensor], pool: Tuple[Tensor, Tensor, Tensor], heads: int) -> Tensor:
+    """NRMSUserEncoder.forward (reference user_encoder.py:33-42), eval mode."""
+    with torch.no_grad():
+        return additive_attention(mha_axis0(clicked, mha["in_proj_weight"], mha["in_proj_bias"], mha["out_proj.weight"],
+                                            mha["out_proj.bias"], heads), *pool)
+
+
 def news_encoder_with_entities(text_vec: Tensor, entity_vec: Tensor, lin_w: Tensor, lin_b: Tensor) -> Tensor:
     """MannerNewsEncoder.forward, use_entities=True (reference news_encoder.py:119-124):
     linear(cat([text_vector, entity_vector], dim=-1))."""

@@ -302,7 +302,50 @@ def gen_train(name, preset, n, lp, seed, std, lengths, frozen_layers, matrix_row
     print(name, out.shape, len(grads), "grad tensors,", len(frozen), "frozen")
 
 
+def gen_baselines(seed=53):
+    """the reference's PLMTextEncoder (news_encoder.py:132-171) and NRMSUserEncoder (user_encoder.py:24-42),
+    eval mode, on padded inputs — both mix padded positions / padded history slots into the result."""
+    from manner.models.components.news_encoder import PLMTextEncoder
+    from manner.models.components.user_encoder import NRMSUserEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    from transformers import BatchEncoding
+    out = {}
+    for tag, preset, heads, lengths in (("bert", "tiny-bert", 4, np.array([2, 5, 9, 14, 20, 20, 7])),
+                                        ("roberta", "tiny-roberta", 2, np.array([3, 18, 6, 11, 18]))):
+        cfg = PRESETS[preset]
+        w = make_plm_weights(cfg, seed=seed, std=0.05)
+        ids, mask = synth_news_tokens(len(lengths), cfg, seed=seed, max_len=int(lengths.max()), lengths=lengths)
+        mw = make_mha_pool_weights(cfg.hidden, 200, seed=seed)
+        with tempfile.TemporaryDirectory() as tmp:
+            enc = PLMTextEncoder(plm_model=hf_model_dir(cfg, w, tmp), frozen_layers=[], text_embedding_dim=cfg.hidden,
+                                 num_attention_heads=heads, query_vector_dim=200, dropout_probability=0.2).eval()
+            missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=False)
+            assert not unexpected and all(m.startswith("plm_model.") for m in missing), (missing, unexpected)
+            res = enc(BatchEncoding({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)})).numpy()
+        out.update({f"plm_{tag}_ids": ids, f"plm_{tag}_mask": mask, f"plm_{tag}_out": res})
+        print("PLMTextEncoder", preset, res.shape, float(np.abs(res).mean()))
+    rng = np.random.default_rng(seed)
+    for tag, dim, heads in (("d96", 96, 2), ("d128", 128, 2)):
+        mw = make_mha_pool_weights(dim, 200, seed=seed + 1)
+        ue = NRMSUserEncoder(news_embedding_dim=dim, num_attention_heads=heads, query_vector_dim=200).eval()
+        ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
+        clicked = rng.standard_normal((6, 9, dim)).astype(np.float32)
+        clicked[1, 4:] = 0.0                             # zero-padded history slots, as to_dense_batch leaves them
+        clicked[3, 1:] = 0.0
+        res = ue(torch.from_numpy(clicked)).numpy()
+        out.update({f"nrms_{tag}_x": clicked, f"nrms_{tag}_out": res})
+        print("NRMSUserEncoder", dim, res.shape)
+    np.savez_compressed(os.path.join(HERE, "baselines.npz"), **out,
+                        meta=json.dumps({"source": "reference PLMTextEncoder (news_encoder.py:132-171) / NRMSUserEncoder "
+                                                   "(user_encoder.py:24-42), eval(), transformers " + __import__("transformers").__version__,
+                                         "seed": seed, "std": 0.05, "plm": {"bert": ["tiny-bert", 4], "roberta": ["tiny-roberta", 2]},
+                                         "nrms": {"d96": [96, 2], "d128": [128, 2]}, "query_dim": 200}))
+
+
 if __name__ == "__main__":
+    if "--baselines-only" in sys.argv:
+        gen_baselines()
+        sys.exit(0)
     if "--train-only" in sys.argv:
         gen_train("train_tiny_bert", "tiny-bert", n=6, lp=24, seed=51, std=0.05, lengths=np.array([3, 7, 12, 16, 23, 24]),
                   frozen_layers=[0])

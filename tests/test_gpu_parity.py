@@ -879,3 +879,53 @@ def test_deferred_layernorm_chunk_invariance_fuzz(prec, tol):
             assert np.abs(base[:24].cpu().numpy() - ref).max() < tol
     assert torch.isfinite(base).all()
     enc.status()
+
+
+def test_baseline_encoders_match_reference(golden_dir):
+    """the PLMTextEncoder / NRMSUserEncoder mirrors (hip.encode_full incl. padded positions, hip.mha_axis0,
+    additive pooler) against the reference's own outputs; a larger-than-golden case against the oracle."""
+    import warnings
+    from manner_amd.models.components.news_encoder import PLMTextEncoder
+    from manner_amd.models.components.user_encoder import NRMSUserEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    z, meta = _load(golden_dir, "baselines")
+    for tag, (preset, heads) in meta["plm"].items():
+        cfg = PRESETS[preset]
+        w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+        mw = make_mha_pool_weights(cfg.hidden, meta["query_dim"], seed=meta["seed"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            enc = PLMTextEncoder(plm_model=preset, frozen_layers=[], text_embedding_dim=cfg.hidden, num_attention_heads=heads,
+                                 query_vector_dim=meta["query_dim"], dropout_probability=0.2)
+        sd = {"plm_model." + k: torch.from_numpy(v) for k, v in w.items()}
+        sd.update({k: torch.from_numpy(v) for k, v in mw.items()})
+        enc.load_state_dict(sd, strict=True)
+        enc = enc.to(DEV).eval()
+        ids, mask = _cuda(z[f"plm_{tag}_ids"]), _cuda(z[f"plm_{tag}_mask"])
+        out = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
+        assert np.abs(out - z[f"plm_{tag}_out"]).max() < FP32_TOL, (tag, np.abs(out - z[f"plm_{tag}_out"]).max())
+        # the padded positions themselves, against the oracle's HF restatement
+        hidden = hip.encode_full(cfg, {k: _cuda(v) for k, v in w.items()}, ids, mask).cpu().numpy()
+        ref_h = O.encode_tokens(z[f"plm_{tag}_ids"], z[f"plm_{tag}_mask"], w, cfg).numpy()
+        assert np.abs(hidden - ref_h).max() < FP32_TOL
+        enc.precision = "f16"
+        out16 = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
+        assert np.abs(out16 - z[f"plm_{tag}_out"]).max() < 2e-2
+    for tag, (dim, heads) in meta["nrms"].items():
+        mw = make_mha_pool_weights(dim, meta["query_dim"], seed=meta["seed"] + 1)
+        ue = NRMSUserEncoder(news_embedding_dim=dim, num_attention_heads=heads, query_vector_dim=meta["query_dim"])
+        ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
+        ue = ue.to(DEV).eval()
+        out = ue(_cuda(z[f"nrms_{tag}_x"])).cpu().numpy()
+        assert np.abs(out - z[f"nrms_{tag}_out"]).max() < 1e-4, tag
+    hip.check_status(DEV)
+    # NRMS at the reference's configured size (768 dims, 16 heads => head_dim 48), 300 users x 50 history slots, vs the oracle
+    mw = make_mha_pool_weights(768, 200, seed=9)
+    mha = {k[len("multihead_attention."):]: v for k, v in mw.items() if k.startswith("multihead_attention.")}
+    pool = tuple(mw["additive_attention." + k] for k in ("linear.weight", "linear.bias", "query"))
+    x = (np.random.default_rng(9).standard_normal((300, 50, 768)) * 0.5).astype(np.float32)
+    x[::3, 20:] = 0.0
+    ue = NRMSUserEncoder(news_embedding_dim=768, num_attention_heads=16, query_vector_dim=200)
+    ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
+    out = ue.to(DEV).eval()(_cuda(x)).cpu().numpy()
+    assert np.abs(out - O.nrms_user_encoder(x, mha, pool, 16).numpy()).max() < 2e-4

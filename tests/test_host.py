@@ -144,6 +144,14 @@ def test_reference_import_paths_resolve_to_the_mirror():
         assert DotProduct.__module__ == "manner_amd.models.components.click_predictors"
         assert UserEncoder.__module__ == "manner_amd.models.components.user_encoder"
         assert AdditiveAttention.__module__ == "manner_amd.models.components.attention"
+        # the PLM baselines' imports (baselines/nrms_plm_module.py:15-16)
+        from manner.models.components.news_encoder import PLMTextEncoder as NewsEncoder
+        from manner.models.components.user_encoder import NRMSUserEncoder
+        assert NewsEncoder is M.PLMTextEncoder and NRMSUserEncoder.__module__ == "manner_amd.models.components.user_encoder"
+        nrms = NRMSUserEncoder(news_embedding_dim=768, num_attention_heads=16, query_vector_dim=200)
+        assert sorted(nrms.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query",
+                                             "multihead_attention.in_proj_bias", "multihead_attention.in_proj_weight",
+                                             "multihead_attention.out_proj.bias", "multihead_attention.out_proj.weight"]
         ue = UserEncoder(news_embedding_dim=768, query_vector_dim=200)          # the reference's call, cr_module.py:65-68
         assert sorted(ue.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"]
     finally:

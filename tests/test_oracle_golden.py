@@ -342,3 +342,27 @@ def test_train_mode_dropout_masks_are_replayable():
     assert (dropped - base).abs().max() > 1e-3
     ones = O.encode_cls_train(ids, mask, w, cfg, p_out=0.5, keep=lambda s, k: torch.ones(3, cfg.hidden))
     assert torch.allclose(ones, base * 2.0, atol=1e-5)
+
+
+def _baseline_weights(seed, dim, query_dim=200):
+    from manner_amd.weights import make_mha_pool_weights
+    mw = make_mha_pool_weights(dim, query_dim, seed=seed)
+    mha = {k[len("multihead_attention."):]: v for k, v in mw.items() if k.startswith("multihead_attention.")}
+    pool = tuple(mw["additive_attention." + k] for k in ("linear.weight", "linear.bias", "query"))
+    return mw, mha, pool
+
+
+def test_baseline_encoders_match_reference(golden_dir):
+    """PLMTextEncoder (hidden states AT PADDED POSITIONS flow through the un-masked axis-0 attention and the
+    un-masked pooler) and NRMSUserEncoder (attention across the users of the batch) against the reference's own outputs."""
+    z, meta = _load(golden_dir, "baselines")
+    for tag, (preset, heads) in meta["plm"].items():
+        cfg = PRESETS[preset]
+        w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+        _, mha, pool = _baseline_weights(meta["seed"], cfg.hidden)
+        out = O.plm_text_encoder(z[f"plm_{tag}_ids"], z[f"plm_{tag}_mask"], w, cfg, mha, pool, heads).numpy()
+        assert np.abs(out - z[f"plm_{tag}_out"]).max() < 2e-5, tag
+    for tag, (dim, heads) in meta["nrms"].items():
+        _, mha, pool = _baseline_weights(meta["seed"] + 1, dim)
+        out = O.nrms_user_encoder(z[f"nrms_{tag}_x"], mha, pool, heads).numpy()
+        assert np.abs(out - z[f"nrms_{tag}_out"]).max() < 1e-5, tag
