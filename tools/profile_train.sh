@@ -10,4 +10,4 @@ d=json.loads(open('gpurun_out/r2/train_bench.json').read().strip().splitlines()[
 print(json.dumps(d.get('train_mode'), indent=1))
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2/train_prof -o train -- python $GRAFT_REPO_ROOT/bench.py $F > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/r2/train_prof/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2/train_prof -o train -- python $GRAFT_REPO_ROOT/bench.py $F > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/r2/train_prof/err.log
