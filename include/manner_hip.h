@@ -399,6 +399,35 @@ int manner_hip_train_loss(const float* scores, const float* labels, const int64_
                           float temperature, int64_t c_max, float* losses, float* loss_and_scale, float* grad_scores,
                           manner_hip_stream_t stream);
 
+/* The small operators of the training step (train_small.hip; f32): what autograd needs below and beside the text encoder
+ * for the reference's default `use_entities: True` (configs/model/cr_module.yaml:13) and for early fusion —
+ *  - manner_hip_linear_backward: nn.Linear (news_encoder.py:110-113 `linear` on cat[text, entity]; the projections of
+ *    nn.MultiheadAttention; AdditiveAttention.linear): y = x W^T + b, x [R, K], W [O, K] (O <= 2000); any of grad_x / grad_w /
+ *    grad_b may be NULL; add_to_dx (nullable) [R, K] is added into grad_x;
+ *  - manner_hip_additive_pool_backward: AdditiveAttention.forward (attention.py:21-27) — grad_x [B, S, D], grad_w [Q, D],
+ *    grad_b [Q], grad_q [Q] from grad_out [B, D]; workspace manner_hip_additive_pool_backward_workspace_bytes;
+ *  - manner_hip_axis0_attention(_backward): the attention core of nn.MultiheadAttention(batch_first=False) as the reference
+ *    calls it (quirk Q1: along axis 0 of [L0, B1, E], per position B1 and head, no mask, no attention dropout) on projected
+ *    qkv [L0, B1, 3E] = [q | k | v]; backward: grad_qkv [L0, B1, 3E] from grad_out [L0, B1, E], stats = L0*B1*heads*3 floats of scratch;
+ *  - manner_hip_embedding(_backward): nn.Embedding.from_pretrained(..., freeze=False, padding_idx=0) (news_encoder.py:99-103):
+ *    lookup, and grad_table [n_rows, D] (overwritten; row padding_idx receives no gradient; f32 atomics);
+ *  - manner_hip_dropout: out = keep ? x / (1 - p) : 0 over a flat tensor with the training path's generator (its own
+ *    backward: apply it to the gradient with the same seed / site). */
+int manner_hip_linear_backward(const float* x, const float* weight, const float* grad_y, int64_t R, int32_t K, int32_t O,
+                               const float* add_to_dx, float* grad_x, float* grad_w, float* grad_b, manner_hip_stream_t stream);
+size_t manner_hip_additive_pool_backward_workspace_bytes(int64_t B, int64_t S, int32_t D, int32_t Q);
+int manner_hip_additive_pool_backward(const float* x, const float* lin_w, const float* lin_b, const float* query, const float* grad_out,
+                                      int64_t B, int64_t S, int32_t D, int32_t Q, float* grad_x, float* grad_w, float* grad_b,
+                                      float* grad_q, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
+int manner_hip_axis0_attention(const float* qkv, int64_t L0, int64_t B1, int32_t E, int32_t heads, float* out, manner_hip_stream_t stream);
+int manner_hip_axis0_attention_backward(const float* qkv, const float* grad_out, int64_t L0, int64_t B1, int32_t E, int32_t heads,
+                                        float* grad_qkv, float* stats, manner_hip_stream_t stream);
+int manner_hip_embedding(const int64_t* ids, int64_t R, const float* table, int64_t n_rows, int32_t D, float* out, int32_t* status,
+                         manner_hip_stream_t stream);
+int manner_hip_embedding_backward(const int64_t* ids, int64_t R, const float* grad_out, int64_t n_rows, int32_t D, int64_t padding_idx,
+                                  float* grad_table, manner_hip_stream_t stream);
+int manner_hip_dropout(const float* x, float* out, int64_t n, uint64_t seed, uint32_t site, float p, manner_hip_stream_t stream);
+
 /* ---- the PLM baseline encoders (f32 activations; not on the throughput path) ------------------------------
  * manner_hip_encode_full replaces `self.plm_model(**tokenized_text)[0]` of PLMTextEncoder.forward
  * (manner/models/components/news_encoder.py:158-160): HF last_hidden_state f32 [n_news, padded_len, H] INCLUDING the padded

@@ -72,6 +72,14 @@ SIGNATURES = {
     "manner_hip_late_fusion_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "manner_hip_dot_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P, _P]),
     "manner_hip_train_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P, _P, _P]),
+    "manner_hip_linear_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
+    "manner_hip_additive_pool_backward_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
+    "manner_hip_additive_pool_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    "manner_hip_axis0_attention": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
+    "manner_hip_axis0_attention_backward": (C.c_int, [_P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
+    "manner_hip_embedding": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _P]),
+    "manner_hip_embedding_backward": (C.c_int, [_P, _I64, _P, _I64, _I32, _I64, _P, _P]),
+    "manner_hip_dropout": (C.c_int, [_P, _P, _I64, C.c_uint64, C.c_uint32, C.c_float, _P]),
     "manner_hip_encode_full_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64]),
     "manner_hip_encode_full": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P, _P]),
     "manner_hip_mha_axis0_workspace_bytes": (_SZ, [_I64, _I64, _I32]),

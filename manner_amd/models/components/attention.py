@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from manner_amd import hip
+from manner_amd import hip, train
 
 
 class AdditiveAttention(nn.Module):
@@ -13,7 +13,7 @@ class AdditiveAttention(nn.Module):
 
     def forward(self, input_vector: torch.Tensor) -> torch.Tensor:
         """(batch, seq, dim) -> (batch, dim); unmasked softmax over ``seq`` as in the reference."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise RuntimeError("manner_amd AdditiveAttention is inference-only (call .eval() / torch.no_grad())")
+        if torch.is_grad_enabled() and (input_vector.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            return train.additive_pool(input_vector, self.linear.weight, self.linear.bias, self.query)      # training: with its backward
         return hip.additive_pool(input_vector, self.linear.weight.detach(), self.linear.bias.detach(),
                                  self.query.detach())

@@ -211,10 +211,19 @@ class MannerEntityEncoder(nn.Module):
         self.dropout = nn.Dropout(p=dropout_probability)
 
     def forward(self, entity_sequence: torch.Tensor) -> torch.Tensor:
-        if self.training:
-            raise RuntimeError("manner_amd MannerEntityEncoder has no training path (SURVEY §8f-3 covers the text encoder, "
-                               "i.e. the use_entities=False configs); call .eval()")
         mha, pool = self.multihead_attention, self.additive_attention
+        if self.training and torch.is_grad_enabled():
+            # train() mode (news_encoder.py:60-72): embedding -> dropout -> axis-0 attention -> dropout -> additive pooler,
+            # every operator with its hand-written backward (manner_amd.train / csrc/train_small.hip)
+            if mha.dropout != 0.0:
+                raise RuntimeError("attention-probability dropout inside nn.MultiheadAttention is not built (the reference uses 0)")
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            emb = self.pretrained_embedding
+            x = train.embedding(entity_sequence, emb.weight, emb.padding_idx)
+            x = train.dropout(x, self.dropout.p, seed, site=2)
+            x = train.mha_axis0(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, mha.num_heads)
+            x = train.dropout(x, self.dropout.p, seed, site=3)
+            return train.additive_pool(x, pool.linear.weight, pool.linear.bias, pool.query)
         return hip.entity_encode(entity_sequence, self.pretrained_embedding.weight.detach(), mha.in_proj_weight.detach(),
                                  mha.in_proj_bias.detach(), mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
                                  pool.linear.weight.detach(), pool.linear.bias.detach(), pool.query.detach(),
@@ -248,8 +257,10 @@ class MannerNewsEncoder(nn.Module):
             return text_vector
         # entity embedding, concat, linear (news_encoder.py:119-124)
         entity_vector = self.entity_encoder(news["entities"])
-        return hip.linear(torch.cat([text_vector, entity_vector], dim=-1), self.linear.weight.detach(),
-                          self.linear.bias.detach())
+        both = torch.cat([text_vector, entity_vector], dim=-1)                  # a copy; its backward is a split
+        if self.training and torch.is_grad_enabled():
+            return train.linear(both, self.linear.weight, self.linear.bias)
+        return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach())
 
 
 class PLMTextEncoder(nn.Module):

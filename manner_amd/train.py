@@ -233,3 +233,150 @@ def model_step_loss(scores: Tensor, labels: Tensor, cand_off: Tensor, supcon: bo
         raise ValueError("cross-entropy mode needs c_max (the dense row width of the reference)")
     # nn.CrossEntropyLoss has no temperature (cr_module.py:169)
     return _Loss.apply(scores, labels, cand_off, 0 if supcon else 1, float(temperature) if supcon else 1.0, int(c_max or 1))
+
+
+# ---------------------------------------------------------------------------------------------- small differentiable operators
+# (train_small.hip) — what the reference's default `use_entities: True` and early fusion need around the text encoder
+def _f32(t: Tensor, name: str) -> Tensor:
+    return hip._dev(t, torch.float32, name).contiguous()
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor]):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        shape = x.shape
+        y = hip.linear(x.reshape(-1, shape[-1]), weight, bias)
+        return y.reshape(*shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, weight = ctx.saved_tensors
+        o, k = weight.shape
+        x2, g2 = x.reshape(-1, k), _f32(g.reshape(-1, o), "grad")
+        r = x2.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(o, dtype=torch.float32, device=x.device) if need_b else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().manner_hip_linear_backward(hip._ptr(x2), hip._ptr(weight), hip._ptr(g2), r, k, o, hip._ptr(None),
+                                                              hip._ptr(dx), hip._ptr(dw), hip._ptr(db), hip._stream()))
+        return (dx.reshape(x.shape) if need_x else None), dw, db
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """nn.Linear with autograd on the HIP kernels (f32): x [..., K], weight [O, K]."""
+    return _Linear.apply(_f32(x, "x"), _f32(weight, "weight"), None if bias is None else _f32(bias, "bias"))
+
+
+class _AdditivePool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor):
+        ctx.save_for_backward(x, lin_w, lin_b, query)
+        return hip.additive_pool(x, lin_w, lin_b, query)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, lin_w, lin_b, query = ctx.saved_tensors
+        b, s, d = x.shape
+        q = lin_w.shape[0]
+        lib = _lib.load()
+        dx, dw, db, dq = torch.empty_like(x), torch.empty_like(lin_w), torch.empty_like(lin_b), torch.empty_like(query)
+        with torch.cuda.device(x.device):
+            need = int(lib.manner_hip_additive_pool_backward_workspace_bytes(b, s, d, q))
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            g = _f32(g, "grad")
+            _lib.check(lib.manner_hip_additive_pool_backward(hip._ptr(x), hip._ptr(lin_w), hip._ptr(lin_b), hip._ptr(query), hip._ptr(g), b, s, d,
+                                                             q, hip._ptr(dx), hip._ptr(dw), hip._ptr(db), hip._ptr(dq), hip._ptr(ws), need,
+                                                             hip._stream()))
+        return dx, dw, db, dq
+
+
+def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:
+    """AdditiveAttention.forward (attention.py:21-27) with autograd: x [B, S, D] -> [B, D]."""
+    return _AdditivePool.apply(_f32(x, "input_vector"), _f32(lin_w, "linear.weight"), _f32(lin_b, "linear.bias"), _f32(query, "query"))
+
+
+class _Axis0Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: Tensor, heads: int):
+        l0, b1, e3 = qkv.shape
+        out = torch.empty((l0, b1, e3 // 3), dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(_lib.load().manner_hip_axis0_attention(hip._ptr(qkv), l0, b1, e3 // 3, heads, hip._ptr(out), hip._stream()))
+        ctx.save_for_backward(qkv)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (qkv,) = ctx.saved_tensors
+        l0, b1, e3 = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        stats = torch.empty(l0 * b1 * ctx.heads * 3, dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            g = _f32(g, "grad")
+            _lib.check(_lib.load().manner_hip_axis0_attention_backward(hip._ptr(qkv), hip._ptr(g), l0, b1, e3 // 3, ctx.heads, hip._ptr(dqkv),
+                                                                       hip._ptr(stats), hip._stream()))
+        return dqkv, None
+
+
+def mha_axis0(x: Tensor, in_proj_w: Tensor, in_proj_b: Tensor, out_proj_w: Tensor, out_proj_b: Tensor, heads: int) -> Tensor:
+    """nn.MultiheadAttention(batch_first=False) as the reference calls it on [batch, seq, E] without masks (quirk Q1), with
+    autograd: in-projection, attention along axis 0, out-projection."""
+    qkv = linear(x, in_proj_w, in_proj_b)
+    return linear(_Axis0Attention.apply(qkv.contiguous(), int(heads)), out_proj_w, out_proj_b)
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids: Tensor, table: Tensor, padding_idx: int):
+        out = torch.empty(tuple(ids.shape) + (table.shape[1],), dtype=torch.float32, device=table.device)
+        with torch.cuda.device(table.device):
+            _lib.check(_lib.load().manner_hip_embedding(hip._ptr(ids), ids.numel(), hip._ptr(table), table.shape[0], table.shape[1], hip._ptr(out),
+                                                        hip._ptr(hip.device_status(table.device).word), hip._stream()))
+        ctx.save_for_backward(ids)
+        ctx.shape, ctx.padding_idx = tuple(table.shape), padding_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (ids,) = ctx.saved_tensors
+        dt = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            g = _f32(g, "grad")
+            _lib.check(_lib.load().manner_hip_embedding_backward(hip._ptr(ids), ids.numel(), hip._ptr(g), ctx.shape[0], ctx.shape[1],
+                                                                 -1 if ctx.padding_idx is None else int(ctx.padding_idx), hip._ptr(dt), hip._stream()))
+        return None, dt, None
+
+
+def embedding(ids: Tensor, table: Tensor, padding_idx: Optional[int] = None) -> Tensor:
+    """nn.Embedding lookup with autograd (row ``padding_idx`` receives no gradient)."""
+    return _Embedding.apply(hip._dev(ids, torch.int64, "ids").contiguous(), _f32(table, "embedding.weight"), padding_idx)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float, seed: int, site: int):
+        ctx.args = (p, seed, site)
+        return _Dropout._run(x, p, seed, site)
+
+    @staticmethod
+    def _run(x, p, seed, site):
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().manner_hip_dropout(hip._ptr(x), hip._ptr(out), x.numel(), C.c_uint64(seed), C.c_uint32(site), C.c_float(p), hip._stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return _Dropout._run(_f32(g, "grad"), *ctx.args), None, None, None
+
+
+def dropout(x: Tensor, p: float, seed: int, site: int = 0) -> Tensor:
+    """nn.Dropout in train() mode on the training path's counter-based generator (mask = f(seed, site, element index))."""
+    if p <= 0.0:
+        return x
+    return _Dropout.apply(_f32(x, "x"), float(p), int(seed) & (2 ** 64 - 1), int(site))

@@ -241,6 +241,22 @@ def nrms_user_encoder(clicked: Tensor, mha: Dict[str, Tensor], pool: Tuple[Tenso
                                             mha["out_proj.bias"], heads), *pool)
 
 
+def news_encoder_train(ids, mask, entity_ids, w_text: Dict[str, Tensor], w_ent: Dict[str, Tensor], cfg, heads: int, **train_kw) -> Tensor:
+    """MannerNewsEncoder.forward with use_entities=True in train() mode (reference news_encoder.py:115-129 over :60-72),
+    differentiable, entity-side dropout off (the text side takes encode_cls_train's keyword arguments): the gradient oracle
+    of the entity branch.  ``w_ent``: the reference's keys (entity_encoder.pretrained_embedding.weight,
+    entity_encoder.multihead_attention.*, entity_encoder.additive_attention.*, linear.weight, linear.bias); the embedding
+    is built with padding_idx=0 (news_encoder.py:99-103), so row 0 receives no gradient."""
+    text = encode_cls_train(ids, mask, w_text, cfg, **train_kw)
+    p = "entity_encoder."
+    ev = F.embedding(_t(entity_ids).long(), w_ent[p + "pretrained_embedding.weight"], padding_idx=0)
+    ev = mha_axis0(ev, w_ent[p + "multihead_attention.in_proj_weight"], w_ent[p + "multihead_attention.in_proj_bias"],
+                   w_ent[p + "multihead_attention.out_proj.weight"], w_ent[p + "multihead_attention.out_proj.bias"], heads)
+    ev = additive_attention(ev, w_ent[p + "additive_attention.linear.weight"], w_ent[p + "additive_attention.linear.bias"],
+                            w_ent[p + "additive_attention.query"])
+    return F.linear(torch.cat([text, ev], dim=-1), w_ent["linear.weight"], w_ent["linear.bias"])
+
+
 def news_encoder_with_entities(text_vec: Tensor, entity_vec: Tensor, lin_w: Tensor, lin_b: Tensor) -> Tensor:
     """MannerNewsEncoder.forward, use_entities=True (reference news_encoder.py:119-124):
     linear(cat([text_vector, entity_vector], dim=-1))."""

@@ -302,6 +302,47 @@ def gen_train(name, preset, n, lp, seed, std, lengths, frozen_layers, matrix_row
     print(name, out.shape, len(grads), "grad tensors,", len(frozen), "frozen")
 
 
+def gen_train_entities(seed=54):
+    """SURVEY §8f-3 with the reference's default use_entities=True: gradients of its own MannerNewsEncoder.train() (all dropout
+    probabilities 0; loss = sum(out * R)) for the entity branch (embedding table with padding_idx 0, axis-0 attention, pooler), the
+    `linear` on cat[text, entity], and — through it — a sample of the text encoder's tensors."""
+    from transformers import BatchEncoding
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=seed, std=0.05)
+    ew = make_entity_weights(60, dim=100, query_dim=200, hidden=cfg.hidden, seed=seed)
+    ids, mask = synth_news_tokens(9, cfg, seed=seed, max_len=20)
+    g = np.random.Generator(np.random.PCG64(seed + 1))
+    ent = g.integers(1, 60, size=(9, 6), dtype=np.int64)
+    for r, keep in enumerate((6, 5, 3, 1, 0, 2, 6, 4, 1)):
+        ent[r, keep:] = 0
+    R = np.random.default_rng(seed).standard_normal((9, cfg.hidden)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp, torch.enable_grad():
+        enc = MannerNewsEncoder(plm_model=hf_model_dir(cfg, w, tmp, no_dropout=True), frozen_layers=[0], dropout_probability=0.0,
+                                use_entities=True, entity_embeddings=ew["entity_encoder.pretrained_embedding.weight"],
+                                entity_embedding_dim=100, num_attention_heads=10, query_vector_dim=200,
+                                text_embedding_dim=cfg.hidden).train()
+        missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in ew.items()}, strict=False)
+        assert not unexpected and all(m.startswith("text_encoder.") for m in missing), (missing, unexpected)
+        out = enc({"text": BatchEncoding({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}),
+                   "entities": torch.from_numpy(ent)})
+        (out * torch.from_numpy(R)).sum().backward()
+        grads = {}
+        for k, p in enc.named_parameters():
+            if k.startswith("text_encoder.") and k not in ("text_encoder.plm_model.encoder.layer.1.output.dense.bias",
+                                                           "text_encoder.plm_model.encoder.layer.1.attention.self.query.bias",
+                                                           "text_encoder.plm_model.embeddings.LayerNorm.weight",
+                                                           "text_encoder.plm_model.embeddings.position_embeddings.weight"):
+                continue
+            assert p.grad is not None, k
+            grads["grad:" + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_entities.npz"), ids=ids, mask=mask, entities=ent, R=R, out=out.detach().numpy(), **grads,
+                        meta=json.dumps({"source": "reference MannerNewsEncoder(use_entities=True).train() (news_encoder.py:40-129), all dropout "
+                                                   "probabilities 0, loss = sum(out * R), transformers " + __import__("transformers").__version__,
+                                         "preset": "tiny-bert", "seed": seed, "std": 0.05, "n_entities": 60, "heads": 10, "query_dim": 200,
+                                         "frozen_layers": [0]}))
+    print("train_entities", out.shape, len(grads), "grad tensors")
+
+
 def gen_baselines(seed=53):
     """the reference's PLMTextEncoder (news_encoder.py:132-171) and NRMSUserEncoder (user_encoder.py:24-42),
     eval mode, on padded inputs — both mix padded positions / padded history slots into the result."""
@@ -343,6 +384,9 @@ def gen_baselines(seed=53):
 
 
 if __name__ == "__main__":
+    if "--train-entities-only" in sys.argv:
+        gen_train_entities()
+        sys.exit(0)
     if "--baselines-only" in sys.argv:
         gen_baselines()
         sys.exit(0)

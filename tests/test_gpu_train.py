@@ -340,3 +340,100 @@ def test_train_attention_geometries(max_len):
     g = _grads(params)
     for k, v in wt.items():
         assert _rel(g[k], v.grad.numpy()) < 2e-3, (k, _rel(g[k], v.grad.numpy()))
+
+
+# ---------------------------------------------------------------------------------------------- small operators (train_small.hip)
+def _check_grads(hip_fn, ref_fn, tensors, tol=2e-4):
+    """Run hip_fn on GPU copies and ref_fn (plain torch on CPU) on CPU copies of `tensors` (all requiring grad), backward through a fixed
+    random cotangent, compare outputs and every gradient."""
+    g_in = [t.clone().to(DEV).requires_grad_(True) for t in tensors]
+    c_in = [t.clone().requires_grad_(True) for t in tensors]
+    out, ref = hip_fn(*g_in), ref_fn(*c_in)
+    assert out.shape == ref.shape
+    cot = torch.from_numpy(np.random.default_rng(0).standard_normal(tuple(ref.shape)).astype(np.float32))
+    (out * cot.to(DEV)).sum().backward()
+    (ref * cot).sum().backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max() < tol * max(1.0, float(ref.detach().abs().max()))
+    for a, b in zip(g_in, c_in):
+        assert _rel(a.grad.cpu().numpy(), b.grad.numpy()) < tol * 5, tuple(a.shape)
+
+
+def test_linear_and_additive_pool_backward():
+    rng = np.random.default_rng(20)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))        # noqa: E731
+    _check_grads(train.linear, torch.nn.functional.linear, [f(37, 5, 100), f(300, 100) * 0.1, f(300)])
+    _check_grads(train.linear, torch.nn.functional.linear, [f(19, 868), f(768, 868) * 0.03, f(768)])       # linear on cat[text, entity]
+    for b, s, d, q in ((7, 6, 100, 200), (33, 50, 768, 200), (2, 300, 64, 16)):
+        _check_grads(train.additive_pool, O.additive_attention, [f(b, s, d), f(q, d) / np.sqrt(d), f(q) * 0.1, f(q) * 0.3])
+
+
+@pytest.mark.parametrize("l0,b1,e,heads", [(11, 6, 100, 10), (300, 3, 100, 10), (40, 5, 96, 2), (9, 4, 128, 2)])
+def test_axis0_attention_backward(l0, b1, e, heads):
+    rng = np.random.default_rng(21)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))        # noqa: E731
+    args = [f(l0, b1, e), f(3 * e, e) / np.sqrt(e), f(3 * e) * 0.1, f(e, e) / np.sqrt(e), f(e) * 0.1]
+    _check_grads(lambda *a: train.mha_axis0(*a, heads), lambda *a: O.mha_axis0(*a, heads), args)
+    # and against torch's own module, called the way the reference calls it
+    mha = torch.nn.MultiheadAttention(e, heads).eval()
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(args[1]); mha.in_proj_bias.copy_(args[2]); mha.out_proj.weight.copy_(args[3]); mha.out_proj.bias.copy_(args[4])
+    ref = mha(args[0], args[0], args[0])[0]
+    out = train.mha_axis0(*[a.to(DEV) for a in args], heads).cpu()
+    assert (out - ref.detach()).abs().max() < 2e-4
+
+
+def test_embedding_and_dropout_operators():
+    rng = np.random.default_rng(22)
+    table = torch.from_numpy(rng.standard_normal((60, 100)).astype(np.float32))
+    ids = torch.from_numpy(rng.integers(0, 60, (13, 6)))
+    ids[0, :3] = 0
+    t1, t2 = table.clone().to(DEV).requires_grad_(True), table.clone().requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((13, 6, 100)).astype(np.float32))
+    (train.embedding(ids.to(DEV), t1, padding_idx=0) * cot.to(DEV)).sum().backward()
+    (torch.nn.functional.embedding(ids, t2, padding_idx=0) * cot).sum().backward()
+    assert _rel(t1.grad.cpu().numpy(), t2.grad.numpy()) < 1e-5 and float(t1.grad[0].abs().max()) == 0.0
+    x = torch.from_numpy(rng.standard_normal((5000,)).astype(np.float32)).to(DEV).requires_grad_(True)
+    y = train.dropout(x, 0.2, seed=5, site=2)
+    keep = train.dropout_mask(5, 2, 0.2, 5000, DEV).float()
+    assert torch.equal(y.detach(), x.detach() * keep / 0.8) and 0.17 < float((keep == 0).float().mean()) < 0.23
+    y.sum().backward()
+    assert torch.equal(x.grad, keep / 0.8)
+
+
+def test_entity_branch_training_matches_reference(golden_dir):
+    """The reference's default use_entities=True through the module mirror in train() mode: outputs and gradients of the
+    entity table (padding row untouched), axis-0 attention, pooler, the linear on cat[text, entity] and text-encoder
+    tensors behind it, against gradients of the reference's own MannerNewsEncoder.train()."""
+    import warnings
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder
+    from test_oracle_golden import golden_train_entities_case
+    cfg, w, ew, z, meta, expect = golden_train_entities_case(golden_dir)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder(plm_model="tiny-bert", frozen_layers=meta["frozen_layers"], dropout_probability=0.0, use_entities=True,
+                                entity_embeddings=ew["entity_encoder.pretrained_embedding.weight"], entity_embedding_dim=100,
+                                num_attention_heads=meta["heads"], query_vector_dim=meta["query_dim"], text_embedding_dim=cfg.hidden)
+    sd = {"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in make_plm_weights(cfg, seed=meta["seed"], std=meta["std"]).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in ew.items()})
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).train()
+    te = enc.text_encoder
+    te.train_precision = "fp32"
+    te.plm_model.hidden_dropout_prob = te.plm_model.attention_probs_dropout_prob = 0.0
+    out = enc({"text": {"input_ids": torch.from_numpy(z["ids"]).to(DEV), "attention_mask": torch.from_numpy(z["mask"]).to(DEV)},
+               "entities": torch.from_numpy(z["entities"]).to(DEV)})
+    assert np.abs(out.detach().cpu().numpy() - z["out"]).max() < 1e-4
+    (out * torch.from_numpy(z["R"]).to(DEV)).sum().backward()
+    hip.check_status(DEV)
+    params = dict(enc.named_parameters())
+    for k, ref in expect.items():
+        assert _rel(params[k].grad.cpu().numpy(), ref) < 1e-3, (k, _rel(params[k].grad.cpu().numpy(), ref))
+    assert float(params["entity_encoder.pretrained_embedding.weight"].grad[0].abs().max()) == 0.0
+    assert params["text_encoder.plm_model.encoder.layer.0.output.dense.weight"].grad is None
+    # entity-side dropout on: reproducible under torch.manual_seed, different across calls
+    enc.entity_encoder.dropout.p = 0.2
+    ent = torch.from_numpy(z["entities"]).to(DEV)
+    torch.manual_seed(3); a = enc.entity_encoder(ent)
+    torch.manual_seed(3); b = enc.entity_encoder(ent)
+    c = enc.entity_encoder(ent)
+    assert torch.equal(a, b) and (a - c).abs().max() > 1e-3

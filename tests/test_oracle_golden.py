@@ -366,3 +366,28 @@ def test_baseline_encoders_match_reference(golden_dir):
         _, mha, pool = _baseline_weights(meta["seed"] + 1, dim)
         out = O.nrms_user_encoder(z[f"nrms_{tag}_x"], mha, pool, heads).numpy()
         assert np.abs(out - z[f"nrms_{tag}_out"]).max() < 1e-5, tag
+
+
+def golden_train_entities_case(golden_dir):
+    from manner_amd.weights import make_entity_weights
+    z, meta = _load(golden_dir, "train_entities")
+    cfg = PRESETS[meta["preset"]]
+    w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"], with_pooler=False)
+    ew = make_entity_weights(meta["n_entities"], dim=100, query_dim=meta["query_dim"], hidden=cfg.hidden, seed=meta["seed"])
+    expect = {k[len("grad:"):]: z[k] for k in z.files if k.startswith("grad:")}
+    return cfg, w, ew, z, meta, expect
+
+
+def test_entity_branch_training_gradients_match_reference(golden_dir):
+    """The reference's default use_entities=True in train() mode: embedding (padding_idx 0), axis-0 attention, pooler, the
+    linear on cat[text, entity] and the text encoder behind it — oracle autograd against the reference's own gradients."""
+    cfg, w, ew, z, meta, expect = golden_train_entities_case(golden_dir)
+    wt = {k: torch.from_numpy(v).requires_grad_("layer.0." not in k) for k, v in w.items()}
+    we = {k: torch.from_numpy(v).requires_grad_(True) for k, v in ew.items()}
+    out = O.news_encoder_train(z["ids"], z["mask"], z["entities"], wt, we, cfg, meta["heads"])
+    assert np.abs(out.detach().numpy() - z["out"]).max() < 2e-5
+    (out * torch.from_numpy(z["R"])).sum().backward()
+    for k, ref in expect.items():
+        g = (wt[k[len("text_encoder.plm_model."):]] if k.startswith("text_encoder.") else we[k]).grad.numpy()
+        assert np.abs(g - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), k
+    assert np.abs(we["entity_encoder.pretrained_embedding.weight"].grad.numpy()[0]).max() == 0.0      # padding_idx row
