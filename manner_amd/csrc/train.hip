@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial sums of dgamma = dy * xhat and
 // dbeta = dy over the rows this block visits (deterministic second stage: reduce_partials_kernel).
 // `dy` may alias `dx`.
-constexpr int LN_BWD_BLOCKS = 128;
+constexpr int LN_BWD_BLOCKS = 512;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
                                                      float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
@@ -399,12 +399,13 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   if (ml) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
 }
 
-// query-row owner: D_i = sum_j dP_ij P_ij, then dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
+// query-row owner: D_i = sum_j dP_ij P_ij = dctx_i . ctx_i (ctx = Pd v carries the same dropout), then
+// dq_i = sum_j P_ij (dP_ij - D_i) k_j / 8
 template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                              const float2* __restrict__ ml, float* __restrict__ dqkv,
-                                                              float* __restrict__ dsum, const int32_t* __restrict__ cu,
-                                                              int heads, int H, Drop drop) {
+                                                              const float* __restrict__ ctx, const float2* __restrict__ ml,
+                                                              float* __restrict__ dqkv, float* __restrict__ dsum,
+                                                              const int32_t* __restrict__ cu, int heads, int H, Drop drop) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
   __shared__ float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
@@ -426,7 +427,12 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
   const float* kh = ks + hs * HS;
   const float* vh = vs + hs * HS;
   float D = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
+  if (active) {
+    const float* o = ctx + (size_t)(base + i) * H + h * AD;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) D = fmaf(go[d], o[d], D);
+  }
+  {
     for (int j0 = 0; j0 < S; j0 += KC) {
       __syncthreads();
       stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
@@ -440,13 +446,9 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
         for (int d = 0; d < AD; ++d) { s = fmaf(q[d], kh[j * AD + d], s); gv = fmaf(go[d], vh[j * AD + d], gv); }
         const float p = expf(s - st.x) * inv;
         const float dp = drop.apply(gv, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
-        if (pass == 0) {
-          D = fmaf(dp, p, D);
-        } else {
-          const float ds = p * (dp - D) * 0.125f;
+        const float ds = p * (dp - D) * 0.125f;
 #pragma unroll
-          for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, kh[j * AD + d], dq[d]);
-        }
+        for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, kh[j * AD + d], dq[d]);
       }
     }
   }
@@ -1174,7 +1176,7 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
     const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
-    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
+    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
     hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da); \
   } while (0)
     MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);

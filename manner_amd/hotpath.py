@@ -79,13 +79,40 @@ def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder
     return hip.to_dense(ragged, cand_off, _width(batch, "cand_max", cand_off)) if dense else ragged
 
 
+def _cat_tokens(a: Dict, b: Dict, pad_id: int) -> Dict:
+    """Two tokenised news sets as one call: rows of `a` then rows of `b`, right-padded to the longer padded length."""
+    la, lb = a["input_ids"].shape[1], b["input_ids"].shape[1]
+    lp = max(la, lb)
+
+    def pad(t, l, value):
+        return t if l == lp else torch.nn.functional.pad(t, (0, lp - l), value=value)
+
+    return {"input_ids": torch.cat([pad(a["input_ids"], la, pad_id), pad(b["input_ids"], lb, pad_id)]),
+            "attention_mask": torch.cat([pad(a["attention_mask"], la, 0), pad(b["attention_mask"], lb, 0)])}
+
+
+def encode_hist_and_cand(news_encoder, x_hist: Dict, x_cand: Dict):
+    """The two news_encoder calls of CRModule.forward (cr_module.py:107,113).  Without entities a news embedding does not
+    depend on its batch, so both sets go through ONE call — one pass over the weights, GEMMs twice as tall —
+    and are split afterwards; with use_entities=True the entity attention couples the news of a call (Q1) and the
+    reference's two separate calls are kept."""
+    keyed = isinstance(x_hist, dict) and "text" in x_hist
+    if getattr(news_encoder, "use_entities", False):
+        return news_encoder(x_hist), news_encoder(x_cand)
+    th, tc = (x_hist["text"], x_cand["text"]) if keyed else (x_hist, x_cand)
+    pad_id = getattr(getattr(getattr(news_encoder, "text_encoder", None), "plm_model", None), "cfg", None)
+    merged = _cat_tokens(th, tc, pad_id.pad_id if pad_id is not None else 0)
+    both = news_encoder({"text": merged} if keyed else merged)
+    n_hist = th["input_ids"].shape[0]
+    return both[:n_hist], both[n_hist:]
+
+
 def cr_train_step(news_encoder, batch: Dict, supcon: bool = True, temperature: float = 0.1):
     """CRModule.model_step for training (cr_module.py:140-171 with late_fusion=True, the shipped MANNeR setting): the
     encoder in train() mode, the fused late-fusion scorer and the loss, all with autograd on the HIP engine.
     Returns (loss, ragged scores [sum c_i] detached, cand_off) — call ``loss.backward()`` and step the reference's optimiser."""
     nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
-    hist_vec = news_encoder(batch["x_hist"])
-    cand_vec = news_encoder(batch["x_cand"])
+    hist_vec, cand_vec = encode_hist_and_cand(news_encoder, batch["x_hist"], batch["x_cand"])
     hist_off = segment_offsets(batch["batch_hist"], nb)
     cand_off = segment_offsets(batch["batch_cand"], nb)
     scores = train.late_fusion_scores(hist_vec, hist_off, cand_vec, cand_off)

@@ -312,6 +312,9 @@ def test_train_at_base_width_exercises_the_256_tile_and_split_gemms(max_len):
     (ref * R).sum().backward()
     assert np.abs(res["fp32"][0] - ref.detach().numpy()).max() < 1e-4
     for k, v in wt.items():
+        if k.endswith("attention.self.key.bias"):           # analytically zero (softmax is shift-invariant): pure rounding noise
+            assert np.abs(res["fp32"][1][k]).max() < 1e-5 and np.abs(v.grad.numpy()).max() < 1e-5
+            continue
         assert _rel(res["fp32"][1][k], v.grad.numpy()) < 2e-3, (k, _rel(res["fp32"][1][k], v.grad.numpy()))
         a, b = res["f16"][1][k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
         if np.abs(b).max() > 1e-5:          # the key-bias gradient is analytically zero: rounding noise has no direction
