@@ -115,6 +115,7 @@ class MannerTextEncoder(nn.Module):
     def __getstate__(self):                      # the HIP handle is rebuilt lazily after copy/unpickle
         d = self.__dict__.copy()
         d["_hip"], d["_hip_key"] = None, None
+        d["_hip_prefix"], d["_hip_prefix_key"] = None, None
         return d
 
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
@@ -133,6 +134,20 @@ class MannerTextEncoder(nn.Module):
     #: activations and gradients) or "fp32"
     train_precision: str = os.environ.get("MANNER_HIP_TRAIN_PRECISION", "f16")
 
+    def _prefix_encoder(self, device: torch.device, params) -> hip.HipEncoder:
+        """Inference engine for the frozen prefix of the training path: rebuilt only when a FROZEN tensor changes (the
+        trainable layers' packed copies go stale after every optimiser step, but encode_hidden never reaches them)."""
+        key = (str(device), self.train_precision,
+               tuple((p.data_ptr(), p._version) for p in params.values() if not p.requires_grad))
+        if getattr(self, "_hip_prefix", None) is None or self._hip_prefix_key != key:
+            if getattr(self, "_hip_prefix", None) is not None:
+                self._hip_prefix.close()
+            prec = self.train_precision if self.train_precision in ("f16", "bf16") else "fp32"
+            self._hip_prefix = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in self.plm_model.named_parameters()},
+                                              precisions=(prec,), device=device)
+            self._hip_prefix_key = key
+        return self._hip_prefix
+
     def _forward_train(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """train() mode (reference news_encoder.py:29-37 under model.train()): HF's dropouts, the [CLS] dropout and autograd
         into every parameter with requires_grad — through the frozen layers into the embeddings when those train (the
@@ -141,7 +156,7 @@ class MannerTextEncoder(nn.Module):
         params = {k: v for k, v in plm.named_parameters() if not k.startswith("pooler.")}
         emb_frozen = not any(p.requires_grad for k, p in params.items() if k.startswith("embeddings."))
         first_frozen = not any(p.requires_grad for k, p in params.items() if "layer.0." in k)
-        engine = self._encoder(ids.device) if (emb_frozen and first_frozen) else None
+        engine = self._prefix_encoder(ids.device, params) if (emb_frozen and first_frozen) else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch's CPU generator: reproducible under manual_seed
         return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=plm.hidden_dropout_prob,
                                   p_attn=plm.attention_probs_dropout_prob, p_out=self.dropout.p, seed=seed, prefix_engine=engine)

@@ -440,3 +440,33 @@ def test_entity_branch_training_matches_reference(golden_dir):
     torch.manual_seed(3); b = enc.entity_encoder(ent)
     c = enc.entity_encoder(ent)
     assert torch.equal(a, b) and (a - c).abs().max() > 1e-3
+
+
+def test_module_mirror_caches_the_frozen_prefix_engine():
+    """Embeddings and layer 0 frozen on the module mirror: train() runs the prefix on an inference engine that survives
+    optimiser steps (only frozen tensors key it) and gives the full path's output."""
+    import warnings
+    from manner_amd.models.components.news_encoder import MannerTextEncoder
+    cfg = PRESETS["tiny-bert"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        te = MannerTextEncoder(plm_model="tiny-bert", frozen_layers=[0], dropout_probability=0.0)
+    te.plm_model.load_state_dict({k: torch.from_numpy(v) for k, v in make_plm_weights(cfg, seed=66, std=0.05).items()})
+    te.plm_model.hidden_dropout_prob = te.plm_model.attention_probs_dropout_prob = 0.0
+    te.train_precision = "fp32"
+    te = te.to(DEV).train()
+    ids_np, mask_np = synth_news_tokens(6, cfg, seed=66, max_len=16)
+    tok = {"input_ids": torch.from_numpy(ids_np).to(DEV), "attention_mask": torch.from_numpy(mask_np).to(DEV)}
+    full = te(tok).detach()                                       # embeddings trainable: full path
+    assert getattr(te, "_hip_prefix", None) is None
+    for k, p in te.plm_model.named_parameters():
+        if k.startswith("embeddings."):
+            p.requires_grad = False
+    opt = torch.optim.SGD([p for p in te.parameters() if p.requires_grad], lr=1e-3)
+    out = te(tok)
+    assert (out.detach() - full).abs().max() < 5e-5
+    engine = te._hip_prefix
+    out.square().sum().backward()
+    opt.step()
+    out2 = te(tok)
+    assert te._hip_prefix is engine and (out2.detach() - full).abs().max() > 1e-6       # same engine, updated upper layers
