@@ -90,6 +90,35 @@ __global__ __launch_bounds__(512, 1) void mfma_order_kernel(const bf16_t* __rest
   dst[blockIdx.x * blockDim.x + threadIdx.x] = s + lane;
 }
 
+// register-only MFMA at reduced DUTY: after every 16 MFMAs (16 x 16 cycles of pipe time) the wave idles NOPS x 16 cycles
+// (both waves of a SIMD do, in the same place): is the data-dependent slowdown still there when the pipe is far from full?
+template <int NOPS>
+__global__ __launch_bounds__(512, 1) void mfma_duty_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + i) * 8);
+    b[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)(threadIdx.x * 8 + 4 + i) * 8);
+  }
+  f32x4 acc[32];
+  for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int u = 16 * (g & 1) + t;
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(t + g) & 3], b[(t >> 2) & 3], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NOPS; ++n) asm volatile("s_nop 15");
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) s += acc[i][e];
+  dst[blockIdx.x * blockDim.x + threadIdx.x] = s + lane;
+}
+
 // shader-clock probe: one wave counts s_memtime ticks against the constant 100 MHz s_memrealtime while other kernels load the
 // chip (it has to be resident BEFORE the persistent GEMM grid takes every CU's registers)
 __global__ void clock_probe_kernel(unsigned long long* out, long long wall_ticks) {
@@ -137,6 +166,23 @@ int main(int argc, char** argv) {
       double ms = time_ms([&] { hipLaunchKernelGGL(mfma_peak16_kernel, dim3(blocks), dim3(512), 0, 0, X, (float*)Y, iters); }, 10);
       const double fl = (double)blocks * 8 * iters * 64 * (2.0 * 16 * 16 * 32);
       printf("mfma_peak 16x16x32 blocks=%d: %.1f us  %.0f TF\n", blocks, ms * 1e3, fl / ms / 1e9);
+    }
+  }
+  {
+    const int iters = 2000;
+    // two waves per SIMD: 16 MFMAs of each = 512 cycles of pipe time per group; NOPS x 16 idle cycles per wave and group
+    const int nops[5] = {0, 8, 16, 32, 64};
+    for (int v = 0; v < 5; ++v) {
+      double ms = time_ms([&] {
+        if (v == 0) hipLaunchKernelGGL(mfma_duty_kernel<0>, dim3(256), dim3(512), 0, 0, X, (float*)Y, iters);
+        else if (v == 1) hipLaunchKernelGGL(mfma_duty_kernel<8>, dim3(256), dim3(512), 0, 0, X, (float*)Y, iters);
+        else if (v == 2) hipLaunchKernelGGL(mfma_duty_kernel<16>, dim3(256), dim3(512), 0, 0, X, (float*)Y, iters);
+        else if (v == 3) hipLaunchKernelGGL(mfma_duty_kernel<32>, dim3(256), dim3(512), 0, 0, X, (float*)Y, iters);
+        else hipLaunchKernelGGL(mfma_duty_kernel<64>, dim3(256), dim3(512), 0, 0, X, (float*)Y, iters);
+      }, 10);
+      const double fl = 256.0 * 8 * iters * 64 * (2.0 * 16 * 16 * 32);
+      // per group and SIMD: max(2 x 256 MFMA cycles, 256 + NOPS x 16) cycles if a wave's idle time hides under its partner's MFMAs
+      printf("mfma_duty nops %2d x16 cycles per 16 MFMAs: %.1f us  %.0f TF\n", nops[v], ms * 1e3, fl / ms / 1e9);
     }
   }
   for (int threads : {512, 256}) {
