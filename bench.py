@@ -775,7 +775,7 @@ def main():
         cpu, par = cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
         result["cpu_baseline"] = cpu
         result["parity"] = par
-    if rank == 0 and world == 1 and not args.no_train and cfg.head_dim == 64:
+    if rank == 0 and world == 1 and not args.no_train and cfg.head_dim == 64 and args.config == 1:
         log("training-step leg (train() mode encoder + scorer + SupCon + backward + AdamW)")
         result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16")
     if rank == 0:
