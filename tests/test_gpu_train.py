@@ -470,3 +470,33 @@ def test_module_mirror_caches_the_frozen_prefix_engine():
     opt.step()
     out2 = te(tok)
     assert te._hip_prefix is engine and (out2.detach() - full).abs().max() > 1e-6       # same engine, updated upper layers
+
+
+def test_train_at_roberta_large_width():
+    """configs[4]'s width (H = 1024, 16 heads, I = 4096, RoBERTa position ids): fp32 against the oracle, f16 against fp32."""
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=67, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(24, cfg, seed=67, max_len=40)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(5).standard_normal((24, cfg.hidden)).astype(np.float32))
+    frozen = {k for k in w if "layer.0." in k}
+    res = {}
+    for prec in ("fp32", "f16"):
+        params = _params(w, frozen)
+        out = train.encode_train(cfg, params, ids, mask, precision=prec, p_hidden=0.0, p_attn=0.0, p_out=0.0)
+        (out * R.to(DEV)).sum().backward()
+        res[prec] = (out.detach().cpu().numpy(), _grads(params))
+    hip.check_status(DEV)
+    wt = {k: torch.from_numpy(v).requires_grad_(k not in frozen) for k, v in w.items()}
+    ref = O.encode_cls_train(ids_np, mask_np, wt, cfg)
+    (ref * R).sum().backward()
+    assert np.abs(res["fp32"][0] - ref.detach().numpy()).max() < 1e-4
+    for k, v in wt.items():
+        if v.grad is None:
+            assert res["fp32"][1][k] is None and res["f16"][1][k] is None
+            continue
+        if k.endswith("attention.self.key.bias"):
+            continue
+        assert _rel(res["fp32"][1][k], v.grad.numpy()) < 2e-3, (k, _rel(res["fp32"][1][k], v.grad.numpy()))
+        a, b = res["f16"][1][k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.999, k
