@@ -324,14 +324,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------ attention (train)
 // qkv [m, 3H] = [Q | K | V].  A workgroup of AT threads serves one news and HPB heads: thread (hs, i) owns query row i of
 // head blockIdx.x * HPB + hs, so short sequences (news titles: <= 32 tokens) still fill a 64-lane wave; keys go through
-// LDS in chunks of KC = 32 / HPB per head (each head's chunk is offset by one word so that the HPB lane groups, which
-// read the same (key, d) of different heads, hit different banks).  P = softmax(q k^T / 8), Pd = dropout(P)
+// LDS in chunks of KC = 32 / HPB per head (each head's chunk is offset by four words so that the HPB lane groups, which
+// read the same 16 bytes of (key, d) of different heads, hit different banks).  P = softmax(q k^T / 8), Pd = dropout(P)
 // (modeling_bert.py:128-140: dropout on the probabilities), ctx = Pd v.  The forward keeps {row max, row sum} so the
 // backward rebuilds P without a reduction pass.
 constexpr int AD = 64;
 template <int HPB> struct AttnGeom {
   static constexpr int KC = 32 / HPB;                 // keys per chunk and head
-  static constexpr int HS = KC * AD + 1;              // words between two heads' chunks
+  static constexpr int HS = KC * AD + 4;              // words between two heads' chunks: 16-byte aligned (ds_read_b128), 4 banks apart
 };
 
 template <int AT, int HPB>
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
                                                             int H, Drop drop, const int32_t* __restrict__ klen) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
-  __shared__ float ks[HPB * HS], vs[HPB * HS];
+  __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
                                                               float* __restrict__ dqkv, float* __restrict__ dsum,
                                                               const int32_t* __restrict__ cu, int heads, int H, Drop drop) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
-  __shared__ float ks[HPB * HS], vs[HPB * HS];
+  __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
                                                                int heads, int H, Drop drop) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
-  __shared__ float qs[HPB * HS], gs[HPB * HS];
+  __shared__ __attribute__((aligned(16))) float qs[HPB * HS], gs[HPB * HS];
   __shared__ float sm[HPB][KC], sl[HPB][KC], sd[HPB][KC];
   const int hs = threadIdx.x / RPH, j = threadIdx.x - hs * RPH;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
