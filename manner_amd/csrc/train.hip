@@ -322,27 +322,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ attention (train)
-// qkv [m, 3H] = [Q | K | V].  A workgroup of AT threads serves one news and HPB heads: thread (hs, i) owns query row i of
-// head blockIdx.x * HPB + hs, so short sequences (news titles: <= 32 tokens) still fill a 64-lane wave; keys go through
-// LDS in chunks of KC = 32 / HPB per head (each head's chunk is offset by four words so that the HPB lane groups, which
-// read the same 16 bytes of (key, d) of different heads, hit different banks).  P = softmax(q k^T / 8), Pd = dropout(P)
-// (modeling_bert.py:128-140: dropout on the probabilities), ctx = Pd v.  The forward keeps {row max, row sum} so the
-// backward rebuilds P without a reduction pass.
-constexpr int AD = 64;
+// qkv [m, 3H] = [Q | K | V].  A workgroup of AT threads serves one news and HPB heads.  Two adjacent lanes own one row
+// (query row in the forward / backward-q kernels, key row in backward-kv) and split its 64 dims: 32 each, so the row
+// state (q, o / q, dctx, dq / k, v, dk, dv) stays in 128 arch VGPRs — the first version kept a whole row per lane and
+// spent more instructions moving accumulators through AGPRs than on FMAs — and dot products are completed with one
+// lane exchange.  RPH = AT / (2 HPB) rows per head: titles (<= 32 tokens) fill a 64-lane workgroup with one head, <= 16
+// tokens with two.  The other side's rows go through LDS in chunks of KC = 32 / HPB per head; a row is stored as two
+// 36-word halves (16-byte aligned for ds_read_b128; the two half-lanes and the HPB head groups read different banks).
+// P = softmax(q k^T / 8), Pd = dropout(P) (modeling_bert.py:128-140: dropout on the probabilities), ctx = Pd v.  The
+// forward keeps {row max, row sum} so the backward rebuilds P without a reduction pass.
+constexpr int AD = 64, AH = 32, RS = 72;              // head dim, dims per lane, LDS words per staged row (2 x (32 + 4))
 template <int HPB> struct AttnGeom {
-  static constexpr int KC = 32 / HPB;                 // keys per chunk and head
-  static constexpr int HS = KC * AD + 4;              // words between two heads' chunks: 16-byte aligned (ds_read_b128), 4 banks apart
+  static constexpr int KC = 32 / HPB;                 // rows per chunk and head
+  static constexpr int HS = KC * RS + 8;              // words between two heads' chunks
 };
 
 template <int AT, int HPB>
 __device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, size_t ld, int col0, int row0, int S, float scale) {
-  // dst[hs][r][d] = src[(row0 + r) * ld + col0 + hs * AD + d] * scale for r < KC (0 beyond S)
+  // dst[hs][r][half][d'] = src[(row0 + r) * ld + col0 + hs * AD + 32 * half + d'] * scale for r < KC (0 beyond S)
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS;
   for (int e = threadIdx.x; e < HPB * KC * AD; e += AT) {
     const int hs = e / (KC * AD), rem = e - hs * (KC * AD), r = rem / AD, d = rem - r * AD;
-    dst[hs * HS + r * AD + d] = row0 + r < S ? src[(size_t)(row0 + r) * ld + col0 + hs * AD + d] * scale : 0.f;
+    dst[hs * HS + r * RS + (d >> 5) * (AH + 4) + (d & 31)] = row0 + r < S ? src[(size_t)(row0 + r) * ld + col0 + hs * AD + d] * scale : 0.f;
   }
 }
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 1, 64); }
 
 // klen != NULL: the rows of news n are queries, only its first klen[n] rows are keys (HF's additive key mask on the
 // padded positions, which still produce outputs of their own: manner_hip_encode_full).
@@ -350,9 +354,9 @@ template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
                                                             int H, Drop drop, const int32_t* __restrict__ klen) {
-  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
-  const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
+  const int hs = threadIdx.x / (2 * RPH), i = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
@@ -360,43 +364,43 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   const int SK = klen ? min(klen[n], S) : S;
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
-  float q[AD], o[AD];
+  float q[AH], o[AH];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { q[d] = active ? rows[(size_t)i * ld + h * AD + d] * 0.125f : 0.f; o[d] = 0.f; }
+  for (int d = 0; d < AH; ++d) { q[d] = active ? rows[(size_t)i * ld + h * AD + AH * half + d] * 0.125f : 0.f; o[d] = 0.f; }
   float mx = -INFINITY, l = 0.f;
-  const float* kh = ks + hs * HS;
-  const float* vh = vs + hs * HS;
+  const float* kh = ks + hs * HS + half * (AH + 4);
+  const float* vh = vs + hs * HS + half * (AH + 4);
   for (int j0 = 0; j0 < SK; j0 += KC) {
     __syncthreads();
     stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, SK, 1.f);
     stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, SK, 1.f);
     __syncthreads();
-    if (!active) continue;
     const int cnt = min(KC, SK - j0);
-    for (int j = 0; j < cnt; ++j) {
+    for (int j = 0; j < cnt; ++j) {                          // (inactive lanes run along: the lane exchange needs both halves)
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) s = fmaf(q[d], kh[j * AD + d], s);
+      for (int d = 0; d < AH; ++d) s = fmaf(q[d], kh[j * RS + d], s);
+      s = pair_sum(s);
       if (s > mx) {
         const float f = expf(mx - s);
         l *= f;
 #pragma unroll
-        for (int d = 0; d < AD; ++d) o[d] *= f;
+        for (int d = 0; d < AH; ++d) o[d] *= f;
         mx = s;
       }
       const float p = expf(s - mx);
       l += p;
       const float pd = drop.apply(p, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
 #pragma unroll
-      for (int d = 0; d < AD; ++d) o[d] = fmaf(pd, vh[j * AD + d], o[d]);
+      for (int d = 0; d < AH; ++d) o[d] = fmaf(pd, vh[j * RS + d], o[d]);
     }
   }
   if (!active) return;
   const float inv = 1.f / l;
-  float* dst = ctx + (size_t)(base + i) * H + h * AD;
+  float* dst = ctx + (size_t)(base + i) * H + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) dst[d] = o[d] * inv;
-  if (ml) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
+  for (int d = 0; d < AH; ++d) dst[d] = o[d] * inv;
+  if (ml && half == 0) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
 }
 
 // query-row owner: D_i = sum_j dP_ij P_ij = dctx_i . ctx_i (ctx = Pd v carries the same dropout), then
@@ -406,57 +410,53 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
                                                               const float* __restrict__ ctx, const float2* __restrict__ ml,
                                                               float* __restrict__ dqkv, float* __restrict__ dsum,
                                                               const int32_t* __restrict__ cu, int heads, int H, Drop drop) {
-  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
-  const int hs = threadIdx.x / RPH, i = threadIdx.x - hs * RPH;
+  const int hs = threadIdx.x / (2 * RPH), i = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
   const bool active = i < S;
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
-  float q[AD], go[AD], dq[AD];
+  float q[AH], go[AH], dq[AH];
+  float D = 0.f;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) {
-    q[d] = active ? rows[(size_t)i * ld + h * AD + d] * 0.125f : 0.f;
-    go[d] = active ? dctx[(size_t)(base + i) * H + h * AD + d] : 0.f;
+  for (int d = 0; d < AH; ++d) {
+    q[d] = active ? rows[(size_t)i * ld + h * AD + AH * half + d] * 0.125f : 0.f;
+    go[d] = active ? dctx[(size_t)(base + i) * H + h * AD + AH * half + d] : 0.f;
     dq[d] = 0.f;
+    D = fmaf(go[d], active ? ctx[(size_t)(base + i) * H + h * AD + AH * half + d] : 0.f, D);
   }
+  D = pair_sum(D);
   const float2 st = active ? ml[(size_t)(base + i) * heads + h] : float2{0.f, 1.f};
   const float inv = 1.f / st.y;
-  const float* kh = ks + hs * HS;
-  const float* vh = vs + hs * HS;
-  float D = 0.f;
-  if (active) {
-    const float* o = ctx + (size_t)(base + i) * H + h * AD;
+  const float* kh = ks + hs * HS + half * (AH + 4);
+  const float* vh = vs + hs * HS + half * (AH + 4);
+  for (int j0 = 0; j0 < S; j0 += KC) {
+    __syncthreads();
+    stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
+    stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, S, 1.f);
+    __syncthreads();
+    const int cnt = min(KC, S - j0);
+    for (int j = 0; j < cnt; ++j) {
+      float s = 0.f, gv = 0.f;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) D = fmaf(go[d], o[d], D);
-  }
-  {
-    for (int j0 = 0; j0 < S; j0 += KC) {
-      __syncthreads();
-      stage_rows<AT, HPB>(ks, rows, ld, H + h0 * AD, j0, S, 1.f);
-      stage_rows<AT, HPB>(vs, rows, ld, 2 * H + h0 * AD, j0, S, 1.f);
-      __syncthreads();
-      if (!active) continue;
-      const int cnt = min(KC, S - j0);
-      for (int j = 0; j < cnt; ++j) {
-        float s = 0.f, gv = 0.f;
+      for (int d = 0; d < AH; ++d) { s = fmaf(q[d], kh[j * RS + d], s); gv = fmaf(go[d], vh[j * RS + d], gv); }
+      s = pair_sum(s);
+      gv = pair_sum(gv);
+      const float p = expf(s - st.x) * inv;
+      const float dp = drop.apply(gv, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
+      const float ds = p * (dp - D) * 0.125f;
 #pragma unroll
-        for (int d = 0; d < AD; ++d) { s = fmaf(q[d], kh[j * AD + d], s); gv = fmaf(go[d], vh[j * AD + d], gv); }
-        const float p = expf(s - st.x) * inv;
-        const float dp = drop.apply(gv, ((uint64_t)(base + i) * heads + h) * 256 + (uint64_t)(j0 + j));
-        const float ds = p * (dp - D) * 0.125f;
-#pragma unroll
-        for (int d = 0; d < AD; ++d) dq[d] = fmaf(ds, kh[j * AD + d], dq[d]);
-      }
+      for (int d = 0; d < AH; ++d) dq[d] = fmaf(ds, kh[j * RS + d], dq[d]);
     }
   }
   if (!active) return;
-  float* dst = dqkv + (size_t)(base + i) * ld + h * AD;
+  float* dst = dqkv + (size_t)(base + i) * ld + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) dst[d] = dq[d];
-  dsum[(size_t)(base + i) * heads + h] = D;
+  for (int d = 0; d < AH; ++d) dst[d] = dq[d];
+  if (half == 0) dsum[(size_t)(base + i) * heads + h] = D;
 }
 
 // key-row owner: dk_j = sum_i dS_ij q_i / 8, dv_j = sum_i Pd_ij dctx_i
@@ -465,25 +465,25 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
                                                                const float2* __restrict__ ml, const float* __restrict__ dsum,
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
                                                                int heads, int H, Drop drop) {
-  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / HPB;
+  constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float qs[HPB * HS], gs[HPB * HS];
   __shared__ float sm[HPB][KC], sl[HPB][KC], sd[HPB][KC];
-  const int hs = threadIdx.x / RPH, j = threadIdx.x - hs * RPH;
+  const int hs = threadIdx.x / (2 * RPH), j = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
   const int base = cu[n], S = cu[n + 1] - base;
   const bool active = j < S;
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
-  float k[AD], v[AD], dk[AD], dv[AD];
+  float k[AH], v[AH], dk[AH], dv[AH];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) {
-    k[d] = active ? rows[(size_t)j * ld + H + h * AD + d] : 0.f;
-    v[d] = active ? rows[(size_t)j * ld + 2 * H + h * AD + d] : 0.f;
+  for (int d = 0; d < AH; ++d) {
+    k[d] = active ? rows[(size_t)j * ld + H + h * AD + AH * half + d] : 0.f;
+    v[d] = active ? rows[(size_t)j * ld + 2 * H + h * AD + AH * half + d] : 0.f;
     dk[d] = dv[d] = 0.f;
   }
-  const float* qh = qs + hs * HS;
-  const float* gh = gs + hs * HS;
+  const float* qh = qs + hs * HS + half * (AH + 4);
+  const float* gh = gs + hs * HS + half * (AH + 4);
   for (int i0 = 0; i0 < S; i0 += KC) {
     __syncthreads();
     stage_rows<AT, HPB>(qs, rows, ld, h0 * AD, i0, S, 0.125f);
@@ -497,35 +497,36 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
       sd[sh][r] = ok ? dsum[(size_t)(base + i0 + r) * heads + h0 + sh] : 0.f;
     }
     __syncthreads();
-    if (!active) continue;
     const int cnt = min(KC, S - i0);
     for (int i = 0; i < cnt; ++i) {
       float s = 0.f, gv = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) { s = fmaf(qh[i * AD + d], k[d], s); gv = fmaf(gh[i * AD + d], v[d], gv); }
+      for (int d = 0; d < AH; ++d) { s = fmaf(qh[i * RS + d], k[d], s); gv = fmaf(gh[i * RS + d], v[d], gv); }
+      s = pair_sum(s);
+      gv = pair_sum(gv);
       const float p = expf(s - sm[hs][i]) * sl[hs][i];
       const uint64_t idx = ((uint64_t)(base + i0 + i) * heads + h) * 256 + (uint64_t)j;
       const float dp = drop.apply(gv, idx);
       const float pd = drop.apply(p, idx);
       const float ds = p * (dp - sd[hs][i]);         // qs already carries the 1/8
 #pragma unroll
-      for (int d = 0; d < AD; ++d) { dk[d] = fmaf(ds, qh[i * AD + d], dk[d]); dv[d] = fmaf(pd, gh[i * AD + d], dv[d]); }
+      for (int d = 0; d < AH; ++d) { dk[d] = fmaf(ds, qh[i * RS + d], dk[d]); dv[d] = fmaf(pd, gh[i * RS + d], dv[d]); }
     }
   }
   if (!active) return;
-  float* dkp = dqkv + (size_t)(base + j) * ld + H + h * AD;
-  float* dvp = dqkv + (size_t)(base + j) * ld + 2 * H + h * AD;
+  float* dkp = dqkv + (size_t)(base + j) * ld + H + h * AD + AH * half;
+  float* dvp = dqkv + (size_t)(base + j) * ld + 2 * H + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
+  for (int d = 0; d < AH; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
 }
 
-// launch geometry from the padded length (<= MANNER_HIP_MAX_LEN = 128): rows per head = 16 / 32 / 64 / 128, up to 4 heads per 64-lane workgroup
+// launch geometry from the padded length (<= MANNER_HIP_MAX_LEN = 128): two lanes per row; rows per head = 16 / 32 / 64 / 128
 #define MANNER_ATTN_DISPATCH(LP, HEADS, CALL)                   \
   do {                                                          \
-    if ((LP) <= 16 && (HEADS) % 4 == 0) { CALL(64, 4); }        \
-    else if ((LP) <= 32 && (HEADS) % 2 == 0) { CALL(64, 2); }   \
-    else if ((LP) <= 64) { CALL(64, 1); }                       \
-    else { CALL(128, 1); }                                      \
+    if ((LP) <= 16 && (HEADS) % 2 == 0) { CALL(64, 2); }        \
+    else if ((LP) <= 32) { CALL(64, 1); }                       \
+    else if ((LP) <= 64) { CALL(128, 1); }                      \
+    else { CALL(256, 1); }                                      \
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ scorer + loss (train)
