@@ -53,6 +53,16 @@ Drop make_drop(uint64_t seed, uint32_t site, float p) {
 enum { SITE_EMB = 0, SITE_CLS = 1, SITE_ATTN = 0, SITE_PROJ = 1, SITE_FFN = 2 };
 __host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (uint32_t)(layer + 1) + (uint32_t)k; }
 
+// optional 16-bit copy of an activation for the next GEMM (saves that GEMM's separate f32 -> 16-bit pass)
+struct Out16 {
+  void* p;
+  int dt;            // 0: none, DT_BF16, DT_F16
+};
+__device__ __forceinline__ void put16(const Out16& o, size_t idx, float v) {
+  if (o.dt == DT_F16) static_cast<f16_t*>(o.p)[idx] = (f16_t)v;
+  else if (o.dt == DT_BF16) static_cast<bf16_t*>(o.p)[idx] = (bf16_t)v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -133,7 +143,7 @@ constexpr int LN_MAX = 16;
 // y = dropout( LN(x) ), stats = {mean, rstd}
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int H, float eps, float* __restrict__ y,
-                                                     float2* __restrict__ stats, const int* __restrict__ m_total, Drop drop) {
+                                                     float2* __restrict__ stats, const int* __restrict__ m_total, Drop drop, Out16 o16) {
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (m >= m_total[0]) return;
@@ -160,7 +170,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < LN_MAX; ++i) {
     const int c = lane + 64 * i;
-    if (c < H) out[c] = drop.apply(fmaf((v[i] - mean) * rstd, gamma[c], beta[c]), (uint64_t)m * H + c);
+    if (c < H) {
+      const float r = drop.apply(fmaf((v[i] - mean) * rstd, gamma[c], beta[c]), (uint64_t)m * H + c);
+      out[c] = r;
+      put16(o16, (size_t)m * H + c, r);
+    }
   }
 }
 
@@ -254,11 +268,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
 // ------------------------------------------------------------------------------------------------ elementwise
 // out = dropout(a) [+ res]; rows >= *m_total untouched
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float* a, const float* res, float* out, int width,
-                                                          const int* __restrict__ m_total, Drop drop) {
+                                                          const int* __restrict__ m_total, Drop drop, Out16 o16) {
   const int64_t total = (int64_t)m_total[0] * width;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const float v = drop.apply(a[i], (uint64_t)i);
-    out[i] = res ? v + res[i] : v;
+    float v = drop.apply(a[i], (uint64_t)i);
+    if (res) v += res[i];
+    out[i] = v;
+    put16(o16, (size_t)i, v);
   }
 }
 
@@ -274,10 +290,13 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 // mode 0: out = gelu(a); mode 1: out = b * gelu'(a)
 __global__ __launch_bounds__(256) void gelu_kernel(const float* a, const float* b, float* out, int width,
-                                                   const int* __restrict__ m_total, int mode) {
+                                                   const int* __restrict__ m_total, int mode, Out16 o16) {
   const int64_t total = (int64_t)m_total[0] * width;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-    out[i] = mode ? b[i] * gelu_grad(a[i]) : gelu_exact(a[i]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = mode ? b[i] * gelu_grad(a[i]) : gelu_exact(a[i]);
+    out[i] = v;
+    put16(o16, (size_t)i, v);
+  }
 }
 
 // out[n] = dropout(x[cu[n]])  ([CLS] rows; news_encoder.py:34-35) — and the scatter of its gradient
@@ -353,7 +372,7 @@ __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 1,
 template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float2* __restrict__ ml, const int32_t* __restrict__ cu, int heads,
-                                                            int H, Drop drop, const int32_t* __restrict__ klen) {
+                                                            int H, Drop drop, const int32_t* __restrict__ klen, Out16 o16) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / (2 * RPH), i = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
@@ -397,9 +416,9 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   }
   if (!active) return;
   const float inv = 1.f / l;
-  float* dst = ctx + (size_t)(base + i) * H + h * AD + AH * half;
+  const size_t c0 = (size_t)(base + i) * H + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) dst[d] = o[d] * inv;
+  for (int d = 0; d < AH; ++d) { ctx[c0 + d] = o[d] * inv; put16(o16, c0 + d, o[d] * inv); }
   if (ml && half == 0) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
 }
 
@@ -409,7 +428,7 @@ template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                               const float* __restrict__ ctx, const float2* __restrict__ ml,
                                                               float* __restrict__ dqkv, float* __restrict__ dsum,
-                                                              const int32_t* __restrict__ cu, int heads, int H, Drop drop) {
+                                                              const int32_t* __restrict__ cu, int heads, int H, Drop drop, Out16 o16) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / (2 * RPH), i = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
@@ -453,9 +472,9 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
     }
   }
   if (!active) return;
-  float* dst = dqkv + (size_t)(base + i) * ld + h * AD + AH * half;
+  const size_t c0 = (size_t)(base + i) * ld + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) dst[d] = dq[d];
+  for (int d = 0; d < AH; ++d) { dqkv[c0 + d] = dq[d]; put16(o16, c0 + d, dq[d]); }
   if (half == 0) dsum[(size_t)(base + i) * heads + h] = D;
 }
 
@@ -464,7 +483,7 @@ template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                const float2* __restrict__ ml, const float* __restrict__ dsum,
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
-                                                               int heads, int H, Drop drop) {
+                                                               int heads, int H, Drop drop, Out16 o16) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float qs[HPB * HS], gs[HPB * HS];
   __shared__ float sm[HPB][KC], sl[HPB][KC], sd[HPB][KC];
@@ -514,10 +533,12 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
     }
   }
   if (!active) return;
-  float* dkp = dqkv + (size_t)(base + j) * ld + H + h * AD + AH * half;
-  float* dvp = dqkv + (size_t)(base + j) * ld + 2 * H + h * AD + AH * half;
+  const size_t ck = (size_t)(base + j) * ld + H + h * AD + AH * half, cv = ck + H;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
+  for (int d = 0; d < AH; ++d) {
+    dqkv[ck + d] = dk[d]; dqkv[cv + d] = dv[d];
+    put16(o16, ck + d, dk[d]); put16(o16, cv + d, dv[d]);
+  }
 }
 
 // launch geometry from the padded length (<= MANNER_HIP_MAX_LEN = 128): two lanes per row; rows per head = 16 / 32 / 64 / 128
@@ -719,6 +740,7 @@ struct Work {
   float *wcat, *bcat, *zero, *tmp; // [3H, H] concatenated Q|K|V weight, its bias, a zero bias, one [Mb, max(I,3H)] temporary
   float *dx, *dr, *dbig, *dqkv, *dsum, *dw, *part;
   float* dwp;                      // partial weight gradients of the split GEMMs: [slices][Nout, K]
+  void *h16a, *h16b, *big16;       // 16-bit copies written by the producers: layer input / ctx or h1 / g or a data gradient
   int32_t* dims;                   // device ints holding row counts of the weight-gradient GEMMs
 };
 void plan_work(Bump& b, Work& w, const manner_hip_encoder_config& c, int64_t Mb) {
@@ -738,6 +760,9 @@ void plan_work(Bump& b, Work& w, const manner_hip_encoder_config& c, int64_t Mb)
   w.dsum = b.take<float>(Mb * c.heads);
   w.dw = b.take<float>(wide * (I > H ? I : H));
   w.part = b.take<float>(2 * (size_t)LN_BWD_BLOCKS * wide);
+  w.h16a = b.take<uint16_t>(Mb * H);
+  w.h16b = b.take<uint16_t>(Mb * H);
+  w.big16 = b.take<uint16_t>(Mb * wide);
   w.dwp = b.take<float>((size_t)1024 * 65536 + wide * (I > H ? I : H));    // slices * Nout * K <= (#CUs <= 1024) * 256 * 256 + Nout * K
   w.dims = b.take<int32_t>(16);
 }
@@ -768,16 +793,21 @@ struct Ctx {
   const float* emb(int i) const { return w[i]; }
   const float* lw(int l, int i) const { return w[MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + i]; }
   DType dt() const { return prec == MANNER_HIP_PREC_F32 ? DT_F32 : prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_BF16; }
+  Out16 o16(void* p) const { return (p && dt() != DT_F32) ? Out16{p, (int)dt()} : Out16{nullptr, 0}; }
   unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
 };
 
 // Y [Mb, Nout] = X [Mb, K] . W [Nout, K]^T + bias      (f32 in / out; operands rounded to the 16-bit type in the mixed modes)
-int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float* Y, int Nout, int K) {
+// X16: the producer's 16-bit copy of X when there is one (else X is converted here)
+int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float* Y, int Nout, int K, const void* X16 = nullptr) {
   int rc;
   if (t.dt() == DT_F32) return gemm_tn(DT_F32, DT_F32, EPI_BIAS, X, W, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
-  if ((rc = convert_f32_to_16(t.dt(), X, t.wk.a16, t.Mb * K, t.s))) return rc;
+  if (!X16) {
+    if ((rc = convert_f32_to_16(t.dt(), X, t.wk.a16, t.Mb * K, t.s))) return rc;
+    X16 = t.wk.a16;
+  }
   if ((rc = convert_f32_to_16(t.dt(), W, t.wk.b16, (int64_t)Nout * K, t.s))) return rc;
-  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, t.wk.a16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
+  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
 }
 
 template <typename T>
@@ -799,13 +829,16 @@ int transpose_to(Ctx& t, const float* in, int64_t rows_in, int64_t cols, void* o
 }
 
 // dX [Mb, K] = dY [Mb, Nout] . W [Nout, K]
-int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, int K) {
+int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, int K, const void* dY16 = nullptr) {
   int rc;
   if ((rc = transpose_to(t, W, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc;       // W^T [K, Nout]
   const void* x = dY;
   if (t.dt() != DT_F32) {
-    if ((rc = convert_f32_to_16(t.dt(), dY, t.wk.a16, t.Mb * Nout, t.s))) return rc;
-    x = t.wk.a16;
+    if (!dY16) {
+      if ((rc = convert_f32_to_16(t.dt(), dY, t.wk.a16, t.Mb * Nout, t.s))) return rc;
+      dY16 = t.wk.a16;
+    }
+    x = dY16;
   }
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, x, t.wk.b16, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
 }
@@ -849,8 +882,9 @@ int bias_grad(Ctx& t, const float* dY, int width, float* db) {
   return MANNER_HIP_OK;
 }
 
-int ln_forward(Ctx& t, const float* x, const float* g, const float* b, float* y, float2* st, Drop drop) {
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)(t.Mb / 4)), dim3(256), 0, t.s, x, g, b, t.c->hidden, t.c->ln_eps, y, st, t.sv.m_total, drop);
+int ln_forward(Ctx& t, const float* x, const float* g, const float* b, float* y, float2* st, Drop drop, void* y16 = nullptr) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)(t.Mb / 4)), dim3(256), 0, t.s, x, g, b, t.c->hidden, t.c->ln_eps, y, st, t.sv.m_total, drop,
+                     t.o16(y16));
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -868,8 +902,8 @@ int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const
   }
   return MANNER_HIP_OK;
 }
-int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop) {
-  hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop);
+int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16 = nullptr) {
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop, t.o16(out16));
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -912,31 +946,34 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
 
 // One BertLayer in train() arithmetic (modeling_bert.py:175-203, 289-293, 334-351); L receives what the backward needs.
 int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out, const int32_t* cu, const int32_t* klen, float p_hidden,
-                  float p_attn, uint64_t seed) {
+                  float p_attn, uint64_t seed, bool x_in_has_16) {
+  // 16-bit copies ride along with the f32 activations (mixed modes): the layer input in wk.h16a (written by whoever produced
+  // x_in when x_in_has_16), ctx then h1 in wk.h16b, gelu's output in wk.big16; this layer's output copy goes to wk.h16a again
   int rc;
   const manner_hip_encoder_config* cfg = t.c;
   const int H = cfg->hidden, I = cfg->intermediate;
   hipStream_t s = t.s;
+  const bool mixed = t.dt() != DT_F32;
   if ((rc = pack_qkv_weights(t, l))) return rc;
-  if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H))) return rc;
+  if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H, mixed && x_in_has_16 ? t.wk.h16a : nullptr))) return rc;
   {
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
 #define MANNER_ATTN_FWD(AT_, HPB_)                                                                                             \
   hipLaunchKernelGGL((attn_train_fwd_kernel<AT_, HPB_>), dim3((unsigned)(cfg->heads / HPB_), (unsigned)t.N), dim3(AT_), 0, s, L.qkv, \
-                     L.ctx, L.ml, cu, cfg->heads, H, da, klen)
+                     L.ctx, L.ml, cu, cfg->heads, H, da, klen, t.o16(t.wk.h16b))
     MANNER_ATTN_DISPATCH(t.Lp, cfg->heads, MANNER_ATTN_FWD);
 #undef MANNER_ATTN_FWD
     MANNER_LAUNCH_CHECK();
   }
-  if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
+  if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H, mixed ? t.wk.h16b : nullptr))) return rc;
   if ((rc = dropout_add(t, t.wk.tmp, x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
-  if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f)))) return rc;
-  if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H))) return rc;
-  hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0);
+  if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
+  if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
+  hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, t.o16(t.wk.big16));
   MANNER_LAUNCH_CHECK();
-  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I))) return rc;
+  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? t.wk.big16 : nullptr))) return rc;
   if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
-  return ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
+  return ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f), t.wk.h16a);
 }
 
 // cu[n] = n * lp (every position is a row), m_total = {n * lp, n}
@@ -1052,11 +1089,11 @@ int manner_hip_encode_full(const manner_hip_encoder_config* cfg, const float* co
                      t.emb(MANNER_HIP_W_WORD_EMB), t.emb(MANNER_HIP_W_POS_EMB), t.emb(MANNER_HIP_W_TYPE_EMB), H, roberta ? cfg->pad_id + 1 : 0,
                      cfg->vocab, cfg->max_pos, f.esum, status, f.lens, roberta ? cfg->pad_id : -1);
   MANNER_LAUNCH_CHECK();
-  if ((rc = ln_forward(t, f.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), f.xa, f.st0, make_drop(0, 0, 0.f)))) return rc;
+  if ((rc = ln_forward(t, f.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), f.xa, f.st0, make_drop(0, 0, 0.f), t.wk.h16a))) return rc;
   float *x_in = f.xa, *x_out = f.xb;
   for (int l = 0; l < cfg->layers; ++l) {
     float* dst = l + 1 == cfg->layers ? hidden : x_out;          // LayerNorm writes rows < n_news * padded_len: exactly `hidden`
-    if ((rc = layer_forward(t, l, f.L, x_in, dst, f.cu_full, f.lens, 0.f, 0.f, 0))) return rc;
+    if ((rc = layer_forward(t, l, f.L, x_in, dst, f.cu_full, f.lens, 0.f, 0.f, 0, true))) return rc;
     float* sw = x_in; x_in = x_out; x_out = sw;
   }
   return MANNER_HIP_OK;
@@ -1091,7 +1128,7 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
                        cfg->vocab, cfg->max_pos, sv.esum, status, nullptr, -1);
     MANNER_LAUNCH_CHECK();
     if ((rc = ln_forward(t, sv.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), x0, sv.st0,
-                         make_drop(seed, SITE_EMB, p_hidden))))
+                         make_drop(seed, SITE_EMB, p_hidden), t.wk.h16a)))
       return rc;
   } else {
     hipLaunchKernelGGL(pack_rows_kernel, dim3(tok_blocks), dim3(256), 0, s, prefix_hidden, x0, n_news, (int)padded_len, sv.cu, H, 0);
@@ -1099,7 +1136,7 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
   }
   for (int l = start_layer; l < cfg->layers; ++l) {
     float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : t.wk.dx;      // the last layer's output is only needed for its [CLS] rows
-    if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, nullptr, p_hidden, p_attn, seed))) return rc;
+    if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, nullptr, p_hidden, p_attn, seed, l > start_layer || start_layer == 0))) return rc;
   }
   hipLaunchKernelGGL(cls_kernel, dim3((unsigned)n_news), dim3(256), 0, s, t.wk.dx, sv.cu, H, cls_out, make_drop(seed, SITE_CLS, p_out));
   MANNER_LAUNCH_CHECK();
@@ -1153,32 +1190,33 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     // LN2: dx -> d r2 (wk.dr)
     if ((rc = ln_backward(t, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
     // r2 = dropout(y2) + h1: d y2 = dropout(d r2) (wk.tmp), d h1 starts as d r2
-    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
+    const bool mixed = t.dt() != DT_F32;
+    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.big16))) return rc;
     if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(t, wk.tmp, L.g, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
-    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I))) return rc;                // d g
-    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, sv.m_total, 1);       // d inter
+    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I, mixed ? wk.big16 : nullptr))) return rc;                // d g
+    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, sv.m_total, 1, t.o16(wk.big16));       // d inter
     MANNER_LAUNCH_CHECK();
     if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(t, wk.dbig, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(t, wk.dbig, L.h1, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
-    if ((rc = linear_dgrad(t, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H))) return rc;
+    if ((rc = linear_dgrad(t, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H, mixed ? wk.big16 : nullptr))) return rc;
     if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d h1
     // LN1: d h1 -> d r1 (wk.dr)
     if ((rc = ln_backward(t, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
     // r1 = dropout(proj) + x_in
-    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;    // d proj
+    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.big16))) return rc;    // d proj
     if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_AO_W) && (rc = linear_wgrad(t, wk.tmp, L.ctx, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
     const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
                        gl(l, MANNER_HIP_WL_K_B) || gl(l, MANNER_HIP_WL_V_B);
     if (!below && !qkv_w) break;
-    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H))) return rc;                 // d ctx
+    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.big16 : nullptr))) return rc;                 // d ctx
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
     const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
-    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da);  \
-    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da); \
+    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da, t.o16(wk.big16));  \
+    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da, t.o16(wk.big16)); \
   } while (0)
     MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);
 #undef MANNER_ATTN_BWD
@@ -1195,7 +1233,7 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     }
     if (!below) break;
     if ((rc = pack_qkv_weights(t, l))) return rc;
-    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.tmp, 3 * H, H))) return rc;
+    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr))) return rc;
     if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d x_in
   }
   const unsigned tok_blocks = (unsigned)(n_news * padded_len);
