@@ -267,11 +267,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
 
 // ------------------------------------------------------------------------------------------------ elementwise
 // out = dropout(a) [+ res]; rows >= *m_total untouched
+// rowmap != NULL: row r of these (compact) tensors stands for row rowmap[r] of the full tensor — the dropout bits are those
+// of the full tensor's element, so the [CLS]-only last layer draws exactly the masks the all-rows computation would
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float* a, const float* res, float* out, int width,
-                                                          const int* __restrict__ m_total, Drop drop, Out16 o16) {
+                                                          const int* __restrict__ m_total, Drop drop, Out16 o16,
+                                                          const int32_t* __restrict__ rowmap) {
   const int64_t total = (int64_t)m_total[0] * width;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float v = drop.apply(a[i], (uint64_t)i);
+    uint64_t di = (uint64_t)i;
+    if (rowmap) { const int64_t r = i / width; di = (uint64_t)rowmap[r] * width + (uint64_t)(i - r * width); }
+    float v = drop.apply(a[i], di);
     if (res) v += res[i];
     out[i] = v;
     put16(o16, (size_t)i, v);
@@ -311,6 +316,18 @@ __global__ __launch_bounds__(256) void cls_bwd_kernel(const float* __restrict__ 
   const int64_t n = blockIdx.x;
   float* dst = dx + (size_t)cu[n] * H;
   for (int c = threadIdx.x; c < H; c += 256) dst[c] = drop.apply(g[(size_t)n * H + c], (uint64_t)n * H + c);
+}
+
+// dst[n] = src[cu[n]] ([CLS] rows -> compact) and dst[cu[n]] += src[n] (compact -> [CLS] rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ cu, int H,
+                                                          float* __restrict__ dst) {
+  const int64_t n = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) dst[(size_t)n * H + c] = src[(size_t)cu[n] * H + c];
+}
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ cu, int H,
+                                                               float* __restrict__ dst) {
+  const int64_t n = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) dst[(size_t)cu[n] * H + c] += src[(size_t)n * H + c];
 }
 
 // out[c][r] = T(in[r][c]) for r < rows_valid, 0 for rows_valid <= r < rows_out  (operands of the gradient GEMMs)
@@ -902,8 +919,9 @@ int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const
   }
   return MANNER_HIP_OK;
 }
-int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16 = nullptr) {
-  hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop, t.o16(out16));
+int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16 = nullptr,
+                const int32_t* rowmap = nullptr) {
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop, t.o16(out16), rowmap);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -945,8 +963,11 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
 
 
 // One BertLayer in train() arithmetic (modeling_bert.py:175-203, 289-293, 334-351); L receives what the backward needs.
+// cls_only (the training path's LAST layer): after the attention only the [CLS] row of every news goes on — the rows
+// r1 / h1 / inter / g / r2 / st1 / st2 of L and x_out are then COMPACT (row n = news n, n_news rows), as in the
+// inference engine's [CLS] tail; x_out [n_news, H].
 int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out, const int32_t* cu, const int32_t* klen, float p_hidden,
-                  float p_attn, uint64_t seed, bool x_in_has_16) {
+                  float p_attn, uint64_t seed, bool x_in_has_16, bool cls_only = false) {
   // 16-bit copies ride along with the f32 activations (mixed modes): the layer input in wk.h16a (written by whoever produced
   // x_in when x_in_has_16), ctx then h1 in wk.h16b, gelu's output in wk.big16; this layer's output copy goes to wk.h16a again
   int rc;
@@ -964,6 +985,25 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     MANNER_ATTN_DISPATCH(t.Lp, cfg->heads, MANNER_ATTN_FWD);
 #undef MANNER_ATTN_FWD
     MANNER_LAUNCH_CHECK();
+  }
+  if (cls_only) {
+    Ctx c = t;                                               // the same helpers over n_news compact rows
+    c.Mb = round_up(t.N, 256);
+    c.sv.m_total = t.sv.m_total + 1;                         // {tokens, news}: the second entry bounds the compact rows
+    float* ctx_c = t.wk.dr;                                  // [n_news, H] gathers (the backward gathers ctx again)
+    float* x_c = t.wk.dbig;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, L.ctx, cu, H, ctx_c);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, x_in, cu, H, x_c);
+    MANNER_LAUNCH_CHECK();
+    if ((rc = linear_fwd(c, ctx_c, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
+    if ((rc = dropout_add(c, t.wk.tmp, x_c, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr, cu))) return rc;
+    if ((rc = ln_forward(c, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
+    if ((rc = linear_fwd(c, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
+    hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, c.sv.m_total, 0, c.o16(t.wk.big16));
+    MANNER_LAUNCH_CHECK();
+    if ((rc = linear_fwd(c, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? t.wk.big16 : nullptr))) return rc;
+    if ((rc = dropout_add(c, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr, cu))) return rc;
+    return ln_forward(c, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
   }
   if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H, mixed ? t.wk.h16b : nullptr))) return rc;
   if ((rc = dropout_add(t, t.wk.tmp, x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
@@ -1136,11 +1176,15 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
   }
   for (int l = start_layer; l < cfg->layers; ++l) {
     float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : t.wk.dx;      // the last layer's output is only needed for its [CLS] rows
-    if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, nullptr, p_hidden, p_attn, seed, l > start_layer || start_layer == 0))) return rc;
+    if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, nullptr, p_hidden, p_attn, seed, l > start_layer || start_layer == 0,
+                            l + 1 == cfg->layers)))
+      return rc;
   }
-  hipLaunchKernelGGL(cls_kernel, dim3((unsigned)n_news), dim3(256), 0, s, t.wk.dx, sv.cu, H, cls_out, make_drop(seed, SITE_CLS, p_out));
-  MANNER_LAUNCH_CHECK();
-  return MANNER_HIP_OK;
+  // wk.dx holds the last layer's [CLS] rows, compact: out[n] = dropout(x_L[cu[n]]) (news_encoder.py:34-35), mask index n * H + c
+  Ctx c = t;
+  c.Mb = round_up(n_news, 256);
+  c.sv.m_total = sv.m_total + 1;
+  return dropout_add(c, t.wk.dx, nullptr, cls_out, H, make_drop(seed, SITE_CLS, p_out));
 }
 
 int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
@@ -1180,37 +1224,57 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     ln_pairs = ln_pairs && (gl(l, MANNER_HIP_WL_ALN_G) != nullptr) == (gl(l, MANNER_HIP_WL_ALN_B) != nullptr) &&
                (gl(l, MANNER_HIP_WL_OLN_G) != nullptr) == (gl(l, MANNER_HIP_WL_OLN_B) != nullptr);
   if (!ln_pairs) return fail(MANNER_HIP_E_INVALID, "train_backward: a LayerNorm's weight and bias gradients come together");
-  // d x_L: only the [CLS] rows carry gradient
-  MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
-  hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, grad_cls, sv.cu, H, wk.dx, make_drop(seed, SITE_CLS, p_out));
-  MANNER_LAUNCH_CHECK();
-  for (int l = cfg->layers - 1; l >= stop; --l) {
+  // One layer, output side first.  `compact` (the last layer): its AO / FFN half ran on the [CLS] rows only (layer_forward), so
+  // that half of the backward runs on n_news compact rows (context `c`), is expanded to the token rows in front of the attention
+  // backward, and the residual gradient is scattered back into d x_in at the end.  On entry wk.dx holds d x_out (compact or full).
+  Ctx cc = t;
+  cc.Mb = round_up(n_news, 256);
+  cc.sv.m_total = sv.m_total + 1;
+  auto layer_backward = [&](int l, bool compact) -> int {
+    Ctx& c = compact ? cc : t;
+    const int32_t* rowmap = compact ? sv.cu : nullptr;
     LayerSaved& L = sv.l[l];
     const bool below = l > stop || emb_grads || grad_prefix;       // is d x_in needed?
-    // LN2: dx -> d r2 (wk.dr)
-    if ((rc = ln_backward(t, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
-    // r2 = dropout(y2) + h1: d y2 = dropout(d r2) (wk.tmp), d h1 starts as d r2
     const bool mixed = t.dt() != DT_F32;
-    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.big16))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(t, wk.tmp, L.g, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
-    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I, mixed ? wk.big16 : nullptr))) return rc;                // d g
-    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, sv.m_total, 1, t.o16(wk.big16));       // d inter
+    // LN2: dx -> d r2 (wk.dr)
+    if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
+    // r2 = dropout(y2) + h1: d y2 = dropout(d r2) (wk.tmp), d h1 starts as d r2
+    if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.big16, rowmap))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(c, wk.tmp, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(c, wk.tmp, L.g, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
+    if ((rc = linear_dgrad(c, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I, mixed ? wk.big16 : nullptr))) return rc;                // d g
+    hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, c.sv.m_total, 1, c.o16(wk.big16));   // d inter
     MANNER_LAUNCH_CHECK();
-    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(t, wk.dbig, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(t, wk.dbig, L.h1, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
-    if ((rc = linear_dgrad(t, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H, mixed ? wk.big16 : nullptr))) return rc;
-    if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d h1
+    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(c, wk.dbig, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(c, wk.dbig, L.h1, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
+    if ((rc = linear_dgrad(c, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H, mixed ? wk.big16 : nullptr))) return rc;
+    if ((rc = add_rows(c, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d h1
     // LN1: d h1 -> d r1 (wk.dr)
-    if ((rc = ln_backward(t, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
+    if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
     // r1 = dropout(proj) + x_in
-    if ((rc = dropout_add(t, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.big16))) return rc;    // d proj
-    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(t, wk.tmp, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_AO_W) && (rc = linear_wgrad(t, wk.tmp, L.ctx, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+    if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.big16, rowmap))) return rc;    // d proj
+    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(c, wk.tmp, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_AO_W)) {
+      const float* ctx_rows = L.ctx;
+      if (compact) {                                     // the [CLS] rows of ctx, gathered as in the forward
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, L.ctx, sv.cu, H, wk.dbig);
+        MANNER_LAUNCH_CHECK();
+        ctx_rows = wk.dbig;
+      }
+      if ((rc = linear_wgrad(c, wk.tmp, ctx_rows, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+    }
     const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
                        gl(l, MANNER_HIP_WL_K_B) || gl(l, MANNER_HIP_WL_V_B);
-    if (!below && !qkv_w) break;
-    if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.big16 : nullptr))) return rc;                 // d ctx
+    if (!below && !qkv_w) return MANNER_HIP_OK;
+    if (compact) {
+      // d ctx of the [CLS] rows -> token rows (every other row of d ctx is zero)
+      if ((rc = linear_dgrad(c, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dqkv, H, H, mixed ? wk.big16 : nullptr))) return rc;
+      MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
+      hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dqkv, sv.cu, H, wk.dx, make_drop(0, 0, 0.f));
+      MANNER_LAUNCH_CHECK();
+    } else if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.big16 : nullptr))) {                 // d ctx
+      return rc;
+    }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
@@ -1231,11 +1295,24 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
         if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
           MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (!below) break;
+    if (!below) return MANNER_HIP_OK;
     if ((rc = pack_qkv_weights(t, l))) return rc;
     if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr))) return rc;
-    if ((rc = add_rows(t, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d x_in
+    if (compact) {                                       // d x_in = d qkv . W on every row, + d r1 on the [CLS] rows
+      MANNER_HIP_TRY(hipMemcpyAsync(wk.dx, wk.tmp, (size_t)m_bound * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dr, sv.cu, H, wk.dx);
+      MANNER_LAUNCH_CHECK();
+      return MANNER_HIP_OK;
+    }
+    return add_rows(t, wk.tmp, wk.dr, wk.dx, H);                                                              // d x_in
+  };
+  if (cfg->layers - 1 >= stop) {
+    // d x_L of the [CLS] rows, compact: the backward of out[n] = dropout(x_L[cu[n]])
+    if ((rc = dropout_add(cc, grad_cls, nullptr, wk.dx, H, make_drop(seed, SITE_CLS, p_out)))) return rc;
+    if ((rc = layer_backward(cfg->layers - 1, true))) return rc;
   }
+  for (int l = cfg->layers - 2; l >= stop; --l)
+    if ((rc = layer_backward(l, false))) return rc;
   const unsigned tok_blocks = (unsigned)(n_news * padded_len);
   if (grad_prefix) {
     hipLaunchKernelGGL(pack_rows_kernel, dim3(tok_blocks), dim3(256), 0, s, grad_prefix, wk.dx, n_news, (int)padded_len, sv.cu, H, 1);
