@@ -63,6 +63,21 @@ __device__ __forceinline__ void put16(const Out16& o, size_t idx, float v) {
   else if (o.dt == DT_BF16) static_cast<bf16_t*>(o.p)[idx] = (bf16_t)v;
 }
 
+// eight consecutive elements at once (idx a multiple of 8): one 16-byte store instead of eight 2-byte ones
+__device__ __forceinline__ void put16x8(const Out16& o, size_t idx, const float* v) {
+  if (o.dt == DT_F16) {
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (f16_t)v[e];
+    *reinterpret_cast<f16x8*>(static_cast<f16_t*>(o.p) + idx) = r;
+  } else if (o.dt == DT_BF16) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(o.p) + idx) = r;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -435,7 +450,9 @@ __global__ __launch_bounds__(AT) void attn_train_fwd_kernel(const float* __restr
   const float inv = 1.f / l;
   const size_t c0 = (size_t)(base + i) * H + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) { ctx[c0 + d] = o[d] * inv; put16(o16, c0 + d, o[d] * inv); }
+  for (int d = 0; d < AH; ++d) { o[d] *= inv; ctx[c0 + d] = o[d]; }
+#pragma unroll
+  for (int d = 0; d < AH; d += 8) put16x8(o16, c0 + d, o + d);
   if (ml && half == 0) ml[(size_t)(base + i) * heads + h] = float2{mx, l};
 }
 
@@ -491,7 +508,9 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __res
   if (!active) return;
   const size_t c0 = (size_t)(base + i) * ld + h * AD + AH * half;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) { dqkv[c0 + d] = dq[d]; put16(o16, c0 + d, dq[d]); }
+  for (int d = 0; d < AH; ++d) dqkv[c0 + d] = dq[d];
+#pragma unroll
+  for (int d = 0; d < AH; d += 8) put16x8(o16, c0 + d, dq + d);
   if (half == 0) dsum[(size_t)(base + i) * heads + h] = D;
 }
 
@@ -552,10 +571,9 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
   if (!active) return;
   const size_t ck = (size_t)(base + j) * ld + H + h * AD + AH * half, cv = ck + H;
 #pragma unroll
-  for (int d = 0; d < AH; ++d) {
-    dqkv[ck + d] = dk[d]; dqkv[cv + d] = dv[d];
-    put16(o16, ck + d, dk[d]); put16(o16, cv + d, dv[d]);
-  }
+  for (int d = 0; d < AH; ++d) { dqkv[ck + d] = dk[d]; dqkv[cv + d] = dv[d]; }
+#pragma unroll
+  for (int d = 0; d < AH; d += 8) { put16x8(o16, ck + d, dk + d); put16x8(o16, cv + d, dv + d); }
 }
 
 // launch geometry from the padded length (<= MANNER_HIP_MAX_LEN = 128): two lanes per row; rows per head = 16 / 32 / 64 / 128
