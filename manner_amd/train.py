@@ -90,8 +90,7 @@ class _EncodeTrain(torch.autograd.Function):
                 ctx.start, C.c_float(opts["p_hidden"]), C.c_float(opts["p_attn"]), C.c_float(opts["p_out"]),
                 C.c_uint64(opts["seed"]), hip._ptr(g), hip._ptr(ctx.saved_buf), ctx.saved_buf.numel(), _table(grads),
                 hip._ptr(gprefix), hip._ptr(ctx.ws), ctx.ws.numel(), hip._stream()))
-        ctx.saved_buf = ctx.ws = None
-        return (None, None, gprefix, None, *grads)
+        return (None, None, gprefix, None, *grads)       # the activation buffer lives with ctx: backward(retain_graph=True) may run again
 
 
 def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mask: Tensor, *, precision: str = "f16",
