@@ -321,14 +321,15 @@ def test_train_at_base_width_exercises_the_256_tile_and_split_gemms(max_len):
             assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.999, k
 
 
-@pytest.mark.parametrize("max_len", [60, 120])
+@pytest.mark.parametrize("max_len", [5, 16, 17, 32, 33, 60, 64, 65, 120, 128])
 def test_train_attention_geometries(max_len):
-    """One head per 64 / 128-thread attention workgroup (padded lengths <= 64 / 128 = MANNER_HIP_MAX_LEN), dropout on."""
+    """Every attention launch geometry and its boundaries (two lanes per row; 16 / 32 / 64 / 128 rows per head, padded lengths up
+    to MANNER_HIP_MAX_LEN = 128), dropout on, a single-news-length-2 edge included."""
     from manner_amd.config import EncoderConfig
     cfg = EncoderConfig(hidden=128, layers=1, heads=2, intermediate=128, vocab=512, max_pos=256)
     w = make_plm_weights(cfg, seed=65, std=0.05, with_pooler=False)
-    lengths = np.array([2, max_len // 3, max_len - 1, max_len, 33][: 5])
-    ids_np, mask_np = synth_news_tokens(5, cfg, seed=65, max_len=max_len, lengths=np.minimum(lengths, max_len))
+    lengths = np.maximum(2, np.minimum(np.array([2, max_len // 3, max_len - 1, max_len, 33]), max_len))
+    ids_np, mask_np = synth_news_tokens(5, cfg, seed=65, max_len=max_len, lengths=lengths)
     R = torch.from_numpy(np.random.default_rng(4).standard_normal((5, cfg.hidden)).astype(np.float32))
     seed, ph, pa, po = 77, 0.1, 0.1, 0.2
     params = _params(w)
