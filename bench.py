@@ -401,9 +401,9 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
         dt = (time.perf_counter() - t0) / steps
         # algorithmic FLOPs: forward of every layer that runs in train() arithmetic, + the data-gradient pass of every layer the
         # activation gradient crosses, + the weight-gradient pass of the trainable layers (each pass = one forward's FLOPs)
-        first = min(l for l in range(cfg.layers) if l not in frozen)
+        first_trainable = min(l for l in range(cfg.layers) if l not in frozen)
         per_layer = float(sum(cfg.flops_per_news(int(n)) for n in mask_np.sum(1))) / cfg.layers
-        passes = (cfg.layers * 2 + (cfg.layers - first)) if emb_trainable else (cfg.layers - first) * 3
+        passes = (cfg.layers * 2 + (cfg.layers - first_trainable)) if emb_trainable else (cfg.layers - first_trainable) * 3
         flops = per_layer * passes
         out[variant] = {"ms_per_step": dt * 1e3, "tokens_per_s": tokens / dt, "news_per_s": (n_hist + n_cand) / dt,
                         "tflops_algorithmic": flops / dt / 1e12, "frac_of_mfma_peak": flops / dt / 1e12 / (F32_PEAK_TFLOPS if precision == "fp32" else BF16_PEAK_TFLOPS),
