@@ -399,6 +399,16 @@ int manner_hip_train_loss(const float* scores, const float* labels, const int64_
                           float temperature, int64_t c_max, float* losses, float* loss_and_scale, float* grad_scores,
                           manner_hip_stream_t stream);
 
+/* The A-Module's loss (manner/models/a_module.py:73-75,102-108): pytorch_metric_learning (>= 2.1.1, requirements.txt:6 — not
+ * vendored by the reference; restated) SupConLoss(temperature, distance=DotProductSimilarity(normalize_embeddings=False)) on the
+ * news embeddings emb f32 [N, D] and their aspect labels int64 [N]: mat = emb emb^T / T; positives of anchor i = other news
+ * with its label, negatives = news with another label; losses[i] = -sum_pos(m_ij - logsumexp_{j != i} m_ij) / (n_pos + FLT_MIN);
+ * loss_and_scale = {mean over the losses > 0 (AvgNonZeroReducer), its factor}; all zero when the batch holds no positive or no
+ * negative pair.  grad_emb f32 [N, D] = d loss / d emb.  workspace: manner_hip_supcon_embeddings_workspace_bytes(N). */
+size_t manner_hip_supcon_embeddings_workspace_bytes(int64_t N);
+int manner_hip_supcon_embeddings(const float* emb, const int64_t* labels, int64_t N, int32_t D, float temperature, float* losses,
+                                 float* loss_and_scale, float* grad_emb, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
+
 /* The small operators of the training step (train_small.hip; f32): what autograd needs below and beside the text encoder
  * for the reference's default `use_entities: True` (configs/model/cr_module.yaml:13) and for early fusion —
  *  - manner_hip_linear_backward: nn.Linear (news_encoder.py:110-113 `linear` on cat[text, entity]; the projections of

@@ -72,6 +72,8 @@ SIGNATURES = {
     "manner_hip_late_fusion_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "manner_hip_dot_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P, _P]),
     "manner_hip_train_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P, _P, _P]),
+    "manner_hip_supcon_embeddings_workspace_bytes": (_SZ, [_I64]),
+    "manner_hip_supcon_embeddings": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _P, _P, _P, _P, _SZ, _P]),
     "manner_hip_linear_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "manner_hip_additive_pool_backward_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
     "manner_hip_additive_pool_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),

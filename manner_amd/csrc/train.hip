@@ -717,6 +717,90 @@ __global__ __launch_bounds__(256) void loss_scale_kernel(float* __restrict__ gra
   for (int64_t j = off[i] + lane; j < off[i + 1]; j += 64) grad[j] *= f;
 }
 
+// ---------------------------------------------------------------- A-Module loss (a_module.py:73-75,102-108)
+// pytorch_metric_learning SupConLoss(temperature, distance=DotProductSimilarity(normalize_embeddings=False)) on the news
+// embeddings E [N, D] and their aspect labels: mat = E E^T / T, positives of anchor i = same label (i itself excluded),
+// negatives = other labels; per anchor l_i = -(sum_pos (m_ij - lse_{j != i} m_ij)) / (n_pos + tiny).
+__global__ __launch_bounds__(256) void a_sim_kernel(const float* __restrict__ emb, int64_t N, int D, float inv_t, float* __restrict__ mat) {
+  const int64_t i = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t j = wave; j < N; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a = fmaf(emb[i * D + c], emb[j * D + c], a);
+    a = wave_sum(a);
+    if (lane == 0) mat[i * N + j] = a * inv_t;
+  }
+}
+// one wave per anchor: loss and the unscaled d l_i / d mat_ij (written over mat; the diagonal gets 0); flags: any positive / any negative
+__global__ __launch_bounds__(256) void a_loss_kernel(float* __restrict__ mat, const int64_t* __restrict__ labels, int64_t N, float tiny,
+                                                     float* __restrict__ losses, int32_t* __restrict__ flags) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N) return;
+  float* row = mat + i * N;
+  const int64_t li = labels[i];
+  float mx = -INFINITY;
+  for (int64_t j = lane; j < N; j += 64) mx = fmaxf(mx, row[j]);                 // the row maximum includes the diagonal, as mat.max(dim=1)
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.f, sp = 0.f, np = 0.f, nn = 0.f;
+  for (int64_t j = lane; j < N; j += 64) {
+    if (j == i) continue;
+    const float v = row[j] - mx;
+    se += expf(v);
+    if (labels[j] == li) { sp += v; np += 1.f; } else nn += 1.f;
+  }
+  se = wave_sum(se); sp = wave_sum(sp); np = wave_sum(np); nn = wave_sum(nn);
+  const float lse = N > 1 ? logf(se) : 0.f;
+  if (lane == 0) {
+    losses[i] = -(sp - np * lse) / (np + tiny);
+    if (np > 0.f) atomicOr(flags, 1);
+    if (nn > 0.f) atomicOr(flags, 2);
+  }
+  for (int64_t j = lane; j < N; j += 64) {
+    if (j == i) { row[j] = 0.f; continue; }
+    const float sm = expf(row[j] - mx - lse);
+    row[j] = -((labels[j] == li ? 1.f : 0.f) - np * sm) / (np + tiny);
+  }
+}
+// {loss, scale} as loss_reduce_kernel (mean over the losses > 0), zero when the batch has no positive pair or no negative pair
+__global__ __launch_bounds__(256) void a_reduce_kernel(float* __restrict__ losses, int64_t N, const int32_t* __restrict__ flags,
+                                                       float* __restrict__ out) {
+  __shared__ float ss[256], sn[256];
+  const bool live = flags[0] == 3;
+  float s = 0.f, n = 0.f;
+  for (int64_t i = threadIdx.x; i < N; i += 256) {
+    if (!live) losses[i] = 0.f;
+    const float l = losses[i];
+    if (l > 0.f) { s += l; n += 1.f; }
+  }
+  ss[threadIdx.x] = s; sn[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sn[threadIdx.x] += sn[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sn[0] > 0.f ? ss[0] / sn[0] : 0.f;
+    out[1] = sn[0] > 0.f ? 1.f / sn[0] : 0.f;
+  }
+}
+// d L / d E_i = (scale / T) sum_j (g_ij [l_i > 0] + g_ji [l_j > 0]) E_j
+__global__ __launch_bounds__(256) void a_grad_kernel(const float* __restrict__ g, const float* __restrict__ losses, const float* __restrict__ red,
+                                                     const float* __restrict__ emb, int64_t N, int D, float inv_t, float* __restrict__ demb) {
+  const int64_t i = blockIdx.x;
+  const float f = red[1] * inv_t;
+  const float li = losses[i] > 0.f ? 1.f : 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+    for (int64_t j = 0; j < N; ++j) {
+      const float w = g[i * N + j] * li + g[j * N + i] * (losses[j] > 0.f ? 1.f : 0.f);
+      a = fmaf(w, emb[j * D + c], a);
+    }
+    demb[i * D + c] = a * f;
+  }
+}
+
 __global__ void mask_kernel(uint8_t* out, int64_t n, Drop drop) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = (drop.thr == 0 || drop_bits(drop.seed, drop.site, (uint64_t)i) >= drop.thr) ? 1 : 0;
@@ -1405,6 +1489,28 @@ int manner_hip_train_loss(const float* scores, const float* labels, const int64_
   MANNER_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_scale_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, grad_scores, losses, cand_off, B, (int)mode,
                      loss_and_scale);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+size_t manner_hip_supcon_embeddings_workspace_bytes(int64_t N) { return N > 0 ? (size_t)N * N * sizeof(float) + 256 : 0; }
+
+int manner_hip_supcon_embeddings(const float* emb, const int64_t* labels, int64_t N, int32_t D, float temperature, float* losses,
+                                 float* loss_and_scale, float* grad_emb, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (!emb || !labels || !losses || !loss_and_scale || !grad_emb || !workspace || N <= 0 || N > 46000 || D <= 0 || !(temperature > 0.f))
+    return fail(MANNER_HIP_E_INVALID, "supcon_embeddings: bad argument");
+  if (workspace_bytes < manner_hip_supcon_embeddings_workspace_bytes(N)) return fail(MANNER_HIP_E_WORKSPACE, "supcon_embeddings: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* mat = static_cast<float*>(workspace);
+  int32_t* flags = reinterpret_cast<int32_t*>(mat + (size_t)N * N);
+  MANNER_HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(a_sim_kernel, dim3((unsigned)N), dim3(256), 0, s, emb, N, D, 1.0f / temperature, mat);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(a_loss_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, mat, labels, N, 1.17549435e-38f, losses, flags);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(a_reduce_kernel, dim3(1), dim3(256), 0, s, losses, N, flags, loss_and_scale);
+  MANNER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(a_grad_kernel, dim3((unsigned)N), dim3(256), 0, s, mat, losses, loss_and_scale, emb, N, D, 1.0f / temperature, grad_emb);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -122,6 +122,14 @@ def cr_train_step(news_encoder, batch: Dict, supcon: bool = True, temperature: f
     return loss, scores.detach(), cand_off
 
 
+def a_train_step(news_encoder, batch: Dict, temperature: float = 0.1):
+    """AModule.model_step for training (a_module.py:102-108): news embeddings in train() mode and the supervised contrastive
+    loss over their aspect labels, both with autograd on the HIP engine.  Returns (loss, embeddings detached)."""
+    emb = news_encoder(batch["news"])
+    loss, _ = train.supcon_embedding_loss(emb, batch["labels"], temperature=temperature)
+    return loss, emb.detach()
+
+
 def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[float], dense: bool = True) -> Tensor:
     """EnsembleModule.forward: CR scores + weighted A-module scores, each z-normalised per impression.
     ``news_encoders[0]`` is the CR-Module's encoder; a zero weight skips that module's encoder entirely

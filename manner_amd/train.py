@@ -379,3 +379,36 @@ def dropout(x: Tensor, p: float, seed: int, site: int = 0) -> Tensor:
     if p <= 0.0:
         return x
     return _Dropout.apply(_f32(x, "x"), float(p), int(seed) & (2 ** 64 - 1), int(site))
+
+
+class _SupConEmbeddings(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb: Tensor, labels: Tensor, temperature: float):
+        n, d = emb.shape
+        lib = _lib.load()
+        losses = torch.empty(n, dtype=torch.float32, device=emb.device)
+        red = torch.empty(2, dtype=torch.float32, device=emb.device)
+        grad = torch.empty_like(emb)
+        with torch.cuda.device(emb.device):
+            need = int(lib.manner_hip_supcon_embeddings_workspace_bytes(n))
+            ws = torch.empty(need, dtype=torch.uint8, device=emb.device)
+            _lib.check(lib.manner_hip_supcon_embeddings(hip._ptr(emb), hip._ptr(labels), n, d, C.c_float(temperature), hip._ptr(losses), hip._ptr(red),
+                                                        hip._ptr(grad), hip._ptr(ws), need, hip._stream()))
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(losses)
+        return red[0], losses
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _g_losses):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def supcon_embedding_loss(embeddings: Tensor, labels: Tensor, temperature: float = 0.1):
+    """The A-Module's criterion (a_module.py:73-75,102-108: pytorch_metric_learning SupConLoss with an un-normalised dot-product
+    similarity) on news embeddings [N, D] and aspect labels [N], with autograd.  Returns (batch loss, per-anchor losses)."""
+    emb = hip._dev(embeddings, torch.float32, "embeddings").contiguous()
+    lab = hip._dev(labels, torch.int64, "labels").contiguous()
+    if emb.dim() != 2 or lab.shape != (emb.shape[0],):
+        raise ValueError("supcon_embedding_loss: embeddings [N, D], labels [N]")
+    return _SupConEmbeddings.apply(emb, lab, float(temperature))

@@ -580,3 +580,28 @@ def model_step_loss(scores: Tensor, labels: Tensor, offsets: Sequence[int], supc
     per = -((pos_mask * log_prob).sum(1) / (pos_mask.sum(1) + torch.finfo(m.dtype).tiny))
     nz = per > 0
     return (per[nz].mean() if bool(nz.any()) else per.sum() * 0), per
+
+
+def supcon_embedding_loss(embeddings: Tensor, labels: Tensor, temperature: float = 0.1):
+    """The A-Module's criterion (reference a_module.py:73-75,102-108): pytorch_metric_learning.losses.SupConLoss(temperature,
+    distance=DotProductSimilarity(normalize_embeddings=False)) called as criterion(embeddings, labels).  The library is not
+    installed here (requirements.txt:6 pins >= 2.1.1): restated from its generic-pair-loss path — all pairs from the labels
+    (positives: same label, the anchor itself excluded; negatives: different label), mat = E E^T, then the very
+    `_compute_loss` the reference copies into manner/models/components/losses.py:21-40 (temperature, row maximum over the
+    whole row detached, logsumexp over positives + negatives, mean positive log-probability) and the loss's default
+    AvgNonZeroReducer.  Differentiable.  Returns (batch loss, per-anchor losses)."""
+    e, y = _t(embeddings), _t(labels).long()
+    n = e.shape[0]
+    same = y[:, None] == y[None, :]
+    eye = torch.eye(n, dtype=torch.bool)
+    pos_mask, neg_mask = (same & ~eye).float(), (~same).float()
+    if not (pos_mask.bool().any() and neg_mask.bool().any()):
+        return e.sum() * 0, torch.zeros(n)
+    m = (e @ e.T) / temperature
+    m = m - m.max(dim=1, keepdim=True)[0].detach()
+    keep = (pos_mask + neg_mask).bool()
+    den = torch.logsumexp(m.masked_fill(~keep, float("-inf")), dim=1, keepdim=True)
+    den = den.masked_fill(~keep.any(dim=1, keepdim=True), 0)
+    per = -((pos_mask * (m - den)).sum(1) / (pos_mask.sum(1) + torch.finfo(m.dtype).tiny))
+    nz = per > 0
+    return (per[nz].mean() if bool(nz.any()) else per.sum() * 0), per

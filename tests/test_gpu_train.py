@@ -501,3 +501,23 @@ def test_train_at_roberta_large_width():
         assert _rel(res["fp32"][1][k], v.grad.numpy()) < 2e-3, (k, _rel(res["fp32"][1][k], v.grad.numpy()))
         a, b = res["f16"][1][k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
         assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.999, k
+
+
+@pytest.mark.parametrize("labels", [[0, 1, 0, 2, 1, 0, 3, 2, 2, 0, 1, 5], [4] * 7, list(range(9)), [0, 0, 1]])
+def test_a_module_supcon_embedding_loss_matches_oracle(labels):
+    """The A-Module's SupConLoss on embeddings (a_module.py:73-75,102-108): loss, per-anchor losses and d loss / d embeddings;
+    batches without a positive or without a negative pair give zero loss and zero gradient; an anchor alone in its class (label
+    3 / 5) is excluded by the non-zero reducer."""
+    n = len(labels)
+    emb_np = (np.random.default_rng(30).standard_normal((n, 128)) * 0.3).astype(np.float32)
+    lab = torch.tensor(labels, dtype=torch.int64)
+    e1, e2 = torch.from_numpy(emb_np).to(DEV).requires_grad_(True), torch.from_numpy(emb_np).requires_grad_(True)
+    loss, per = train.supcon_embedding_loss(e1, lab.to(DEV), temperature=0.36)
+    ref, ref_per = O.supcon_embedding_loss(e2, lab, temperature=0.36)
+    (loss * 1.7).backward()
+    (ref * 1.7).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert (per.cpu() - ref_per.detach()).abs().max() < 1e-4
+    assert _rel(e1.grad.cpu().numpy(), e2.grad.numpy(), floor=1e-4) < 2e-4 or float(e2.grad.abs().max()) == 0.0
+    if len(set(labels)) in (1, n):
+        assert float(loss.detach()) == 0.0 and float(e1.grad.abs().max()) == 0.0
