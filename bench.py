@@ -383,7 +383,8 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
         def enc(x):
             step_no[0] += 1
             return train.encode_train(cfg, params, x["input_ids"], x["attention_mask"], precision=precision, p_hidden=0.1, p_attn=0.1,
-                                      p_out=0.2, seed=step_no[0], prefix_engine=engine)
+                                      p_out=0.2, seed=step_no[0], prefix_engine=engine,
+                                      token_bound=tokens if x["input_ids"].shape[0] == n_hist + n_cand else None)
 
         def step():
             loss, _, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)

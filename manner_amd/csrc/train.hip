@@ -895,6 +895,7 @@ int check_cfg(const manner_hip_encoder_config* c, int64_t N, int64_t Lp, int64_t
   if (N <= 0 || Lp <= 0 || Lp > MANNER_HIP_MAX_LEN)
     return fail(MANNER_HIP_E_INVALID, "train: n_news=%lld padded_len=%lld (padded_len <= %d, as the inference engine)", (long long)N, (long long)Lp, MANNER_HIP_MAX_LEN);
   if (Mb <= 0 || Mb % 256 || Mb > 0x7fffff00ll / (3 * (int64_t)c->hidden)) return fail(MANNER_HIP_E_INVALID, "train: m_bound=%lld must be a positive multiple of 256 within int range", (long long)Mb);
+  if (Mb < round_up(N, 256)) return fail(MANNER_HIP_E_INVALID, "train: m_bound=%lld holds fewer rows than there are news (%lld): every news has a token", (long long)Mb, (long long)N);
   if (precision != MANNER_HIP_PREC_F32 && precision != MANNER_HIP_PREC_BF16 && precision != MANNER_HIP_PREC_F16)
     return fail(MANNER_HIP_E_INVALID, "train: precision %d (fp32, bf16, f16)", precision);
   if (start < 0 || start >= c->layers) return fail(MANNER_HIP_E_INVALID, "train: start_layer %d of %d layers", start, c->layers);

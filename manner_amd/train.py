@@ -96,12 +96,13 @@ class _EncodeTrain(torch.autograd.Function):
 def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mask: Tensor, *, precision: str = "f16",
                  p_hidden: float = 0.1, p_attn: float = 0.1, p_out: float = 0.2, seed: int = 0,
                  prefix_engine: Optional[hip.HipEncoder] = None, prefix_hidden: Optional[Tensor] = None,
-                 start_layer: Optional[int] = None) -> Tensor:
+                 start_layer: Optional[int] = None, token_bound: Optional[int] = None) -> Tensor:
     """[N, Lp] ids / mask -> [N, H] dropout([CLS]) with autograd into ``params`` (HF-named parameter dict).
 
     ``start_layer`` / ``prefix_hidden``: explicit cached prefix; by default the prefix is used automatically when no
     tensor below the first trainable layer requires grad and a ``prefix_engine`` (inference HipEncoder over the same
-    weights) is given."""
+    weights) is given.  ``token_bound``: a host-known upper bound of the real tokens (e.g. the collate's sum of lengths) —
+    activation buffers are sized for it instead of N * Lp; a mask with more tokens raises through the device status word."""
     if precision not in _TRAIN_PRECISIONS:
         raise ValueError(f"training precision {precision!r}: one of {_TRAIN_PRECISIONS}")
     ids, mask = hip._dev(ids, torch.int64, "input_ids").contiguous(), hip._dev(mask, torch.int64, "attention_mask").contiguous()
@@ -132,7 +133,8 @@ def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mas
         if tuple(prefix_hidden.shape) != (ids.shape[0], ids.shape[1], cfg.hidden):
             raise ValueError("prefix_hidden must be [N, Lp, H]")
     opts = dict(cfg=cfg, precision=precision, p_hidden=float(p_hidden), p_attn=float(p_attn), p_out=float(p_out),
-                seed=int(seed) & (2 ** 64 - 1), start_layer=int(start_layer))
+                seed=int(seed) & (2 ** 64 - 1), start_layer=int(start_layer),
+                m_bound=None if token_bound is None else (max(int(token_bound), 1) + 255) // 256 * 256)
     return _EncodeTrain.apply(ids, mask, prefix_hidden, opts, *table)
 
 

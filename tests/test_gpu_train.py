@@ -521,3 +521,30 @@ def test_a_module_supcon_embedding_loss_matches_oracle(labels):
     assert _rel(e1.grad.cpu().numpy(), e2.grad.numpy(), floor=1e-4) < 2e-4 or float(e2.grad.abs().max()) == 0.0
     if len(set(labels)) in (1, n):
         assert float(loss.detach()) == 0.0 and float(e1.grad.abs().max()) == 0.0
+
+
+def test_train_token_bound_sizes_the_buffers_and_is_checked():
+    """token_bound (the collate's host-known token count) gives the same results as the N * Lp default; a bound below the real
+    token count is caught by the device status word, one below the news count is rejected up front."""
+    cfg = PRESETS["tiny-bert"]
+    w = make_plm_weights(cfg, seed=68, std=0.05, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(10, cfg, seed=68, max_len=24)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(6).standard_normal((10, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = []
+    for tb in (None, int(mask_np.sum())):
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision="fp32", p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=11, token_bound=tb)
+        (out * R).sum().backward()
+        res.append((out.detach().cpu(), _grads(params)))
+    hip.check_status(DEV)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert _rel(res[1][1][k], res[0][1][k]) < 1e-5, k       # (embedding gradients are summed with atomics: last bits may differ)
+    big = synth_news_tokens(300, cfg, seed=69, max_len=24)
+    with pytest.raises(RuntimeError, match="fewer rows"):
+        train.encode_train(cfg, _params(w), torch.from_numpy(big[0]).to(DEV), torch.from_numpy(big[1]).to(DEV), precision="fp32", token_bound=200)
+    train.encode_train(cfg, _params(w), torch.from_numpy(big[0]).to(DEV), torch.from_numpy(big[1]).to(DEV), precision="fp32",
+                       token_bound=int(big[1].sum()) // 2, p_hidden=0.0, p_attn=0.0, p_out=0.0)
+    with pytest.raises(RuntimeError, match="host_lengths disagree|input error"):
+        hip.check_status(DEV)
