@@ -2,6 +2,7 @@
 """Headline bench: candidate news encoded+scored per second (BASELINE.json metric).
 
     python bench.py [--config 1|2|3|4] --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -458,7 +459,11 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             "cand_idx": torch.from_numpy(imp["cand_idx"][co[a]:co[b]]).to(dev), "cand_off": torch.from_numpy(co[a:b + 1] - co[a]).to(dev)}
     labels = torch.from_numpy(imp["labels"][co[a]:co[b]]).to(dev)
     K = len(encs)
-    local = [torch.zeros((mx_rows, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]   # padded send blocks
+    # The table is assembled in place (distributed.MeshTableGather): the encoder writes its shard's rows straight into the
+    # [N_news, D] table and every finished piece goes out to the 7 peers over xGMI while the next piece is being encoded.
+    pieces = 1 if world == 1 else 4
+    gathers = [D.MeshTableGather(n_news, cfg.hidden, dev, pieces=pieces) for _ in range(K)]
+    local = [g.table[lo:hi] for g in gathers]           # this rank's rows of each table (world == 1: the whole table)
 
     def sync():
         torch.cuda.synchronize()
@@ -466,21 +471,49 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def encode_all(prec):
+    def encode_all(prec, post=False):
         for k in range(K):
-            encs[k].encode_cls(pool_ids[lo:hi], pool_mask[lo:hi], precision=prec, host_lengths=pool_len[lo:hi],
-                               max_chunk_tokens=args.chunk_tokens, out=local[k][: hi - lo])
+            for c in range(pieces):
+                a_, b_ = gathers[k].piece_rows(rank, c)
+                if b_ > a_:
+                    encs[k].encode_cls(pool_ids[a_:b_], pool_mask[a_:b_], precision=prec, host_lengths=pool_len[a_:b_],
+                                       max_chunk_tokens=args.chunk_tokens, out=gathers[k].local_out(c))
+                if post:
+                    gathers[k].post(c)
 
     times = {}
     for it in range(2):                                 # pass 0 warms up (workspace, RCCL channels)
         sync(); t0 = time.perf_counter()
-        encode_all(args.precision)
-        sync(); t1 = time.perf_counter()
-        tables = [D.all_gather_table(local[k], shards) for k in range(K)]
+        encode_all(args.precision, post=True)
+        torch.cuda.current_stream().synchronize()       # this rank's encoding is done; transfers of the last pieces may still fly
+        t1 = time.perf_counter()
+        tables = [g.wait() for g in gathers]
         sync(); t2 = time.perf_counter()
         res = hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10)
         sync(); t3 = time.perf_counter()
         times = {"encode_s": t1 - t0, "allgather_s": t2 - t1, "score_s": t3 - t2, "total_s": t3 - t0}
+    # the exchange alone, nothing to hide behind: (a) the same full-mesh transfers, all pieces posted at once; (b) ONE
+    # all_gather_into_tensor (RCCL's own algorithm choice) of the same blocks
+    mesh_s = coll_s = None
+    if world > 1:
+        sync(); t0 = time.perf_counter()
+        for g in gathers:
+            for c in range(pieces):
+                g.post(c)
+        for g in gathers:
+            g.wait()
+        sync(); mesh_s = time.perf_counter() - t0
+        blocks = [torch.zeros((mx_rows, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]
+        for k in range(K):
+            blocks[k][: hi - lo] = local[k]
+        D.all_gather_table(blocks[0], shards)
+        sync(); t0 = time.perf_counter()
+        gathered = [D.all_gather_table(blocks[k], shards) for k in range(K)]
+        sync(); coll_s = time.perf_counter() - t0
+        same = all(bool(torch.equal(gathered[k], tables[k])) for k in range(K))
+        del blocks, gathered
+    else:
+        same = True
     sc_r, off_r = res["scores"], dimp["cand_off"]
     n_c = int(sc_r.numel())
     # the fused scorer alone on the first table, by HIP events (the score_s above also holds fusion + ranking)
@@ -488,12 +521,14 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
                   "auc": timed_ms(lambda: hip.auc(sc_r.nan_to_num(0.0), labels)),
                   "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
-    st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"]], dtype=torch.float64, device=dev)
+    st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"], mesh_s or 0.0, coll_s or 0.0],
+                      dtype=torch.float64, device=dev)
     nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a)], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
         D.allreduce_metric_sums(nd)
-    enc_s, ag_s, sc_s, tot_s = st.tolist()
+    enc_s, ag_s, sc_s, tot_s, mesh_s, coll_s = st.tolist()
+    recv_bytes = (n_news - (hi - lo)) * cfg.hidden * 4 * K
     total_c = int(co[-1])
     occ_local = float((ho[b] - ho[a]) + (co[b] - co[a]))
     scorer_bytes = occ_local * (cfg.hidden * 4 + 4) + float(co[b] - co[a]) * 4
@@ -511,9 +546,19 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
                            "HBM fraction — see profiles/ for the FETCH_SIZE pass" if table_bytes < 256 * 2 ** 20 else
                            "occurrence bytes: every history/candidate row read counts once; the table exceeds the 256 MiB "
                            "Infinity Cache, popular rows (Zipf) still hit — HBM-side bytes are in profiles/ (FETCH_SIZE pass)"),
-           "allgather_ms": 1e3 * ag_s, "allgather_bytes_per_rank": (n_news - (hi - lo)) * cfg.hidden * 4 * K if world > 1 else 0,
-           "allgather_GBps_per_rank": ((n_news - (hi - lo)) * cfg.hidden * 4 * K / ag_s / 1e9) if world > 1 and ag_s > 0 else None,
-           "allgather_frac_of_xgmi": ((n_news - (hi - lo)) * cfg.hidden * 4 * K / ag_s / 1e9 / (7 * 153.0)) if world > 1 and ag_s > 0 else None,
+           "allgather_ms": 1e3 * ag_s,
+           "allgather_what": "EXPOSED time of the table exchange: from the end of this rank's encoding to the complete table on every rank "
+                             f"(direct full mesh over xGMI, {pieces} pieces per shard, each posted while the next is encoded)",
+           "allgather_bytes_per_rank": recv_bytes if world > 1 else 0,
+           "allgather_standalone": None if world == 1 else {
+               "mesh_ms": 1e3 * mesh_s, "mesh_GBps_per_rank": recv_bytes / mesh_s / 1e9, "mesh_frac_of_xgmi": recv_bytes / mesh_s / 1e9 / (7 * 153.0),
+               "collective_ms": 1e3 * coll_s, "collective_GBps_per_rank": recv_bytes / coll_s / 1e9,
+               "collective_frac_of_xgmi": recv_bytes / coll_s / 1e9 / (7 * 153.0), "tables_identical": same,
+               "what": "the exchange with nothing to overlap: the mesh transfers of all pieces at once, and ONE all_gather_into_tensor per module; "
+                       "bytes = what a rank receives; xGMI peak = 7 links x 153 GB/s"},
+           "allgather_GBps_per_rank": (recv_bytes / mesh_s / 1e9) if world > 1 and mesh_s > 0 else None,
+           "allgather_frac_of_xgmi": (recv_bytes / mesh_s / 1e9 / (7 * 153.0)) if world > 1 and mesh_s > 0 else None,
+           "world_size_seen": world,
            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(),
            "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
                                 "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}
@@ -542,15 +587,82 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     return out, parity, (dimp, labels)
 
 
+# --------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh rank processes of this script
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1) and wait.
+    Runs BEFORE anything in this process has touched the GPU (no torch.cuda call, no encoder): the children are ordinary
+    child processes (never an exec of a process that initialised HIP).  Rank 0 inherits stdout, so its one JSON line is this
+    command's output; the exit code is the first non-zero child exit code (the other ranks are then terminated by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MANNER_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            code = p_.poll()
+            if code is None:
+                continue
+            live.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                                          # a rank died: the others would wait in a collective forever
+                    q.terminate()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """MANNER_BENCH_DRY=1 (CPU rehearsal of the multi-rank plumbing, tests/test_host.py): rendezvous, one all-reduce and the
+    barrier / MAX-over-ranks protocol of the timed region without any GPU work.  Prints a line marked ``dry_run``; never a
+    measurement."""
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        dist.init_process_group(os.environ.get("MANNER_DIST_BACKEND", "gloo"))
+        seen = dist.get_world_size()
+        dist.barrier()
+    t0 = time.perf_counter()
+    stats = torch.tensor([0.001 * (rank + 1), float(args.impressions)], dtype=torch.float64)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats[0] = mx[0]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "candidate news encoded+scored/sec", "value": None, "unit": "candidates/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "world_size_seen": seen,
+                          "launcher": os.environ.get("MANNER_BENCH_LAUNCHER", "external"),
+                          "impressions_all_ranks": stats[1].item(), "max_rank_time_s": stats[0].item(),
+                          "wall_s": time.perf_counter() - t0}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 # --------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     conf = CONFIGS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (see docstring)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: drop the launcher (bench.py starts its own ranks) or make them agree")
+    if os.environ.get("MANNER_BENCH_DRY"):
+        return dry_run(args, rank, world)
     if os.environ.get("MANNER_BENCH_ONE_DEVICE"):      # rehearsal: every rank on cuda:0
         local = 0
     torch.cuda.set_device(local)
@@ -564,6 +676,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        log(f"process group up: backend {backend}, world size {dist.get_world_size()} (launcher: {os.environ.get('MANNER_BENCH_LAUNCHER', 'external')})")
 
     model = args.model or conf["model"]
     cfg = PRESETS[model]
@@ -683,6 +796,9 @@ def main():
                        "baseline_config": args.config, "modules": K, "ensemble_weights": list(fuse_w),
                        "impressions_per_step_per_gpu": args.impressions, "length_profile": args.profile,
                        "seeded_weights_std": args.std, "parallelism": f"dp{world} (impressions sharded, no collective)"},
+            "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
+            "dist_backend": None if world == 1 else {"nccl": "nccl (RCCL)"}.get(os.environ.get("MANNER_DIST_BACKEND", "nccl"), os.environ.get("MANNER_DIST_BACKEND")),
+            "launcher": os.environ.get("MANNER_BENCH_LAUNCHER", "external") if world > 1 else None,
             "news_encoded_per_s": news_all / elapsed_max, "tokens_per_s": tokens_all / elapsed_max,
             # algorithmic = SURVEY.md §8d F(L) for every news (what the reference computes); executed
             # excludes the last layer's non-[CLS] rows, which the HIP path prunes (not credited as
@@ -797,7 +913,9 @@ def main():
         result["parity"] = par
     if rank == 0 and world == 1 and not args.no_train and cfg.head_dim == 64 and args.config == 1:
         log("training-step leg (train() mode encoder + scorer + SupCon + backward + AdamW)")
-        result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16")
+        # bf16 GEMM operands: f32's exponent range, so the step needs no loss scaling (f16 needs the caller's GradScaler, as the
+        # reference's 16-mixed Lightning plugin provides — manner_amd/models/components/news_encoder.py train_precision)
+        result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("bf16", "fp32") else "bf16")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -100,8 +100,9 @@ int pool_logits_mfma(const float* x, const float* W, const float* bias, const fl
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // m_bound: rows the chunk's buffers hold; expect_tokens >= 0: what the caller's host_lengths promised.  A mask that
-// yields more tokens than m_bound is truncated there (cu clamped) and, like any disagreement with expect_tokens,
-// raises MANNER_HIP_STATUS_LENGTHS — downstream kernels never index past m_bound.
+// yields more tokens than m_bound is truncated there (cu[n] clamped to m_bound - 1 for a news START, cu[n_news] to m_bound:
+// every row index cu[n] + t, t < len, and every [CLS] row cu[n] stays below m_bound) and, like any disagreement with
+// expect_tokens, raises MANNER_HIP_STATUS_LENGTHS.
 int lengths_and_offsets(const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t* lens,
                         int32_t* cu /*[n_news+1]*/, int32_t* m_total /*[2]: tokens, news*/, int64_t m_bound,
                         int64_t expect_tokens, int32_t* status, hipStream_t stream);

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
     __syncthreads();
   }
   int run = part[t] - s;
-  for (int64_t i = lo; i < hi; ++i) { cu[i] = min(run, m_bound); run += lens[i]; }
+  // a news never STARTS at row m_bound: when the mask holds more tokens than the buffers (a wrong host_lengths / token_bound —
+  // STATUS_LENGTHS below), the news past the bound collapse onto the last row, so the [CLS] gathers / scatters that index
+  // row cu[n] stay inside the [m_bound, *] buffers (they used to touch the first row of the NEXT buffer)
+  for (int64_t i = lo; i < hi; ++i) { cu[i] = min(run, m_bound - 1); run += lens[i]; }
   if (t == 1023) {
     const int total = part[1023];
     cu[n] = min(total, m_bound);

@@ -740,18 +740,25 @@ __global__ __launch_bounds__(256) void a_loss_kernel(float* __restrict__ mat, co
   if (i >= N) return;
   float* row = mat + i * N;
   const int64_t li = labels[i];
+  // mat - mat.max(dim=1) (the row maximum INCLUDES the diagonal |E_i|^2 / T, which dominates every other entry for real
+  // [CLS] vectors), then lmu.logsumexp over the kept entries j != i = torch.logsumexp: its own maximum m2 over the kept set
+  // comes out first, so the sum never underflows to 0 however far the diagonal sits above the rest.
   float mx = -INFINITY;
-  for (int64_t j = lane; j < N; j += 64) mx = fmaxf(mx, row[j]);                 // the row maximum includes the diagonal, as mat.max(dim=1)
+  for (int64_t j = lane; j < N; j += 64) mx = fmaxf(mx, row[j]);
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float m2 = -INFINITY;
+  for (int64_t j = lane; j < N; j += 64)
+    if (j != i) m2 = fmaxf(m2, row[j] - mx);
+  for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
   float se = 0.f, sp = 0.f, np = 0.f, nn = 0.f;
   for (int64_t j = lane; j < N; j += 64) {
     if (j == i) continue;
     const float v = row[j] - mx;
-    se += expf(v);
+    se += expf(v - m2);
     if (labels[j] == li) { sp += v; np += 1.f; } else nn += 1.f;
   }
   se = wave_sum(se); sp = wave_sum(sp); np = wave_sum(np); nn = wave_sum(nn);
-  const float lse = N > 1 ? logf(se) : 0.f;
+  const float lse = N > 1 ? m2 + logf(se) : 0.f;
   if (lane == 0) {
     losses[i] = -(sp - np * lse) / (np + tiny);
     if (np > 0.f) atomicOr(flags, 1);
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(256) void a_loss_kernel(float* __restrict__ mat, co
   }
   for (int64_t j = lane; j < N; j += 64) {
     if (j == i) { row[j] = 0.f; continue; }
-    const float sm = expf(row[j] - mx - lse);
+    const float sm = expf((row[j] - mx) - lse);
     row[j] = -((labels[j] == li ? 1.f : 0.f) - np * sm) / (np + tiny);
   }
 }

@@ -357,10 +357,15 @@ int manner_hip_dropout(const float* x, float* out, int64_t n, uint64_t seed, uin
 
 int manner_hip_linear_backward(const float* x, const float* weight, const float* grad_y, int64_t R, int32_t K, int32_t O,
                                const float* add_to_dx, float* grad_x, float* grad_w, float* grad_b, manner_hip_stream_t stream) {
-  if (R <= 0) return R == 0 ? MANNER_HIP_OK : fail(MANNER_HIP_E_INVALID, "linear_backward: R < 0");
-  if (!grad_y || K <= 0 || O <= 0 || O > 2000 || (grad_x && !weight) || (grad_w && !x))
-    return fail(MANNER_HIP_E_INVALID, "linear_backward: bad argument (O <= 2000)");
+  if (R < 0 || K <= 0 || O <= 0) return fail(MANNER_HIP_E_INVALID, "linear_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
+  if (R == 0) {                                    // no rows: the parameter gradients are sums over nothing = 0 (grad_x is empty)
+    if (grad_w) MANNER_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)O * K * sizeof(float), s));
+    if (grad_b) MANNER_HIP_TRY(hipMemsetAsync(grad_b, 0, (size_t)O * sizeof(float), s));
+    return MANNER_HIP_OK;
+  }
+  if (!grad_y || O > 2000 || (grad_x && !weight) || (grad_w && !x))
+    return fail(MANNER_HIP_E_INVALID, "linear_backward: bad argument (O <= 2000)");
   if (grad_x) {
     hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((unsigned)((R + LB_ROWS - 1) / LB_ROWS)), dim3(256), LB_ROWS * O * sizeof(float), s, grad_y,
                        weight, R, K, O, add_to_dx, grad_x);
@@ -385,8 +390,15 @@ size_t manner_hip_additive_pool_backward_workspace_bytes(int64_t B, int64_t S, i
 int manner_hip_additive_pool_backward(const float* x, const float* lin_w, const float* lin_b, const float* query, const float* grad_out,
                                       int64_t B, int64_t S, int32_t D, int32_t Q, float* grad_x, float* grad_w, float* grad_b,
                                       float* grad_q, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream) {
-  if (B == 0 || S == 0) return MANNER_HIP_OK;
-  if (!x || !lin_w || !lin_b || !query || !grad_out || !grad_x || !grad_w || !grad_b || !grad_q || !workspace || B < 0 || S < 0 ||
+  if (B < 0 || S < 0 || D <= 0 || Q <= 0) return fail(MANNER_HIP_E_INVALID, "additive_pool_backward: bad shape");
+  if (B == 0 || S == 0) {                          // an empty batch / empty sequences: zero parameter gradients (grad_x is empty)
+    hipStream_t s0 = (hipStream_t)stream;
+    if (grad_w) MANNER_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)Q * D * sizeof(float), s0));
+    if (grad_b) MANNER_HIP_TRY(hipMemsetAsync(grad_b, 0, (size_t)Q * sizeof(float), s0));
+    if (grad_q) MANNER_HIP_TRY(hipMemsetAsync(grad_q, 0, (size_t)Q * sizeof(float), s0));
+    return MANNER_HIP_OK;
+  }
+  if (!x || !lin_w || !lin_b || !query || !grad_out || !grad_x || !grad_w || !grad_b || !grad_q || !workspace ||
       S > POOL_MAX_S || D <= 0 || Q <= 0)
     return fail(MANNER_HIP_E_INVALID, "additive_pool_backward: bad argument (S <= %d)", POOL_MAX_S);
   if (workspace_bytes < manner_hip_additive_pool_backward_workspace_bytes(B, S, D, Q))

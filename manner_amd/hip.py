@@ -140,6 +140,18 @@ def check_status(device=None) -> None:
         st.check()
 
 
+def status_poll(device) -> None:
+    """Non-blocking: raise for every armed snapshot of ``device``'s status word whose copy has completed.  The composed
+    entry points (hotpath.*, train.encode_train, the module mirrors) call this on the way in and ``status_arm`` on the
+    way out, so an out-of-range index / a token_bound below the mask's token count surfaces at the NEXT call at the
+    latest — without a host synchronisation on the fast path (``check_status`` is the blocking form)."""
+    device_status(device).poll()
+
+
+def status_arm(device) -> None:
+    device_status(device).arm()
+
+
 def weight_table_order(cfg: EncoderConfig) -> Sequence[str]:
     """HF parameter names in the order of the ``weights`` table of manner_hip_encoder_create."""
     names = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",

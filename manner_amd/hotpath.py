@@ -60,6 +60,7 @@ def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder
     """CRModule.forward: scores [B, Cmax] (or the ragged [sum c_i] vector with ``dense=False``).  No torch indexing
     and — when the batch carries ``hist_max`` / ``cand_max`` — no host synchronisation."""
     nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
+    hip.status_poll(batch["batch_cand"].device)
     hist_vec = news_encoder(batch["x_hist"])
     cand_vec = news_encoder(batch["x_cand"])
     hist_off = segment_offsets(batch["batch_hist"], nb)
@@ -76,6 +77,7 @@ def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder
             return click_predictor(user.unsqueeze(1), cand_dense.permute(0, 2, 1))
         cidx = torch.arange(cand_vec.shape[0], dtype=torch.int32, device=cand_vec.device)
         ragged = hip.score_user(cand_vec, user, cidx, cand_off)
+    hip.status_arm(cand_vec.device)
     return hip.to_dense(ragged, cand_off, _width(batch, "cand_max", cand_off)) if dense else ragged
 
 
@@ -112,6 +114,7 @@ def cr_train_step(news_encoder, batch: Dict, supcon: bool = True, temperature: f
     encoder in train() mode, the fused late-fusion scorer and the loss, all with autograd on the HIP engine.
     Returns (loss, ragged scores [sum c_i] detached, cand_off) — call ``loss.backward()`` and step the reference's optimiser."""
     nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
+    hip.status_poll(batch["batch_cand"].device)       # (encode_train arms the word again after its own kernels)
     hist_vec, cand_vec = encode_hist_and_cand(news_encoder, batch["x_hist"], batch["x_cand"])
     hist_off = segment_offsets(batch["batch_hist"], nb)
     cand_off = segment_offsets(batch["batch_cand"], nb)
@@ -138,6 +141,7 @@ def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[flo
     ``sum_k w_k (0 - mean_k) / std_k`` rather than 0 (the reference's consumers mask them away; they are reproduced
     here so that the output is identical, not merely equivalent)."""
     nb = batch["users"].numel()
+    hip.status_poll(batch["users"].device)
     hist_off = segment_offsets(batch["batch_hist"], nb)
     cand_off = segment_offsets(batch["batch_cand"], nb)
     planes, used = [], []
@@ -147,6 +151,7 @@ def ensemble_forward(news_encoders: Sequence, batch: Dict, weights: Sequence[flo
         planes.append(_late_fusion_ragged(enc(batch["x_hist"]), enc(batch["x_cand"]), hist_off, cand_off))
         if k > 0:
             used.append(weights[k - 1])
+    hip.status_arm(cand_off.device)
     if not dense:
         return hip.zscore_fuse(torch.stack(planes), used, cand_off)
     fused, pad = hip.zscore_fuse(torch.stack(planes), used, cand_off, with_pad_value=True)
@@ -169,10 +174,12 @@ def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights:
     hist_off/cand_off int64 (device).  With a single table and no weights the scores are the raw
     late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion."""
     planes = []
+    hip.status_poll(tables[0].device)                 # an out-of-range news index of an earlier call raises here (IndexError in the reference)
     for j, t in enumerate(tables):
         if j > 0 and weights[j - 1] == 0:
             continue
         planes.append(hip.score_late_fusion(t, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"]))
+    hip.status_arm(tables[0].device)
     if len(tables) == 1 and len(weights) == 0:
         scores = planes[0]
     else:

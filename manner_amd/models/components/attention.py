@@ -13,7 +13,8 @@ class AdditiveAttention(nn.Module):
 
     def forward(self, input_vector: torch.Tensor) -> torch.Tensor:
         """(batch, seq, dim) -> (batch, dim); unmasked softmax over ``seq`` as in the reference."""
-        if torch.is_grad_enabled() and (input_vector.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            return train.additive_pool(input_vector, self.linear.weight, self.linear.bias, self.query)      # training: with its backward
+        # autograd records this forward whenever the reference's torch ops would (train() or eval(): there is no dropout here)
+        if torch.is_grad_enabled() and (input_vector.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return train.additive_pool(input_vector, self.linear.weight, self.linear.bias, self.query)      # with its backward
         return hip.additive_pool(input_vector, self.linear.weight.detach(), self.linear.bias.detach(),
                                  self.query.detach())

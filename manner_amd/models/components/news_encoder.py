@@ -22,6 +22,29 @@ from manner_amd.models.components.attention import AdditiveAttention
 from manner_amd.weights import plm_param_shapes
 
 
+_warned_eval_graph = False
+
+
+def _wants_graph(module: nn.Module, *inputs) -> bool:
+    """Does autograd have to record this forward?  The reference's modules are plain torch: whenever grad mode is on and a
+    parameter (or an input) requires grad, their output carries a grad_fn — in eval() too (dropout-free fine-tuning,
+    gradient attribution).  The mirrors follow the same rule: the differentiable engine runs then, with the dropouts
+    switched by ``module.training`` alone; the inference engine serves eval() under no_grad / inference_mode (what Lightning's
+    validation and test loops use) or a fully frozen module."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)
+
+
+def _warn_eval_graph(name: str) -> None:
+    global _warned_eval_graph
+    if not _warned_eval_graph:
+        _warned_eval_graph = True
+        warnings.warn(f"{name}: eval() forward with grad mode on and trainable parameters — running the differentiable engine "
+                      "(dropout off), as the reference would build a graph here; wrap inference in torch.no_grad() / "
+                      "inference_mode() to get the MFMA inference engine")
+
+
 def _set_nested_parameter(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
     parts = dotted.split(".")
     mod = root
@@ -123,7 +146,11 @@ class MannerTextEncoder(nn.Module):
         key = (str(device), self.precision, tuple((p.data_ptr(), p._version) for p in params.values()))
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
-                self._hip.close()
+                try:
+                    self._hip.status()           # input-validation flags still pending on the old handle surface here, not never
+                finally:
+                    self._hip.close()
+                    self._hip = None
             precisions = tuple(dict.fromkeys(("bf16", "fp32", self.precision)))
             self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
                                        precisions=precisions, device=device)
@@ -132,7 +159,11 @@ class MannerTextEncoder(nn.Module):
 
     #: GEMM arithmetic of the training path: "f16" / "bf16" ("16-mixed": 16-bit GEMM operands, f32 accumulation, f32
     #: activations and gradients) or "fp32"
-    train_precision: str = os.environ.get("MANNER_HIP_TRAIN_PRECISION", "f16")
+    #: Default bf16: f32's exponent range, so activation gradients need no loss scaling.  "f16" is the arithmetic of the
+    #: reference's `precision: 16-mixed` and, exactly as there, needs the caller's GradScaler (Lightning's 16-mixed plugin
+    #: scales the loss before backward() and unscales .grad afterwards — the engine then sees scaled gradients): token-level
+    #: gradients of a fine-tuning step routinely fall below f16's normal range (6e-5) and would flush to zero unscaled.
+    train_precision: str = os.environ.get("MANNER_HIP_TRAIN_PRECISION", "bf16")
 
     def _prefix_encoder(self, device: torch.device, params) -> hip.HipEncoder:
         """Inference engine for the frozen prefix of the training path: rebuilt only when a FROZEN tensor changes (the
@@ -148,18 +179,20 @@ class MannerTextEncoder(nn.Module):
             self._hip_prefix_key = key
         return self._hip_prefix
 
-    def _forward_train(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    def _forward_train(self, ids: torch.Tensor, mask: torch.Tensor, dropout: bool = True) -> torch.Tensor:
         """train() mode (reference news_encoder.py:29-37 under model.train()): HF's dropouts, the [CLS] dropout and autograd
         into every parameter with requires_grad — through the frozen layers into the embeddings when those train (the
-        reference's default); with the embeddings frozen too, the frozen prefix runs once on the inference engine."""
+        reference's default); with the embeddings frozen too, the frozen prefix runs once on the inference engine.
+        ``dropout=False``: the same differentiable engine with every dropout off (eval() with grad mode on)."""
         plm = self.plm_model
         params = {k: v for k, v in plm.named_parameters() if not k.startswith("pooler.")}
         emb_frozen = not any(p.requires_grad for k, p in params.items() if k.startswith("embeddings."))
         first_frozen = not any(p.requires_grad for k, p in params.items() if "layer.0." in k)
         engine = self._prefix_encoder(ids.device, params) if (emb_frozen and first_frozen) else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch's CPU generator: reproducible under manual_seed
-        return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=plm.hidden_dropout_prob,
-                                  p_attn=plm.attention_probs_dropout_prob, p_out=self.dropout.p, seed=seed, prefix_engine=engine)
+        on = 1.0 if dropout else 0.0
+        return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=on * plm.hidden_dropout_prob,
+                                  p_attn=on * plm.attention_probs_dropout_prob, p_out=on * self.dropout.p, seed=seed, prefix_engine=engine)
 
     def forward(self, tokenized_text) -> torch.Tensor:
         ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
@@ -174,8 +207,12 @@ class MannerTextEncoder(nn.Module):
         # the device; its flag word is snapshotted behind an event after every call and the completed snapshots are
         # examined before the next one — an invalid batch raises at the following forward (or at check_inputs()),
         # never passes silently, and the fast path has no host synchronisation.
-        if self.training and torch.is_grad_enabled():
-            return self._forward_train(ids, mask)
+        # Which engine: train() draws dropout masks (with or without a graph), and a graph is recorded whenever autograd
+        # would record one for the reference (_wants_graph); only eval() without a graph runs the inference engine.
+        if self.training or _wants_graph(self.plm_model):
+            if not self.training:
+                _warn_eval_graph("MannerTextEncoder")
+            return self._forward_train(ids, mask, dropout=self.training)
         enc = self._encoder(ids.device)
         enc.status_poll()
         out = enc.encode_cls(ids, mask, precision=self.precision)
@@ -227,22 +264,27 @@ class MannerEntityEncoder(nn.Module):
 
     def forward(self, entity_sequence: torch.Tensor) -> torch.Tensor:
         mha, pool = self.multihead_attention, self.additive_attention
-        if self.training and torch.is_grad_enabled():
+        if self.training or _wants_graph(self):
             # train() mode (news_encoder.py:60-72): embedding -> dropout -> axis-0 attention -> dropout -> additive pooler,
-            # every operator with its hand-written backward (manner_amd.train / csrc/train_small.hip)
+            # every operator with its hand-written backward (manner_amd.train / csrc/train_small.hip); eval() with a graph:
+            # the same operators with the dropouts off
             if mha.dropout != 0.0:
                 raise RuntimeError("attention-probability dropout inside nn.MultiheadAttention is not built (the reference uses 0)")
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            p = self.dropout.p if self.training else 0.0
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
             emb = self.pretrained_embedding
             x = train.embedding(entity_sequence, emb.weight, emb.padding_idx)
-            x = train.dropout(x, self.dropout.p, seed, site=2)
+            x = train.dropout(x, p, seed, site=2)
             x = train.mha_axis0(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, mha.num_heads)
-            x = train.dropout(x, self.dropout.p, seed, site=3)
+            x = train.dropout(x, p, seed, site=3)
             return train.additive_pool(x, pool.linear.weight, pool.linear.bias, pool.query)
-        return hip.entity_encode(entity_sequence, self.pretrained_embedding.weight.detach(), mha.in_proj_weight.detach(),
-                                 mha.in_proj_bias.detach(), mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
-                                 pool.linear.weight.detach(), pool.linear.bias.detach(), pool.query.detach(),
-                                 heads=mha.num_heads)
+        hip.status_poll(entity_sequence.device)          # an entity index outside the table (IndexError in the reference) of an earlier call
+        out = hip.entity_encode(entity_sequence, self.pretrained_embedding.weight.detach(), mha.in_proj_weight.detach(),
+                                mha.in_proj_bias.detach(), mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
+                                pool.linear.weight.detach(), pool.linear.bias.detach(), pool.query.detach(),
+                                heads=mha.num_heads)
+        hip.status_arm(entity_sequence.device)
+        return out
 
 
 class MannerNewsEncoder(nn.Module):
@@ -273,7 +315,7 @@ class MannerNewsEncoder(nn.Module):
         # entity embedding, concat, linear (news_encoder.py:119-124)
         entity_vector = self.entity_encoder(news["entities"])
         both = torch.cat([text_vector, entity_vector], dim=-1)                  # a copy; its backward is a split
-        if self.training and torch.is_grad_enabled():
+        if _wants_graph(self.linear, both):
             return train.linear(both, self.linear.weight, self.linear.bias)
         return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach())
 

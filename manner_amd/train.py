@@ -60,11 +60,13 @@ class _EncodeTrain(torch.autograd.Function):
             out = torch.empty((n, cfg.hidden), dtype=torch.float32, device=dev)
             weights = [p.detach() for p in params]
             status = hip.device_status(dev)
+            status.poll()                     # flags of earlier calls (a token_bound below the mask's count, a bad id) raise here
             _lib.check(lib.manner_hip_train_forward(
                 C.byref(cc), _table(weights), len(weights), hip._ptr(ids), hip._ptr(mask), n, lp, m_bound, prec, start,
                 hip._ptr(prefix), C.c_float(opts["p_hidden"]), C.c_float(opts["p_attn"]), C.c_float(opts["p_out"]),
                 C.c_uint64(opts["seed"]), hip._ptr(out), hip._ptr(saved), saved.numel(), hip._ptr(ws), ws.numel(),
                 hip._ptr(status.word), hip._stream()))
+            status.arm()                      # snapshot behind an event: examined, without blocking, by the next poll
         ctx.opts, ctx.m_bound, ctx.prec, ctx.start = opts, m_bound, prec, start
         ctx.saved_buf, ctx.ws = saved, ws
         ctx.save_for_backward(ids, *params)
@@ -102,7 +104,9 @@ def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mas
     ``start_layer`` / ``prefix_hidden``: explicit cached prefix; by default the prefix is used automatically when no
     tensor below the first trainable layer requires grad and a ``prefix_engine`` (inference HipEncoder over the same
     weights) is given.  ``token_bound``: a host-known upper bound of the real tokens (e.g. the collate's sum of lengths) —
-    activation buffers are sized for it instead of N * Lp; a mask with more tokens raises through the device status word."""
+    activation buffers are sized for it instead of N * Lp; a mask with more tokens is truncated at the bound (never indexed past
+    it) and raises ``RuntimeError`` through the device status word: at the next training / scoring call (non-blocking poll) or
+    at ``hip.check_status`` (blocking)."""
     if precision not in _TRAIN_PRECISIONS:
         raise ValueError(f"training precision {precision!r}: one of {_TRAIN_PRECISIONS}")
     ids, mask = hip._dev(ids, torch.int64, "input_ids").contiguous(), hip._dev(mask, torch.int64, "attention_mask").contiguous()

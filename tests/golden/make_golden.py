@@ -401,6 +401,12 @@ if __name__ == "__main__":
         gen_encoder("enc_roberta_base", "roberta-base", n=16, lp=96, seed=46, std=0.02,
                     lengths=np.array([5, 9, 12, 16, 17, 23, 31, 32, 33, 47, 48, 64, 65, 80, 95, 96]))
         sys.exit(0)
+    if "--roberta-large-only" in sys.argv:
+        # BASELINE.json configs[4] at its FULL architecture (24 layers, H = 1024, 16 heads, I = 4096; vocab 50265, positions
+        # 514, eps 1e-5, pad 1 — SURVEY §8c): 12 news with lengths {2, 33, 96} each four times, in mixed order
+        gen_encoder("enc_roberta_large", "roberta-large", n=12, lp=96, seed=56, std=0.02,
+                    lengths=np.array([2, 33, 96, 96, 2, 33, 33, 96, 2, 96, 33, 2]))
+        sys.exit(0)
     if "--distilbert-only" in sys.argv:
         keys = json.load(open(os.path.join(HERE, "state_dict_keys.json")))
         keys["tiny-distilbert"] = gen_encoder("enc_tiny_distilbert", "tiny-distilbert", n=12, lp=40, seed=45, std=0.05)

@@ -42,7 +42,9 @@ def _encoder(preset, seed, std):
 
 GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base",
               # round 2: 64 news incl. lengths 2 and 96; [title, abstract] pair inputs through a real tokenizer call (Q4)
-              "enc_bert_base_64", "enc_roberta_base_64", "enc_pair_bert_base", "enc_pair_tiny_bert"]
+              "enc_bert_base_64", "enc_roberta_base_64", "enc_pair_bert_base", "enc_pair_tiny_bert",
+              # round 3: BASELINE configs[4] at its FULL architecture — roberta-large, 24 layers, H = 1024, 16 heads; lengths {2, 33, 96}
+              "enc_roberta_large"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_ENC)
@@ -327,7 +329,23 @@ def test_module_surface_matches_reference(golden_dir):
     ue.load_state_dict({k: torch.from_numpy(v) for k, v in
                         make_additive_attention_weights(ma["input_dim"], ma["query_dim"], seed=ma["seed"]).items()})
     ue = ue.to(DEV).eval()
-    assert np.abs(ue(_cuda(za["x"])).cpu().numpy() - za["out"]).max() < 1e-5
+    with torch.no_grad():
+        assert np.abs(ue(_cuda(za["x"])).cpu().numpy() - za["out"]).max() < 1e-5
+    # eval() with grad mode ON and trainable parameters: the reference's torch modules record a graph there (dropout off),
+    # so do the mirrors — same values as the inference engine, with a grad_fn (this used to return a constant)
+    out_g = ue(_cuda(za["x"]))
+    assert out_g.requires_grad and np.abs(out_g.detach().cpu().numpy() - za["out"]).max() < 1e-5
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out_e = enc(news)                                        # enc is in eval(), dropout p = 0.2 configured but off
+    assert out_e.requires_grad and np.abs(out_e.detach().cpu().numpy() - z["out"]).max() < FP32_TOL
+    out_e.sum().backward()
+    named = dict(enc.named_parameters())
+    assert named["text_encoder.plm_model.encoder.layer.1.output.dense.weight"].grad is not None
+    assert named["text_encoder.plm_model.encoder.layer.0.output.dense.weight"].grad is None          # frozen_layers=[0]
+    for p_ in enc.parameters():                                  # fully frozen: the inference engine again, no graph
+        p_.requires_grad_(False)
+    assert not enc(news).requires_grad
     zd, _ = _load(golden_dir, "dot_product")
     assert np.abs(DotProduct()(_cuda(zd["user"]), _cuda(zd["cand"])).cpu().numpy() - zd["out"]).max() < 1e-4
 
@@ -834,7 +852,8 @@ def test_encoder_bf16x3_close_to_the_fp32_bar(golden_dir, name):
     enc.close()
 
 
-@pytest.mark.parametrize("name", ["enc_bert_base", "enc_bert_base_spread", "enc_roberta_base", "enc_bert_base_64", "enc_pair_bert_base"])
+@pytest.mark.parametrize("name", ["enc_bert_base", "enc_bert_base_spread", "enc_roberta_base", "enc_bert_base_64", "enc_pair_bert_base",
+                                  "enc_roberta_large"])
 def test_encoder_f16x3_meets_the_fp32_bar(golden_dir, name):
     """F16X3: the split-operand schedule on IEEE half (hi and lo carry 11 bits each: ~21 operand bits through the three
     products).  Held to the FP32 mode's bar — 1e-4 absolute against the reference's CLS embeddings — at the speed of
@@ -902,21 +921,24 @@ def test_baseline_encoders_match_reference(golden_dir):
         enc.load_state_dict(sd, strict=True)
         enc = enc.to(DEV).eval()
         ids, mask = _cuda(z[f"plm_{tag}_ids"]), _cuda(z[f"plm_{tag}_mask"])
-        out = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
+        with torch.no_grad():
+            out = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
         assert np.abs(out - z[f"plm_{tag}_out"]).max() < FP32_TOL, (tag, np.abs(out - z[f"plm_{tag}_out"]).max())
         # the padded positions themselves, against the oracle's HF restatement
         hidden = hip.encode_full(cfg, {k: _cuda(v) for k, v in w.items()}, ids, mask).cpu().numpy()
         ref_h = O.encode_tokens(z[f"plm_{tag}_ids"], z[f"plm_{tag}_mask"], w, cfg).numpy()
         assert np.abs(hidden - ref_h).max() < FP32_TOL
         enc.precision = "f16"
-        out16 = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
+        with torch.no_grad():
+            out16 = enc({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
         assert np.abs(out16 - z[f"plm_{tag}_out"]).max() < 2e-2
     for tag, (dim, heads) in meta["nrms"].items():
         mw = make_mha_pool_weights(dim, meta["query_dim"], seed=meta["seed"] + 1)
         ue = NRMSUserEncoder(news_embedding_dim=dim, num_attention_heads=heads, query_vector_dim=meta["query_dim"])
         ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
         ue = ue.to(DEV).eval()
-        out = ue(_cuda(z[f"nrms_{tag}_x"])).cpu().numpy()
+        with torch.no_grad():
+            out = ue(_cuda(z[f"nrms_{tag}_x"])).cpu().numpy()
         assert np.abs(out - z[f"nrms_{tag}_out"]).max() < 1e-4, tag
     hip.check_status(DEV)
     # NRMS at the reference's configured size (768 dims, 16 heads => head_dim 48), 300 users x 50 history slots, vs the oracle
@@ -927,5 +949,6 @@ def test_baseline_encoders_match_reference(golden_dir):
     x[::3, 20:] = 0.0
     ue = NRMSUserEncoder(news_embedding_dim=768, num_attention_heads=16, query_vector_dim=200)
     ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
-    out = ue.to(DEV).eval()(_cuda(x)).cpu().numpy()
+    with torch.no_grad():
+        out = ue.to(DEV).eval()(_cuda(x)).cpu().numpy()
     assert np.abs(out - O.nrms_user_encoder(x, mha, pool, 16).numpy()).max() < 2e-4

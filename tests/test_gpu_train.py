@@ -371,6 +371,28 @@ def test_linear_and_additive_pool_backward():
         _check_grads(train.additive_pool, O.additive_attention, [f(b, s, d), f(q, d) / np.sqrt(d), f(q) * 0.1, f(q) * 0.3])
 
 
+def test_empty_calls_give_zero_parameter_gradients():
+    """A rank whose batch has no history (or no candidate) rows calls the operators with zero rows: the parameter gradients
+    are sums over nothing — zeros, never whatever torch.empty held."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    w = torch.randn((300, 100), device=DEV, generator=g).requires_grad_(True)
+    b = torch.randn(300, device=DEV, generator=g).requires_grad_(True)
+    junk = [torch.full((300, 100), float("nan"), device=DEV) for _ in range(8)]          # poison the allocator's free blocks
+    del junk
+    x = torch.empty((0, 100), device=DEV, requires_grad=True)
+    train.linear(x, w, b).sum().backward()
+    assert w.grad is not None and float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0 and x.grad.shape == (0, 100)
+    pw = torch.randn((200, 768), device=DEV, generator=g).requires_grad_(True)
+    pb, pq = torch.randn(200, device=DEV, generator=g).requires_grad_(True), torch.randn(200, device=DEV, generator=g).requires_grad_(True)
+    junk = [torch.full((200, 768), float("nan"), device=DEV) for _ in range(8)]
+    del junk
+    out = train.additive_pool(torch.empty((0, 5, 768), device=DEV, requires_grad=True), pw, pb, pq)
+    assert out.shape == (0, 768)
+    out.sum().backward()
+    for t in (pw, pb, pq):
+        assert float(t.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("l0,b1,e,heads", [(11, 6, 100, 10), (300, 3, 100, 10), (40, 5, 96, 2), (9, 4, 128, 2)])
 def test_axis0_attention_backward(l0, b1, e, heads):
     rng = np.random.default_rng(21)
@@ -521,6 +543,30 @@ def test_a_module_supcon_embedding_loss_matches_oracle(labels):
     assert _rel(e1.grad.cpu().numpy(), e2.grad.numpy(), floor=1e-4) < 2e-4 or float(e2.grad.abs().max()) == 0.0
     if len(set(labels)) in (1, n):
         assert float(loss.detach()) == 0.0 and float(e1.grad.abs().max()) == 0.0
+
+
+def test_a_module_supcon_loss_at_real_embedding_magnitudes():
+    """[CLS] vectors of a trained PLM: |E| ~ 20, pairwise cosine ~ 0.9, T = 0.1 — the diagonal |E_i|^2 / T of the similarity
+    matrix then sits hundreds above every kept entry, and a log-sum-exp shifted by the WHOLE row's maximum underflows to
+    log(0).  pytorch_metric_learning's lmu.logsumexp = torch.logsumexp takes its own maximum over the kept set
+    (j != i): loss and gradient stay finite, and equal the oracle's."""
+    rng = np.random.default_rng(33)
+    n, d = 24, 768
+    base = rng.standard_normal(d)
+    emb_np = (base[None, :] + 0.48 * rng.standard_normal((n, d))).astype(np.float32)        # cosine ~ 0.81 .. 0.9
+    emb_np *= (20.0 / np.linalg.norm(emb_np, axis=1, keepdims=True)).astype(np.float32) * rng.uniform(0.9, 1.1, (n, 1)).astype(np.float32)
+    labels = torch.tensor([i % 5 for i in range(n)], dtype=torch.int64)
+    g = emb_np @ emb_np.T / 0.1
+    assert (np.diag(g)[:, None] - (g - np.diag(np.diag(g))).max(1, keepdims=True)).min() > 100.0   # the regime of the finding
+    e1, e2 = torch.from_numpy(emb_np).to(DEV).requires_grad_(True), torch.from_numpy(emb_np).requires_grad_(True)
+    loss, per = train.supcon_embedding_loss(e1, labels.to(DEV), temperature=0.1)
+    ref, ref_per = O.supcon_embedding_loss(e2, labels, temperature=0.1)
+    loss.backward()
+    ref.backward()
+    assert torch.isfinite(per).all() and torch.isfinite(e1.grad).all() and float(ref.detach()) > 1.0
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-4 * abs(float(ref.detach()))
+    assert ((per.cpu() - ref_per.detach()).abs() / ref_per.detach().abs().clamp(min=1.0)).max() < 2e-4
+    assert _rel(e1.grad.cpu().numpy(), e2.grad.numpy(), floor=1e-4) < 1e-3
 
 
 def test_train_token_bound_sizes_the_buffers_and_is_checked():

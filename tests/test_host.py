@@ -209,6 +209,70 @@ def _gloo_worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (what the driver's command line looks like): the parent starts
+    two fresh rank processes before anything touches a GPU, the ranks rendezvous (gloo here, RCCL on the node), run the
+    barrier / MAX-over-ranks protocol and rank 0's ONE JSON line is the command's stdout; a failing rank fails the command.
+    MANNER_BENCH_DRY keeps the rank processes off the GPU (there is none in this container)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MANNER_BENCH_DRY="1", MANNER_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["launcher"] == "self" and j["steps"] == 3 and j["dry_run"] is True
+    assert j["impressions_all_ranks"] == 512.0 and abs(j["max_rank_time_s"] - 0.002) < 1e-12      # SUM and MAX over both ranks
+    # a rank that cannot start fails the whole command (non-zero exit), it does not hang the others
+    env["MANNER_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _mesh_worker(rank, world, port, n_news, pieces):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from manner_amd import distributed as D
+        full = torch.arange(n_news * 6, dtype=torch.float32).reshape(n_news, 6) * 0.5 + 1.0
+        g = D.MeshTableGather(n_news, 6, "cpu", pieces=pieces)
+        g.table.fill_(-7.0)
+        seen = []
+        for c in range(pieces):                              # "encode" piece c of the own shard straight into the table, then post it
+            a, b = g.piece_rows(rank, c)
+            g.local_out(c).copy_(full[a:b])
+            seen.append((a, b))
+            g.post(c)
+        lo, hi = g.shards[rank]
+        assert seen[0][0] == lo and seen[-1][1] == hi and all(x[1] == y[0] for x, y in zip(seen, seen[1:]))
+        table = g.wait()
+        assert torch.equal(table, full), (rank, (table - full).abs().max())
+        # same bytes as the single collective
+        eq = D.equal_news_shards(n_news, world)
+        assert torch.equal(D.all_gather_table(full[eq[rank][0]:eq[rank][1]].clone(), eq), table)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_news,pieces", [(2, 37, 4), (3, 41, 3), (4, 6, 4)])
+def test_mesh_table_gather_overlapped_pieces_gloo(world, n_news, pieces):
+    """the direct full-mesh exchange of the news-embedding table in pieces (each piece posted while the next
+    is being encoded) assembles exactly the table the single all-gather does — uneven last shard, pieces that are empty on
+    some ranks (6 news over 4 ranks x 4 pieces) included."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_mesh_worker, args=(world, port, n_news, pieces), nprocs=world, join=True)
+
+
 def test_two_rank_table_allgather_and_impression_sharding_gloo(tmp_path):
     import socket
     import torch.multiprocessing as mp

@@ -19,7 +19,9 @@ def _load(golden_dir, name):
 
 GOLDEN_ENC = ["enc_tiny_bert", "enc_tiny_roberta", "enc_tiny_distilbert", "enc_bert_base", "enc_bert_base_spread", "enc_roberta_base",
               # round 2: 64 news incl. lengths 2 and 96; [title, abstract] pair inputs through a real tokenizer call (Q4)
-              "enc_bert_base_64", "enc_roberta_base_64", "enc_pair_bert_base", "enc_pair_tiny_bert"]
+              "enc_bert_base_64", "enc_roberta_base_64", "enc_pair_bert_base", "enc_pair_tiny_bert",
+              # round 3: BASELINE configs[4] at its FULL architecture — roberta-large, 24 layers, H = 1024, 16 heads; lengths {2, 33, 96}
+              "enc_roberta_large"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_ENC)
