@@ -90,6 +90,7 @@ def parse():
     p.add_argument("--no-scale-parity", action="store_true", help="skip the at-scale bf16-vs-fp32 ranking comparison")
     p.add_argument("--no-small-ops", action="store_true", help="skip the pooler / dot / z-score kernel legs")
     p.add_argument("--no-train", action="store_true", help="skip the training-step leg (SURVEY §8f-3)")
+    p.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (mirror classes under the unchanged CRModule.forward at B = 8 / 64)")
     return p.parse_args()
 
 
@@ -419,6 +420,135 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
             engine.close()
         del params, opt
         torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------------------------------- drop-in leg
+def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8, 64), iters=8):
+    """What a maintainer gets from INTEGRATION.md §2 alone: the UNCHANGED `CRModule.forward` /
+    `model_step` call pattern (reference cr_module.py:105-131, 140-171) over the mirror classes — two `news_encoder` calls,
+    `to_dense_batch` of both sides, the per-row `torch.where` loop for the history sizes, mean, `DotProduct` on the permuted
+    dense candidates — at the reference's batch size (`batch_size: 8`, configs/data/mind_rec.yaml:51) and at 64.
+    eval: `model.eval()` under `torch.no_grad()` (Lightning's test loop), evaluation-shaped impressions (all candidates of an
+    impression, title + abstract tokens).  train: `model.train()`, 1 positive + 4 sampled negatives per impression
+    (neg_sampling_ratio 4, mind_rec.yaml:44), dropouts on, the SupCon loss of `model_step`, backward, AdamW.
+    `to_dense_batch` (torch_geometric, not installed on the box) is restated with the torch ops it consists of; the SupConLoss
+    (pytorch_metric_learning, not installed) is `train.model_step_loss`.  wall = per-step time with a device synchronisation at the end;
+    enqueue = time until the Python call returns (the host-side share: when it approaches wall, the step is host-bound)."""
+    import warnings
+    from manner_amd import train
+    from manner_amd.models.components.click_predictors import DotProduct
+    from manner_amd.models.components.news_encoder import MannerNewsEncoder
+    pool_ids, pool_mask, pool_len = pool
+    n_pool = pool_ids.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerNewsEncoder(plm_model=model_name, frozen_layers=list(range(8)) if cfg.layers >= 12 else [0], dropout_probability=0.2,
+                                use_entities=False, entity_embeddings=None, entity_embedding_dim=100, num_attention_heads=10,
+                                query_vector_dim=200, text_embedding_dim=cfg.hidden)
+    own = enc.state_dict()
+    enc.load_state_dict({"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in weights_np.items()
+                         if "text_encoder.plm_model." + k in own}, strict=False)
+    enc = enc.to(dev)
+    enc.text_encoder.precision = precision
+    click = DotProduct()
+
+    def to_dense_batch(x, batch, nb, width):
+        # torch_geometric.utils.to_dense_batch(x, batch) -> (dense, mask), restated with the torch ops it is made of (bincount,
+        # cumsum, index assignment): it stays third-party torch code in a real deployment and carries autograd for the train step
+        counts = torch.bincount(batch, minlength=nb)
+        cum = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        idx = torch.arange(batch.numel(), device=batch.device) - cum[batch] + batch * width
+        dense = x.new_zeros((nb * width,) + tuple(x.shape[1:]))
+        dense[idx] = x
+        mask = torch.zeros(nb * width, dtype=torch.bool, device=batch.device)
+        mask[idx] = True
+        return dense.view(nb, width, *x.shape[1:]), mask.view(nb, width)
+
+    def forward(b):                                             # cr_module.py:105-131, late_fusion=True, line by line
+        clicked = enc(b["x_hist"])
+        clicked_agg, mask_hist = to_dense_batch(clicked, b["batch_hist"], b["nb"], b["hist_max"])
+        cand = enc(b["x_cand"])
+        cand_agg, _ = to_dense_batch(cand, b["batch_cand"], b["nb"], b["cand_max"])
+        hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])], device=dev)
+        user = torch.div(clicked_agg.sum(dim=1), hist_size.unsqueeze(dim=-1))
+        return click(user.unsqueeze(dim=1), cand_agg.permute(0, 2, 1))
+
+    def make_batch(imp, lo, hi, train_mode, g):
+        ho, co = imp["hist_off"], imp["cand_off"]
+        hist = imp["hist_idx"][ho[lo]:ho[hi]].astype(np.int64)
+        hsz = np.diff(ho[lo:hi + 1])
+        if train_mode:                                          # 1 positive + 4 negatives per impression
+            cands, labels, csz = [], [], []
+            for i in range(lo, hi):
+                c = imp["cand_idx"][co[i]:co[i + 1]].astype(np.int64)
+                y = imp["labels"][co[i]:co[i + 1]]
+                pos = c[y > 0.5][:1]
+                neg = c[y <= 0.5]
+                neg = g.choice(neg, 4, replace=len(neg) < 4) if len(neg) else np.repeat(pos, 4)
+                cands.append(np.concatenate([pos, neg])); labels.append(np.array([1, 0, 0, 0, 0], np.float32)); csz.append(5)
+            cand, lab, csz = np.concatenate(cands), np.concatenate(labels), np.array(csz)
+        else:
+            cand, lab, csz = imp["cand_idx"][co[lo]:co[hi]].astype(np.int64), imp["labels"][co[lo]:co[hi]], np.diff(co[lo:hi + 1])
+
+        def side(idx):
+            lp = int(pool_len[idx].max())
+            d = torch.from_numpy(idx).to(dev)
+            return {"text": {"input_ids": pool_ids[d][:, :lp].contiguous(), "attention_mask": pool_mask[d][:, :lp].contiguous()}}
+
+        nb = hi - lo
+        seg = lambda sz: torch.repeat_interleave(torch.arange(nb), torch.from_numpy(sz)).to(dev)      # noqa: E731
+        return {"x_hist": side(hist), "x_cand": side(cand), "batch_hist": seg(hsz), "batch_cand": seg(csz), "nb": nb,
+                "hist_max": int(hsz.max()), "cand_max": int(csz.max()), "labels": torch.from_numpy(lab.astype(np.float32)).to(dev),
+                "n_cand": int(csz.sum()), "n_news": int(hsz.sum() + csz.sum())}
+
+    out = {"what": dropin_leg.__doc__.split("eval:")[0].strip(), "model": model_name, "eval_precision": precision,
+           "train_precision": enc.text_encoder.train_precision}
+    g = np.random.default_rng(3)
+    for bs in batch_sizes:
+        imp = synth_impressions(bs * (iters + 2), n_pool, seed=900 + bs)
+        for mode in ("eval", "train"):
+            batches = [make_batch(imp, k * bs, (k + 1) * bs, mode == "train", g) for k in range(iters + 2)]
+            if mode == "eval":
+                enc.eval()
+
+                def step(b):
+                    with torch.no_grad():
+                        return forward(b)
+            else:
+                enc.train()
+                opt = torch.optim.AdamW([p for p in enc.parameters() if p.requires_grad], lr=1e-5)
+
+                def step(b):
+                    scores = forward(b)                                        # dense [B, Cmax]
+                    off = hotpath.segment_offsets(b["batch_cand"], b["nb"])
+                    ragged = scores.reshape(-1)                                 # every impression has 5 candidates: dense == ragged
+                    loss, _ = train.model_step_loss(ragged, b["labels"], off, supcon=True, temperature=0.36)
+                    loss.backward()
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                    return loss
+            for b in batches[:2]:
+                step(b)
+            torch.cuda.synchronize()
+            wall, enq = [], []
+            for b in batches[2:]:
+                t0 = time.perf_counter()
+                step(b)
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                wall.append(t2 - t0); enq.append(t1 - t0)
+            w_, e_ = float(np.median(wall)), float(np.median(enq))
+            nc = float(np.mean([b["n_cand"] for b in batches[2:]]))
+            nn = float(np.mean([b["n_news"] for b in batches[2:]]))
+            out[f"B{bs}_{mode}"] = {"ms_per_step": 1e3 * w_, "enqueue_ms": 1e3 * e_, "host_share": e_ / w_, "candidates_per_s": nc / w_,
+                                    "news_encoded_per_s": nn / w_, "impressions_per_s": bs / w_, "news_per_step": nn, "candidates_per_step": nc}
+            if mode == "train":
+                del opt
+    enc.text_encoder.check_inputs() if enc.text_encoder._hip is not None else None
+    del enc
+    torch.cuda.empty_cache()
     return out
 
 
@@ -916,6 +1046,11 @@ def main():
         # bf16 GEMM operands: f32's exponent range, so the step needs no loss scaling (f16 needs the caller's GradScaler, as the
         # reference's 16-mixed Lightning plugin provides — manner_amd/models/components/news_encoder.py train_precision)
         result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("bf16", "fp32") else "bf16")
+    if rank == 0 and world == 1 and not args.no_dropin and cfg.head_dim == 64 and args.config == 1:
+        log("drop-in leg (mirror classes under the unchanged CRModule.forward, B = 8 and 64, eval + train)")
+        for e in encs:
+            e.close()
+        result["dropin"] = dropin_leg(cfg, model, weight_sets[0], (pool_ids, pool_mask, pool_len), dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

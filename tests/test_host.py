@@ -392,3 +392,37 @@ def test_distilbert_directory_loading_and_keys(tmp_path, golden_dir):
     assert frozen and all("layer.0." in n for n in frozen)                      # news_encoder.py:24-27 name test
     c = canonical_weights(cfg, w)
     assert "encoder.layer.1.attention.self.query.weight" in c and c["embeddings.token_type_embeddings.weight"].shape == (1, cfg.hidden)
+
+
+def test_training_buffer_sizes_follow_the_documented_rule():
+    """manner_hip_train_workspace_bytes / _saved_bytes (host arithmetic, no GPU) against the sizing rule written out here —
+    what each training kernel may touch (csrc/train.hip plan_work / plan_saved): a change of the rule has to be made twice."""
+    import ctypes as C
+    from manner_amd import _lib
+    from manner_amd.train import _cfg_c
+    lib = _lib.load()
+
+    def up(v):
+        return (v + 255) // 256 * 256
+
+    for preset, n, mb in (("tiny-bert", 9, 256), ("tiny-bert", 300, 7424), ("bert-base-uncased", 928, 15616), ("roberta-large", 64, 2048)):
+        cfg = PRESETS[preset]
+        h, i, heads, layers = cfg.hidden, cfg.intermediate, cfg.heads, cfg.layers
+        wide = max(i, 3 * h)
+        rows = max(mb, wide) + 64 * 64
+        work = [4 * wide * rows] * 2 + [4 * 3 * h * h, 4 * 3 * h, 4 * wide, 4 * mb * wide,                       # a16, b16, wcat, bcat, zero, tmp
+                                        4 * mb * h, 4 * mb * h, 4 * mb * wide, 4 * mb * 3 * h, 4 * mb * heads,   # dx, dr, dbig, dqkv, dsum
+                                        4 * wide * max(i, h), 4 * 2 * 512 * wide,                                # dw, part (2 x LN_BWD_BLOCKS rows)
+                                        2 * mb * h, 2 * mb * h, 2 * mb * wide,                                   # h16a, h16b, big16
+                                        4 * (1024 * 65536 + wide * max(i, h)), 4 * 16]                           # dwp, dims
+        want_w = 0
+        for b in work:
+            want_w = up(want_w) + b
+        assert int(lib.manner_hip_train_workspace_bytes(C.byref(_cfg_c(cfg)), mb)) == want_w + 256, preset
+        per_layer = [4 * mb * h, 4 * mb * 3 * h, 4 * mb * h, 4 * mb * h, 4 * mb * h, 4 * mb * i, 4 * mb * i, 4 * mb * h,   # x_in qkv ctx r1 h1 inter g r2
+                     8 * mb, 8 * mb, 8 * mb * heads]                                                                         # st1 st2 ml
+        parts = [4 * n, 4 * (n + 1), 16, 4 * mb * h, 8 * mb] + per_layer * layers                                          # lens cu m_total esum st0
+        want_s = 0
+        for b in parts:
+            want_s = up(want_s) + b
+        assert int(lib.manner_hip_train_saved_bytes(C.byref(_cfg_c(cfg)), n, mb, 0)) == want_s + 256, preset

@@ -19,7 +19,24 @@ torch.set_num_threads(8)
 cfg = PRESETS['bert-base-uncased']
 def rnd(t, dt):
     return t if dt is None else t.to(dt).float()
-def enc(ids, mask, w, op_dt, res_dt, act_dt):
+E4M3_MAX = 448.0
+def q_e4m3(t, mode):
+    """Round-trip through e4m3 (torch.float8_e4m3fn, the OCP format of v_mfma_*_f8f6f4): 'tensor' = one f32 scale for the
+    whole tensor (amax -> 448), 'row' = one scale per row (per token / per output channel: folds into the GEMM epilogue),
+    'block32' = one power-of-two (E8M0) scale per 32 consecutive K elements, the MX block format of
+    v_mfma_scale_f32_16x16x128_f8f6f4."""
+    if mode == 'tensor':
+        s = t.abs().max().clamp(min=1e-30) / E4M3_MAX
+    elif mode == 'row':
+        s = t.abs().amax(-1, keepdim=True).clamp(min=1e-30) / E4M3_MAX
+    else:
+        k = t.shape[-1]
+        b = t.reshape(*t.shape[:-1], k // 32, 32)
+        s = torch.exp2(torch.ceil(torch.log2(b.abs().amax(-1, keepdim=True).clamp(min=1e-30) / E4M3_MAX)))
+        return ((b / s).to(torch.float8_e4m3fn).float() * s).reshape(t.shape)
+    return (t / s).to(torch.float8_e4m3fn).float() * s
+def enc(ids, mask, w, op_dt, res_dt, act_dt, fp8=None, fp8_mode='tensor'):
+    # fp8: None | 'ffn2' (only output.dense: K = I) | 'ffn' (both FFN GEMMs) | 'all' (all four GEMMs) take e4m3 operands
     # op_dt: GEMM operand dtype; res_dt: residual stream storage; act_dt: stored activations qkv/ctx/ffn
     ids, mask = torch.from_numpy(ids).long(), torch.from_numpy(mask)
     w = {k: torch.as_tensor(v) for k, v in w.items()}
@@ -30,6 +47,9 @@ def enc(ids, mask, w, op_dt, res_dt, act_dt):
     for l in range(cfg.layers):
         p = f"encoder.layer.{l}."
         def lin(t, name):
+            use8 = fp8 == 'all' or (fp8 == 'ffn' and name in ("intermediate.dense", "output.dense")) or (fp8 == 'ffn2' and name == "output.dense")
+            if use8:
+                return F.linear(q_e4m3(rnd(t, op_dt), fp8_mode), q_e4m3(w[p+name+".weight"], 'row' if fp8_mode == 'tensor' else fp8_mode), w[p+name+".bias"])
             return F.linear(rnd(t, op_dt), rnd(w[p+name+".weight"], op_dt), w[p+name+".bias"])
         q = rnd(lin(x, "attention.self.query"), act_dt).view(n, s, a, d).transpose(1, 2)
         k = rnd(lin(x, "attention.self.key"), act_dt).view(n, s, a, d).transpose(1, 2)
@@ -40,6 +60,8 @@ def enc(ids, mask, w, op_dt, res_dt, act_dt):
         inter = rnd(F.gelu(lin(x, "intermediate.dense")), act_dt)
         x = rnd(F.layer_norm(lin(inter, "output.dense") + x, (h,), w[p+"output.LayerNorm.weight"], w[p+"output.LayerNorm.bias"], cfg.ln_eps), res_dt)
     return x[:, 0].contiguous()
+FP8 = "fp8" in sys.argv[1:]
+sys.argv = [a for a in sys.argv if a != "fp8"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ids, mask = synth_news_tokens(N, cfg, seed=42, max_len=96, profile='title')
 imp = synth_impressions(128, N, seed=5)
@@ -50,6 +72,29 @@ def scores(tab):
         c = tab[imp['cand_idx'][imp['cand_off'][i]:imp['cand_off'][i+1]].astype(np.int64)]
         out.append(c @ h)
     return out
+def ndcg10(s_list):
+    flat = torch.cat(s_list)
+    return O.ndcg_at_k(flat, torch.from_numpy(imp['labels']), imp['cand_off'].tolist(), 10)[0]
+if FP8:
+    # e4m3 operands, measured.  f16 everywhere else (the headline arithmetic); per-tensor activation scale +
+    # per-output-channel weight scale ("tensor"), per-row activation scale ("row"), MX block scales ("block32").
+    for std in (0.02, 0.05):
+        w = make_plm_weights(cfg, seed=42, std=std)
+        with torch.no_grad():
+            ref = enc(ids, mask, w, None, None, None)
+            sref = scores(ref)
+            nref = ndcg10(sref)
+            legs = [("f16 all (headline arithmetic)", None, 'tensor')] + [(f"f16 + e4m3 {which} [{mode}]", which, mode)
+                                                                          for which in ("ffn2", "ffn", "all") for mode in ("tensor", "row", "block32")]
+            for name, which, mode in legs:
+                t = enc(ids, mask, w, torch.float16, torch.float16, torch.float16, fp8=which, fp8_mode=mode)
+                s = scores(t)
+                agree = np.mean([torch.equal(torch.argsort(x, descending=True, stable=True)[:10], torch.argsort(y, descending=True, stable=True)[:10]) for x, y in zip(s, sref)])
+                top1 = np.mean([int(torch.argmax(x)) == int(torch.argmax(y)) for x, y in zip(s, sref)])
+                serr = max(float((x-y).abs().max()) for x, y in zip(s, sref))
+                print(f"std {std} {name:36s} emb max err {float((t-ref).abs().max()):.3e}  score err {serr:.3e} (scale {float(sref[0].abs().max()):.0f}) "
+                      f"top10 identical {agree:.3f} top1 {top1:.3f}  |dnDCG@10| {abs(ndcg10(s) - nref):.2e}", flush=True)
+    sys.exit(0)
 for std in (0.02, 0.05):
     w = make_plm_weights(cfg, seed=42, std=std)
     with torch.no_grad():
