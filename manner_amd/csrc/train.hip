@@ -17,41 +17,12 @@
 // backward pass runs through the frozen layers into the embedding tables — or to `start_layer` when the caller
 // supplies cached hidden states of a frozen prefix).
 #include <math.h>
+#include <stdlib.h>
 
-#include "common.h"
+#include "train_common.h"
 
 namespace manner {
 namespace {
-
-// ------------------------------------------------------------------------------------------------ dropout bits
-// splitmix64 over (seed, site, index): 32 uniform bits; an element is KEPT when bits >= thr, thr = p * 2^32.
-__host__ __device__ __forceinline__ uint32_t drop_bits(uint64_t seed, uint32_t site, uint64_t idx) {
-  uint64_t z = (seed ^ ((uint64_t)site * 0xD6E8FEB86659FD93ull)) + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
-}
-struct Drop {
-  uint64_t seed;
-  uint32_t site, thr;
-  float scale;          // 1 / (1 - p)
-  __host__ __device__ __forceinline__ float apply(float v, uint64_t idx) const {
-    return (thr == 0 || drop_bits(seed, site, idx) >= thr) ? v * scale : 0.f;
-  }
-};
-Drop make_drop(uint64_t seed, uint32_t site, float p) {
-  Drop d;
-  d.seed = seed;
-  d.site = site;
-  const double t = (double)p * 4294967296.0;
-  d.thr = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
-  d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
-  return d;
-}
-// dropout sites of a layer (site = 8 * (layer + 1) + k; site 0..7 belong to the embeddings / the [CLS] output)
-enum { SITE_EMB = 0, SITE_CLS = 1, SITE_ATTN = 0, SITE_PROJ = 1, SITE_FFN = 2 };
-__host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (uint32_t)(layer + 1) + (uint32_t)k; }
 
 // optional 16-bit copy of an activation for the next GEMM (saves that GEMM's separate f32 -> 16-bit pass)
 struct Out16 {
@@ -921,6 +892,12 @@ struct Ctx {
   const float* lw(int l, int i) const { return w[MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + i]; }
   DType dt() const { return prec == MANNER_HIP_PREC_F32 ? DT_F32 : prec == MANNER_HIP_PREC_F16 ? DT_F16 : DT_BF16; }
   Out16 o16(void* p) const { return (p && dt() != DT_F32) ? Out16{p, (int)dt()} : Out16{nullptr, 0}; }
+  // 16-bit modes: Q | K | V are kept in the 16-bit type (the f32 slot of the saved buffer, half used) and the attention runs on the
+  // matrix pipe (train_attn.hip).  MANNER_HIP_TRAIN_ATTN_VALU=1 keeps the f32 VALU kernels for A/B; the fp32 mode always uses them.
+  bool mfma_attn() const {
+    static const bool valu = getenv("MANNER_HIP_TRAIN_ATTN_VALU") != nullptr;
+    return dt() != DT_F32 && !valu;
+  }
   unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
 };
 
@@ -1086,9 +1063,21 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   hipStream_t s = t.s;
   const bool mixed = t.dt() != DT_F32;
   if ((rc = pack_qkv_weights(t, l))) return rc;
-  if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H, mixed && x_in_has_16 ? t.wk.h16a : nullptr))) return rc;
-  {
-    const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+  const Drop da_m = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+  if (t.mfma_attn() && !klen) {
+    // Q | K | V straight in the 16-bit type (one rounding, at the GEMM's output — what the MFMA attention reads), then the
+    // matrix-pipe attention: ctx f32 + its 16-bit copy + {row max, row sum}
+    const void* x16 = t.wk.h16a;
+    if (!x_in_has_16) {
+      if ((rc = convert_f32_to_16(t.dt(), x_in, t.wk.a16, t.Mb * H, s))) return rc;
+      x16 = t.wk.a16;
+    }
+    if ((rc = convert_f32_to_16(t.dt(), t.wk.wcat, t.wk.b16, (int64_t)3 * H * H, s))) return rc;
+    if ((rc = gemm_tn(t.dt(), t.dt(), EPI_BIAS, x16, t.wk.b16, t.wk.bcat, nullptr, L.qkv, t.Mb, 3 * H, H, t.sv.m_total, s))) return rc;
+    if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, L.ctx, t.wk.h16b, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc;
+  } else {
+    if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H, mixed && x_in_has_16 ? t.wk.h16a : nullptr))) return rc;
+    const Drop da = da_m;
 #define MANNER_ATTN_FWD(AT_, HPB_)                                                                                             \
   hipLaunchKernelGGL((attn_train_fwd_kernel<AT_, HPB_>), dim3((unsigned)(cfg->heads / HPB_), (unsigned)t.N), dim3(AT_), 0, s, L.qkv, \
                      L.ctx, L.ml, cu, cfg->heads, H, da, klen, t.o16(t.wk.h16b))
@@ -1386,6 +1375,12 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
       return rc;
     }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+    if (t.mfma_attn()) {
+      // matrix-pipe backward: D = dctx . ctx and the 16-bit copy of dctx (wk.h16a is free in the backward), then d q and d k / d v
+      if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.big16, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
+                                         (int)padded_len, da, m_bound, sv.m_total, s)))
+        return rc;
+    } else {
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
     const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
@@ -1395,6 +1390,7 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);
 #undef MANNER_ATTN_BWD
     MANNER_LAUNCH_CHECK();
+    }
     if (qkv_w) {
       if ((rc = bias_grad(t, wk.dqkv, 3 * H, wk.dw))) return rc;
       for (int k = 0; k < 3; ++k)

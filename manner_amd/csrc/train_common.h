@@ -1,0 +1,50 @@
+// Shared pieces of the training path (train.hip, train_attn.hip): the counter-based dropout generator.  Not part of the ABI.
+#pragma once
+#include "common.h"
+
+namespace manner {
+
+// ---- dropout bits
+// splitmix64 over (seed, site, index): 32 uniform bits; an element is KEPT when bits >= thr, thr = p * 2^32.
+__host__ __device__ __forceinline__ uint32_t drop_bits(uint64_t seed, uint32_t site, uint64_t idx) {
+  uint64_t z = (seed ^ ((uint64_t)site * 0xD6E8FEB86659FD93ull)) + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+struct Drop {
+  uint64_t seed;
+  uint32_t site, thr;
+  float scale;          // 1 / (1 - p)
+  __host__ __device__ __forceinline__ float apply(float v, uint64_t idx) const {
+    return (thr == 0 || drop_bits(seed, site, idx) >= thr) ? v * scale : 0.f;
+  }
+};
+static inline Drop make_drop(uint64_t seed, uint32_t site, float p) {
+  Drop d;
+  d.seed = seed;
+  d.site = site;
+  const double t = (double)p * 4294967296.0;
+  d.thr = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
+  d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
+  return d;
+}
+// dropout sites of a layer (site = 8 * (layer + 1) + k; site 0..7 belong to the embeddings / the [CLS] output)
+enum { SITE_EMB = 0, SITE_CLS = 1, SITE_ATTN = 0, SITE_PROJ = 1, SITE_FFN = 2 };
+__host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (uint32_t)(layer + 1) + (uint32_t)k; }
+
+
+// Training attention on the matrix pipe (train_attn.hip; 16-bit modes): S <= 128 keys per news, head_dim 64, one wave per
+// (news, head).  qkv16 [m, 3H] = [Q | K | V] of the 16-bit type `dt`.
+//   forward : ctx [m, H] f32 (+ its 16-bit copy ctx16, may be NULL) = dropout(softmax(q k^T / 8)) v;  ml[m, heads] = {row max of the
+//             RAW scores q.k, sum of exp((s - max) / 8)} so that the backward rebuilds P without a reduction pass.
+//   backward: dsum[m, heads] = dctx . ctx per head and dctx16 (scratch [m_bound, H] of `dt`) first, then d qkv [m, 3H] f32 and its
+//             16-bit copy dqkv16 (may be NULL).  Dropout bits: element ((row * heads + head) * 256 + key) of `drop`'s stream.
+int attn_train_mfma_forward(DType dt, const void* qkv16, float* ctx, void* ctx16, float2* ml, const int32_t* cu, int64_t n_news,
+                            int heads, int H, int max_len, Drop drop, hipStream_t stream);
+int attn_train_mfma_backward(DType dt, const void* qkv16, const float* dctx, const float* ctx, const float2* ml, float* dqkv,
+                             void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H, int max_len,
+                             Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream);
+
+}  // namespace manner

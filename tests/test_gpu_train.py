@@ -346,6 +346,40 @@ def test_train_attention_geometries(max_len):
         assert _rel(g[k], v.grad.numpy()) < 2e-3, (k, _rel(g[k], v.grad.numpy()))
 
 
+@pytest.mark.parametrize("precision,out_tol,cos_tol", [("f16", 2e-2, 0.999), ("bf16", 1e-1, 0.99)])
+@pytest.mark.parametrize("max_len", [5, 17, 32, 33, 64, 65, 96, 97, 128])
+def test_train_mfma_attention_geometries(max_len, precision, out_tol, cos_tol):
+    """The matrix-pipe training attention of the 16-bit modes (csrc/train_attn.hip: forward, backward-q, backward-kv) at every
+    key-tile count and its boundaries, DROPOUT ON with the masks replayed into the oracle: a wrong (query, key) -> dropout-bit
+    mapping in any of the three accumulator layouts, a wrong transposed read or a wrong row statistic would change values at
+    O(1), far outside the 16-bit rounding these tolerances allow.  Two heads, lengths 2 .. max_len."""
+    from manner_amd.config import EncoderConfig
+    cfg = EncoderConfig(hidden=128, layers=2, heads=2, intermediate=128, vocab=512, max_pos=256)
+    w = make_plm_weights(cfg, seed=66, std=0.05, with_pooler=False)
+    lengths = np.maximum(2, np.minimum(np.array([2, max_len // 3, max_len - 1, max_len, 33, max_len // 2 + 1, 31]), max_len))
+    ids_np, mask_np = synth_news_tokens(len(lengths), cfg, seed=66, max_len=max_len, lengths=lengths)
+    R = torch.from_numpy(np.random.default_rng(4).standard_normal((len(lengths), cfg.hidden)).astype(np.float32))
+    seed, ph, pa, po = 78, 0.1, 0.25, 0.2
+    params = _params(w)
+    out = train.encode_train(cfg, params, torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV), precision=precision,
+                             p_hidden=ph, p_attn=pa, p_out=po, seed=seed)
+    (out * R.to(DEV)).sum().backward()
+    hip.check_status(DEV)
+    wt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    ref = O.encode_cls_train(ids_np, mask_np, wt, cfg, p_hidden=ph, p_attn=pa, p_out=po, keep=_replay_keep(seed, ph, pa, po, cfg, mask_np))
+    (ref * R).sum().backward()
+    err = float((out.detach().cpu() - ref.detach()).abs().max())
+    assert err < out_tol, err
+    g = _grads(params)
+    for k, v in wt.items():
+        a, b = g[k].ravel().astype(np.float64), v.grad.numpy().ravel().astype(np.float64)
+        if np.abs(b).max() < 1e-5:                     # the key-bias gradient is analytically zero: rounding noise has no direction
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > cos_tol, (k, cos)
+        assert _rel(g[k], v.grad.numpy()) < (0.05 if precision == "f16" else 0.25), (k, _rel(g[k], v.grad.numpy()))
+
+
 # ---------------------------------------------------------------------------------------------- small operators (train_small.hip)
 def _check_grads(hip_fn, ref_fn, tensors, tol=2e-4):
     """Run hip_fn on GPU copies and ref_fn (plain torch on CPU) on CPU copies of `tensors` (all requiring grad), backward through a fixed
