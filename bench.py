@@ -648,6 +648,18 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     n_c = int(sc_r.numel())
     # the fused scorer alone on the first table, by HIP events (the score_s above also holds fusion + ranking)
     scorer_ms = timed_ms(lambda: hip.score_late_fusion(tables[0], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
+    # the same scorer over the IEEE-half copy of the table (manner_hip_score_late_fusion_f16): half the bytes per gathered row and,
+    # at the MIND-large shape, a table that fits the 256 MiB Infinity Cache; its scores against the f32-table scores
+    t16 = hip.table_to_f16(tables[0])
+    conv_ms = timed_ms(lambda: hip.table_to_f16(tables[0], out=t16))
+    scorer16_ms = timed_ms(lambda: hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
+    s32_one = hip.score_late_fusion(tables[0], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+    s16_one = hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+    f16_table = {"scorer_kernel_ms_rank0": scorer16_ms, "table_MB": n_news * cfg.hidden * 2 / 1e6, "convert_ms": conv_ms,
+                 "speedup_vs_f32_table": scorer_ms / scorer16_ms,
+                 "vs_f32_table_scores": ranking_agreement(s16_one, s32_one, labels, off_r),
+                 "what": "module 0's table as IEEE half (rows rounded to 11 bits; f32 accumulation): for tables the 16-bit encoder modes produced"}
+    del t16, s32_one, s16_one
     metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
                   "auc": timed_ms(lambda: hip.auc(sc_r.nan_to_num(0.0), labels)),
                   "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
@@ -670,7 +682,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
            "scorer_kernel_ms_rank0": scorer_ms, "scorer_algorithmic_bytes_rank0": scorer_bytes,
            "scorer_GBps_algorithmic": scorer_bytes / scorer_ms / 1e6,
            "scorer_frac_of_8TBps": scorer_bytes / scorer_ms / 1e6 / HBM_PEAK_GBS,
-           "table_MB": table_bytes / 1e6,
+           "table_MB": table_bytes / 1e6, "scorer_f16_table": f16_table,
            "scorer_note": ("occurrence bytes: every history/candidate row read counts once; rows repeat (Zipf), so a table "
                            "that fits the 256 MiB Infinity Cache is served from cache and this is a cache hit rate, not an "
                            "HBM fraction — see profiles/ for the FETCH_SIZE pass" if table_bytes < 256 * 2 ** 20 else

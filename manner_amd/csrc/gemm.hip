@@ -619,6 +619,8 @@ struct DlnAux {
                           // a wave's 16 rows per store instruction are one contiguous 128-byte line)
   int64_t part_stride;    // m_bound
   int col_group;          // column tiles per pass over the rows (0 = all): see the tile order in the kernel
+  int plain_stores;       // A/B (MANNER_HIP_NT_STORES=0): the streaming Q|K|V / FFN outputs with default-policy instead of
+                          // non-temporal stores, so that a small chunk's intermediates may stay in the 256 MiB Infinity Cache
   // EPI_BIAS only: gridDim.y independent problems of the same shape (problem y reads X + y * batch_x, W + y * batch_w
   // and writes Y + y * batch_y, elements) — the split-K slices of the training path's weight-gradient GEMMs
   int64_t batch_x, batch_w, batch_y;
@@ -1038,7 +1040,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
           // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
           // that they do not push the weight tiles, re-read by every row panel, out of the XCD's 4 MB L2
-          if (NORM && ABL != 5) __builtin_nontemporal_store(raw, dst);
+          if (NORM && ABL != 5 && !dln.plain_stores) __builtin_nontemporal_store(raw, dst);
           else *dst = raw;
         }
       }
@@ -1182,7 +1184,8 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
   dim3 g((unsigned)(tiles < cus ? tiles : cus));
-  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group};
+  static const bool plain_stores = getenv("MANNER_HIP_NT_STORES") && atoi(getenv("MANNER_HIP_NT_STORES")) == 0;   // A/B switch
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
   if (dt == DT_F16) return launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
   return launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
 }

@@ -82,6 +82,55 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
   }
 }
 
+// The same scorer over an IEEE-half copy of the table (manner_hip_score_late_fusion_f16): rows are 2 D bytes, so the MIND-large
+// table (161 013 x 768) is 247 MB and stays resident in the 256 MiB Infinity Cache while the impressions stream their
+// ~50 row gathers each — with the f32 table (495 MB) the Zipf tail of the gathers re-fetches rows from HBM 15.7 times over.
+// Accumulation and the user vector stay f32; only the stored rows are rounded (2^-12 relative, below the error the 16-bit
+// encoder modes put into those rows in the first place).  D % 8 == 0.
+__global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
+    const f16_t* __restrict__ table, int64_t n_rows, int D, const int32_t* __restrict__ hist_idx,
+    const int64_t* __restrict__ hist_off, const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off,
+    float* __restrict__ out, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  const int64_t b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* user = sm + 4 * D;
+  const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
+  for (int cb = 0; cb < D; cb += 512) {
+    const int c = cb + lane * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      for (int64_t j = h0 + wave; j < h1; j += 4) {
+        const int64_t r = checked_row(hist_idx[j], n_rows, status, lane);
+        const f16x8 x = *reinterpret_cast<const f16x8*>(table + r * D + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm[wave * D + c + e] = acc[e];
+    }
+  }
+  __syncthreads();
+  const float hn = (float)(h1 - h0);
+  for (int c = threadIdx.x; c < D; c += 256)
+    user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  __syncthreads();
+  const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
+  for (int64_t j = c0 + wave; j < c1; j += 4) {
+    const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
+    const f16_t* row = table + r * D;
+    float a = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+      const f16x8 x = *reinterpret_cast<const f16x8*>(row + c);
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(user + c), u1 = *reinterpret_cast<const f32x4*>(user + c + 4);
+      a += (((float)x[0] * u0[0] + (float)x[1] * u0[1]) + ((float)x[2] * u0[2] + (float)x[3] * u0[3])) +
+           (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[j] = a;
+  }
+}
+
 // ---------------------------------------------------------------- K9 to_dense_batch
 // ragged rows x[off[b] + j] -> dense[b, j, :] for j < min(count_b, width); the other slots get fill[b] (or 0) and
 // mask 0.  One wave per output row for D >= 4 (16-byte pieces), one thread per slot for scalars (D == 1).
@@ -375,6 +424,24 @@ int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D, 
                      table, n_rows, D, hist_idx, hist_off, (const float*)nullptr, cand_idx, cand_off, out, status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
+}
+
+int manner_hip_score_late_fusion_f16(const void* table16, int64_t n_rows, int32_t D, const int32_t* hist_idx,
+                                     const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
+                                     float* out, int32_t* status, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!table16 || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: null pointer");
+  if (D <= 0 || D % 8 || D > 3072 || n_rows <= 0 || (uintptr_t)table16 % 16) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: D=%d must be a multiple of 8, <= 3072, rows 16-byte aligned", D);
+  hipLaunchKernelGGL(score_late_fusion_f16_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                     static_cast<const f16_t*>(table16), n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out, status);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int manner_hip_table_to_f16(const float* table, int64_t n_elements, void* table16, manner_hip_stream_t stream) {
+  if (n_elements == 0) return MANNER_HIP_OK;
+  if (!table || !table16 || n_elements < 0) return fail(MANNER_HIP_E_INVALID, "table_to_f16: bad argument");
+  return convert_f32_to_16(DT_F16, table, table16, n_elements, (hipStream_t)stream);
 }
 
 int manner_hip_score_user(const float* table, int64_t n_rows, int32_t D, const float* user, const int32_t* cand_idx,

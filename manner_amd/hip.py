@@ -445,8 +445,14 @@ def dot(user: Tensor, cand: Tensor) -> Tensor:
 
 def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
                       total_cand: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
-    """Ragged scores [sum c_i] of impressions given as CSR index lists into ``table`` [n, D]."""
-    table = _dev(table, torch.float32, "table").contiguous()
+    """Ragged scores [sum c_i] of impressions given as CSR index lists into ``table`` [n, D] — float32, or the float16
+    copy made by ``table_to_f16`` (half the bytes per gathered row; Infinity-Cache resident at the MIND-large shape)."""
+    if isinstance(table, torch.Tensor) and table.dtype == torch.float16:
+        table = _dev(table, torch.float16, "table").contiguous()
+        entry = _lib.load().manner_hip_score_late_fusion_f16
+    else:
+        table = _dev(table, torch.float32, "table").contiguous()
+        entry = _lib.load().manner_hip_score_late_fusion
     hist_idx, cand_idx = _dev(hist_idx, torch.int32, "hist_idx"), _dev(cand_idx, torch.int32, "cand_idx")
     hist_off, cand_off = _dev(hist_off, torch.int64, "hist_off"), _dev(cand_off, torch.int64, "cand_off")
     nb = hist_off.numel() - 1
@@ -462,9 +468,21 @@ def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_id
     hist_idx, hist_off, cand_idx, cand_off = (hist_idx.contiguous(), hist_off.contiguous(), cand_idx.contiguous(),
                                               cand_off.contiguous())
     with torch.cuda.device(table.device):
-        _lib.check(_lib.load().manner_hip_score_late_fusion(
-            _ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
-            nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
+        _lib.check(entry(_ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
+                         nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
+    return out
+
+
+def table_to_f16(table: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """IEEE-half copy of a news-embedding table for ``score_late_fusion`` (rows rounded to 11 mantissa bits)."""
+    table = _dev(table, torch.float32, "table").contiguous()
+    if out is None:
+        out = torch.empty(table.shape, dtype=torch.float16, device=table.device)
+    else:
+        _dev(out, torch.float16, "out")
+        assert out.is_contiguous() and out.shape == table.shape
+    with torch.cuda.device(table.device):
+        _lib.check(_lib.load().manner_hip_table_to_f16(_ptr(table), table.numel(), _ptr(out), _stream()))
     return out
 
 

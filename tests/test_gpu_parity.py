@@ -677,6 +677,44 @@ def test_scorer_linearity_full_size():
         assert (s1[co[i]:co[i + 1]].cpu() - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_scorer_over_the_f16_table_copy():
+    """manner_hip_score_late_fusion_f16: the fused scorer over the IEEE-half copy of the table.  On a table whose entries are
+    exactly representable in half precision it computes the f32 scorer's scores (f32 accumulation, another summation order:
+    a few ulp); on a real f32 table the only difference is the rounding of the stored rows — |d score| <= 2^-11 |score| scale,
+    stated here as 1e-3 of max |score| — and an out-of-range index still raises the status bit."""
+    n_news, d = 20000, 768
+    g = torch.Generator(device="cpu").manual_seed(1)
+    table = torch.randn((n_news, d), generator=g).to(DEV)
+    imp_np = synth_impressions(2048, n_news, seed=11)
+    imp = {k: _cuda(v) for k, v in imp_np.items() if k != "labels"}
+    t16 = hip.table_to_f16(table)
+    assert t16.dtype == torch.float16 and torch.equal(t16, table.half())
+    exact = t16.float()                                             # a table the half copy represents exactly
+    s32 = hip.score_late_fusion(exact, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    s16 = hip.score_late_fusion(t16, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    scale = float(s32.abs().max())
+    assert float((s16 - s32).abs().max()) < 2e-6 * scale
+    full = hip.score_late_fusion(table, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    err = float((s16 - full).abs().max())
+    print(f"f16 table copy: max |d score| {err:.3e} at score scale {scale:.1f}")
+    assert err < 1e-3 * scale
+    t1, _ = hip.rank_ndcg(s16, None, imp["cand_off"], 10)
+    t2, _ = hip.rank_ndcg(full, None, imp["cand_off"], 10)
+    assert float((t1 == t2).all(dim=1).float().mean()) > 0.97       # random table: candidates are far apart relative to 2^-11
+    # CPU spot check in float64 on the half table
+    tc = t16.cpu().double()
+    ho, co = imp_np["hist_off"], imp_np["cand_off"]
+    for i in range(0, 2048, 64):
+        u = tc[imp_np["hist_idx"][ho[i]:ho[i + 1]].astype(np.int64)].sum(0) / float(ho[i + 1] - ho[i])
+        ref = tc[imp_np["cand_idx"][co[i]:co[i + 1]].astype(np.int64)] @ u
+        assert float((s16[co[i]:co[i + 1]].cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    bad = imp["cand_idx"].clone()
+    bad[5] = n_news
+    hip.score_late_fusion(t16, imp["hist_idx"], imp["hist_off"], bad, imp["cand_off"])
+    with pytest.raises(RuntimeError, match="index outside"):
+        hip.check_status(DEV)
+
+
 @pytest.mark.gpu
 def test_auc_matches_oracle():
     """Global AUC (SURVEY §8f rank 1): exact integer Mann-Whitney counts, ties included, bit-equal to the oracle;

@@ -36,7 +36,17 @@ out = {"score_late_fusion": {"launches": 3, "table_MB": n_news * D * 4 / 1e6, "i
 for _ in range(3):
     sc = hip.score_late_fusion(table, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
 torch.cuda.synchronize()
-del table
+# the same impressions over the IEEE-half copy of the table (247 MB: Infinity-Cache resident)
+t16 = hip.table_to_f16(table)
+out["score_late_fusion_f16"] = {"launches": 3, "table_MB": n_news * D * 2 / 1e6, "impressions": n_imp, "row_reads": occ, "distinct_rows": uniq,
+                                "algorithmic_bytes_per_launch": occ * (D * 2 + 4) + int(imp["cand_off"][-1]) * 4,
+                                "compulsory_bytes_per_launch": uniq * D * 2 + occ * 4 + int(imp["cand_off"][-1]) * 4}
+for _ in range(3):
+    sc16 = hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+torch.cuda.synchronize()
+out["score_late_fusion_f16"]["max_abs_score_diff_vs_f32_table"] = float((sc16 - sc).abs().max())
+out["score_late_fusion_f16"]["score_abs_scale"] = float(sc.abs().max())
+del table, t16
 B, S, Q, C = 4096, 50, 200, 37
 x = torch.randn((B, S, D), device=dev, generator=g)
 W, bq, q = torch.randn((Q, D), device=dev, generator=g) * 0.05, torch.zeros(Q, device=dev), torch.randn(Q, device=dev, generator=g)
