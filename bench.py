@@ -650,15 +650,17 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     scorer_ms = timed_ms(lambda: hip.score_late_fusion(tables[0], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
     # the same scorer over the IEEE-half copy of the table (manner_hip_score_late_fusion_f16): half the bytes per gathered row and,
     # at the MIND-large shape, a table that fits the 256 MiB Infinity Cache; its scores against the f32-table scores
-    t16 = hip.table_to_f16(tables[0])
-    conv_ms = timed_ms(lambda: hip.table_to_f16(tables[0], out=t16))
-    scorer16_ms = timed_ms(lambda: hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
     s32_one = hip.score_late_fusion(tables[0], dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
-    s16_one = hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
-    f16_table = {"scorer_kernel_ms_rank0": scorer16_ms, "table_MB": n_news * cfg.hidden * 2 / 1e6, "convert_ms": conv_ms,
-                 "speedup_vs_f32_table": scorer_ms / scorer16_ms,
-                 "vs_f32_table_scores": ranking_agreement(s16_one, s32_one, labels, off_r),
-                 "what": "module 0's table as IEEE half (rows rounded to 11 bits; f32 accumulation): for tables the 16-bit encoder modes produced"}
+    f16_table = {"table_MB": n_news * cfg.hidden * 2 / 1e6,
+                 "what": "module 0's table as IEEE half (rows rounded to 11 bits; f32 accumulation) — `plain`: half(T); `centred`: half(T - column mean) "
+                         "with the scores reassembled exactly: for tables the 16-bit encoder modes produced"}
+    for name, centre in (("plain", False), ("centred", True)):
+        t16 = hip.table_to_f16(tables[0], centre=centre)
+        conv_ms = timed_ms(lambda: hip.table_to_f16(tables[0], centre=centre))
+        ms16 = timed_ms(lambda: hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"]))
+        s16_one = hip.score_late_fusion(t16, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+        f16_table[name] = {"scorer_kernel_ms_rank0": ms16, "convert_ms": conv_ms, "speedup_vs_f32_table": scorer_ms / ms16,
+                           "vs_f32_table_scores": ranking_agreement(s16_one, s32_one, labels, off_r)}
     del t16, s32_one, s16_one
     metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
                   "auc": timed_ms(lambda: hip.auc(sc_r.nan_to_num(0.0), labels)),

@@ -228,13 +228,20 @@ int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D,
 /* The same scorer (same reference lines: cr_module.py:108-131, ensemble_module.py:116-135) over an IEEE-half copy of the
  * table, table16 [n_rows, D] (D % 8 == 0): half the bytes per gathered row, and a MIND-large table (161 013 x 768 = 247 MB)
  * that stays resident in the 256 MiB Infinity Cache.  Accumulation, the user vector and the scores are f32; only the
- * stored rows are rounded (2^-12 relative).  For tables produced by the 16-bit encoder modes; the fp32 parity mode keeps
- * the f32 table.  manner_hip_table_to_f16 makes the copy (n_elements = n_rows * D). */
-int manner_hip_score_late_fusion_f16(const void* table16, int64_t n_rows, int32_t D,
+ * stored rows are rounded.  mean == NULL: table16 = half(T).  mean != NULL (f32 [D]): table16 = half(T - mean), the rows
+ * centred on the table's column mean — the tables of one encoder are nearly collinear, so the deviations are an order of
+ * magnitude smaller than the entries and the rounding error of the scores shrinks alike; the scores are reassembled
+ * exactly (<mean + u', mean + c'> = <w, mean> + <w, c'>, w = mean + u').  For tables produced by the 16-bit encoder
+ * modes; the fp32 parity mode keeps the f32 table.
+ * manner_hip_table_to_f16 makes the copy; with mean != NULL it first computes the column mean into `mean` (workspace:
+ * manner_hip_table_to_f16_workspace_bytes(D) bytes). */
+int manner_hip_score_late_fusion_f16(const void* table16, const float* mean, int64_t n_rows, int32_t D,
                                      const int32_t* hist_idx, const int64_t* hist_off,
                                      const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
                                      float* out, int32_t* status, manner_hip_stream_t stream);
-int manner_hip_table_to_f16(const float* table, int64_t n_elements, void* table16, manner_hip_stream_t stream);
+size_t manner_hip_table_to_f16_workspace_bytes(int32_t D);
+int manner_hip_table_to_f16(const float* table, int64_t n_rows, int32_t D, float* mean /*nullable*/, void* table16,
+                            void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
 
 /* Same scorer with the user vectors given: the early-fusion tail of CRModule.forward —
  * manner/models/cr_module.py:125-129 (user_vector = user_encoder(...), then the click predictor) — on ragged

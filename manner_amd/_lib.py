@@ -53,8 +53,9 @@ SIGNATURES = {
     "manner_hip_linear": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "manner_hip_dot": (C.c_int, [_P, _P, _I64, _I64, _I32, _I64, _I64, _I64, _P, _P]),
     "manner_hip_score_late_fusion": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
-    "manner_hip_score_late_fusion_f16": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
-    "manner_hip_table_to_f16": (C.c_int, [_P, _I64, _P, _P]),
+    "manner_hip_score_late_fusion_f16": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "manner_hip_table_to_f16_workspace_bytes": (_SZ, [_I32]),
+    "manner_hip_table_to_f16": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "manner_hip_score_user": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P]),
     "manner_hip_to_dense": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P]),
     "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P, _P]),

@@ -87,11 +87,16 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
 // ~50 row gathers each — with the f32 table (495 MB) the Zipf tail of the gathers re-fetches rows from HBM 15.7 times over.
 // Accumulation and the user vector stay f32; only the stored rows are rounded (2^-12 relative, below the error the 16-bit
 // encoder modes put into those rows in the first place).  D % 8 == 0.
+// `mu` != NULL: the table holds the CENTRED rows T' = T - mu (mu = column mean of T, f32 [D]).  Embedding tables of one
+// encoder are nearly collinear (|score| in the hundreds, neighbouring candidates 0.01 - 0.1 apart), so the deviations from the
+// mean row are an order of magnitude smaller than the entries and half precision rounds THEM: with w = mu + mean(T'[hist]),
+// <mu + u', mu + c'> = <w, mu> + <w, c'> exactly, i.e. one extra dot product per impression.
 __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
     const f16_t* __restrict__ table, int64_t n_rows, int D, const int32_t* __restrict__ hist_idx,
     const int64_t* __restrict__ hist_off, const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off,
-    float* __restrict__ out, int32_t* __restrict__ status) {
+    float* __restrict__ out, int32_t* __restrict__ status, const float* __restrict__ mu) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  __shared__ float cpart[4];
   const int64_t b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* user = sm + 4 * D;
@@ -112,9 +117,16 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
   }
   __syncthreads();
   const float hn = (float)(h1 - h0);
-  for (int c = threadIdx.x; c < D; c += 256)
-    user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  float cp = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float u = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+    if (mu) { const float m = mu[c]; u += m; cp = fmaf(u, m, cp); }
+    user[c] = u;
+  }
+  cp = wave_sum(cp);
+  if (lane == 0) cpart[wave] = cp;
   __syncthreads();
+  const float konst = (cpart[0] + cpart[1]) + (cpart[2] + cpart[3]);          // <w, mu> (0 without centring)
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
   for (int64_t j = c0 + wave; j < c1; j += 4) {
     const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
@@ -127,7 +139,34 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
            (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
     }
     a = wave_sum(a);
-    if (lane == 0) out[j] = a;
+    if (lane == 0) out[j] = a + konst;
+  }
+}
+
+// column means of a table [n_rows, D] (two stages, fixed order) and the centred half copy T' = half(T - mu)
+constexpr int MEAN_BLOCKS = 256;
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ t, int64_t n_rows, int D, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t r = blockIdx.y;
+  for (; r + MEAN_BLOCKS < n_rows; r += 2 * MEAN_BLOCKS) { s0 += t[r * D + c]; s1 += t[(r + MEAN_BLOCKS) * D + c]; }
+  if (r < n_rows) s0 += t[r * D + c];
+  part[(size_t)blockIdx.y * D + c] = s0 + s1;
+}
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ part, int64_t n_rows, int D, float* __restrict__ mu) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  double s = 0.0;
+  for (int b = 0; b < MEAN_BLOCKS; ++b) s += (double)part[(size_t)b * D + c];
+  mu[c] = (float)(s / (double)n_rows);
+}
+__global__ __launch_bounds__(256) void centre_f16_kernel(const float* __restrict__ t, const float* __restrict__ mu, int64_t n, int D,
+                                                         f16_t* __restrict__ out) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(t + i);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(mu + (int)(i % D));
+    *reinterpret_cast<f16x4*>(out + i) = f16x4{(f16_t)(x[0] - m[0]), (f16_t)(x[1] - m[1]), (f16_t)(x[2] - m[2]), (f16_t)(x[3] - m[3])};
   }
 }
 
@@ -426,22 +465,35 @@ int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D, 
   return MANNER_HIP_OK;
 }
 
-int manner_hip_score_late_fusion_f16(const void* table16, int64_t n_rows, int32_t D, const int32_t* hist_idx,
+int manner_hip_score_late_fusion_f16(const void* table16, const float* mean, int64_t n_rows, int32_t D, const int32_t* hist_idx,
                                      const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off, int64_t B,
                                      float* out, int32_t* status, manner_hip_stream_t stream) {
   if (B == 0) return MANNER_HIP_OK;
   if (!table16 || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: null pointer");
   if (D <= 0 || D % 8 || D > 3072 || n_rows <= 0 || (uintptr_t)table16 % 16) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: D=%d must be a multiple of 8, <= 3072, rows 16-byte aligned", D);
   hipLaunchKernelGGL(score_late_fusion_f16_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
-                     static_cast<const f16_t*>(table16), n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out, status);
+                     static_cast<const f16_t*>(table16), n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out, status, mean);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
 
-int manner_hip_table_to_f16(const float* table, int64_t n_elements, void* table16, manner_hip_stream_t stream) {
-  if (n_elements == 0) return MANNER_HIP_OK;
-  if (!table || !table16 || n_elements < 0) return fail(MANNER_HIP_E_INVALID, "table_to_f16: bad argument");
-  return convert_f32_to_16(DT_F16, table, table16, n_elements, (hipStream_t)stream);
+size_t manner_hip_table_to_f16_workspace_bytes(int32_t D) { return D > 0 ? (size_t)MEAN_BLOCKS * D * sizeof(float) + 256 : 0; }
+
+int manner_hip_table_to_f16(const float* table, int64_t n_rows, int32_t D, float* mean, void* table16, void* workspace,
+                            size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (n_rows == 0) return MANNER_HIP_OK;
+  if (!table || !table16 || n_rows < 0 || D <= 0 || D % 4) return fail(MANNER_HIP_E_INVALID, "table_to_f16: bad argument (D %% 4 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  if (!mean) return convert_f32_to_16(DT_F16, table, table16, n_rows * D, s);
+  if (!workspace || workspace_bytes < manner_hip_table_to_f16_workspace_bytes(D)) return fail(MANNER_HIP_E_WORKSPACE, "table_to_f16: workspace too small");
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(col_partial_kernel, dim3((unsigned)((D + 255) / 256), MEAN_BLOCKS), dim3(256), 0, s, table, n_rows, D, part);
+  hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, part, n_rows, D, mean);
+  const int64_t blocks = (n_rows * D / 4 + 255) / 256;
+  hipLaunchKernelGGL(centre_f16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, table, mean, n_rows * D, D,
+                     static_cast<f16_t*>(table16));
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
 }
 
 int manner_hip_score_user(const float* table, int64_t n_rows, int32_t D, const float* user, const int32_t* cand_idx,

@@ -443,16 +443,27 @@ def dot(user: Tensor, cand: Tensor) -> Tensor:
     return out
 
 
-def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
+class HalfTable:
+    """IEEE-half copy of a news-embedding table for the scorer: ``rows`` float16 [n, D] and, when centred, ``mean`` float32 [D]
+    (rows = half(T - mean)); see ``table_to_f16``."""
+
+    def __init__(self, rows: Tensor, mean: Optional[Tensor]):
+        self.rows, self.mean = rows, mean
+        self.shape, self.device = rows.shape, rows.device
+
+
+def score_late_fusion(table, hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
                       total_cand: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
     """Ragged scores [sum c_i] of impressions given as CSR index lists into ``table`` [n, D] — float32, or the float16
     copy made by ``table_to_f16`` (half the bytes per gathered row; Infinity-Cache resident at the MIND-large shape)."""
-    if isinstance(table, torch.Tensor) and table.dtype == torch.float16:
+    mean = None
+    half = isinstance(table, HalfTable) or (isinstance(table, torch.Tensor) and table.dtype == torch.float16)
+    if half:
+        if isinstance(table, HalfTable):
+            table, mean = table.rows, table.mean
         table = _dev(table, torch.float16, "table").contiguous()
-        entry = _lib.load().manner_hip_score_late_fusion_f16
     else:
         table = _dev(table, torch.float32, "table").contiguous()
-        entry = _lib.load().manner_hip_score_late_fusion
     hist_idx, cand_idx = _dev(hist_idx, torch.int32, "hist_idx"), _dev(cand_idx, torch.int32, "cand_idx")
     hist_off, cand_off = _dev(hist_off, torch.int64, "hist_off"), _dev(cand_off, torch.int64, "cand_off")
     nb = hist_off.numel() - 1
@@ -468,22 +479,39 @@ def score_late_fusion(table: Tensor, hist_idx: Tensor, hist_off: Tensor, cand_id
     hist_idx, hist_off, cand_idx, cand_off = (hist_idx.contiguous(), hist_off.contiguous(), cand_idx.contiguous(),
                                               cand_off.contiguous())
     with torch.cuda.device(table.device):
-        _lib.check(entry(_ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
-                         nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
+        if half:
+            _lib.check(_lib.load().manner_hip_score_late_fusion_f16(
+                _ptr(table), _ptr(mean), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
+                nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
+        else:
+            _lib.check(_lib.load().manner_hip_score_late_fusion(
+                _ptr(table), table.shape[0], table.shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx), _ptr(cand_off),
+                nb, _ptr(out), _ptr(device_status(table.device).word), _stream()))
     return out
 
 
-def table_to_f16(table: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """IEEE-half copy of a news-embedding table for ``score_late_fusion`` (rows rounded to 11 mantissa bits)."""
+def table_to_f16(table: Tensor, centre: bool = False, out: Optional[Tensor] = None):
+    """IEEE-half copy of a news-embedding table for ``score_late_fusion`` (rows rounded to 11 mantissa bits).
+    ``centre=False`` -> the float16 tensor half(T).  ``centre=True`` -> ``HalfTable(half(T - mean), mean)``: the rows are
+    centred on the table's column mean first, which is what keeps the rounding away from the scores when the rows are
+    nearly collinear (the usual state of one encoder's [CLS] vectors)."""
     table = _dev(table, torch.float32, "table").contiguous()
+    n, d = table.shape
     if out is None:
         out = torch.empty(table.shape, dtype=torch.float16, device=table.device)
     else:
         _dev(out, torch.float16, "out")
         assert out.is_contiguous() and out.shape == table.shape
+    lib = _lib.load()
     with torch.cuda.device(table.device):
-        _lib.check(_lib.load().manner_hip_table_to_f16(_ptr(table), table.numel(), _ptr(out), _stream()))
-    return out
+        if not centre:
+            _lib.check(lib.manner_hip_table_to_f16(_ptr(table), n, d, None, _ptr(out), None, 0, _stream()))
+            return out
+        mean = torch.empty(d, dtype=torch.float32, device=table.device)
+        need = int(lib.manner_hip_table_to_f16_workspace_bytes(d))
+        ws = torch.empty(need, dtype=torch.uint8, device=table.device)
+        _lib.check(lib.manner_hip_table_to_f16(_ptr(table), n, d, _ptr(mean), _ptr(out), _ptr(ws), need, _stream()))
+    return HalfTable(out, mean)
 
 
 def score_user(table: Tensor, user: Tensor, cand_idx: Tensor, cand_off: Tensor, total_cand: Optional[int] = None) -> Tensor:

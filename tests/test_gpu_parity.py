@@ -708,6 +708,18 @@ def test_scorer_over_the_f16_table_copy():
         u = tc[imp_np["hist_idx"][ho[i]:ho[i + 1]].astype(np.int64)].sum(0) / float(ho[i + 1] - ho[i])
         ref = tc[imp_np["cand_idx"][co[i]:co[i + 1]].astype(np.int64)] @ u
         assert float((s16[co[i]:co[i + 1]].cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    # the CENTRED half table on nearly collinear rows (the state of one encoder's [CLS] vectors: |score| ~ 800, candidates
+    # ~0.05 apart): plain half rounds entries of magnitude ~1, the centred copy rounds deviations of magnitude ~0.05
+    base = torch.randn(d, generator=g)
+    coll = (base[None, :] + 0.05 * torch.randn((n_news, d), generator=g)).to(DEV)
+    ref = hip.score_late_fusion(coll, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    plain = hip.score_late_fusion(hip.table_to_f16(coll), imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    ct = hip.table_to_f16(coll, centre=True)
+    assert float((ct.mean - coll.mean(0)).abs().max()) < 1e-5
+    centred = hip.score_late_fusion(ct, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+    e_plain, e_centred = float((plain - ref).abs().max()), float((centred - ref).abs().max())
+    print(f"collinear table: max |d score| plain half {e_plain:.3e}, centred half {e_centred:.3e} at scale {float(ref.abs().max()):.0f}")
+    assert e_centred < 0.2 * e_plain and e_centred < 1e-5 * float(ref.abs().max()) + 2e-3
     bad = imp["cand_idx"].clone()
     bad[5] = n_news
     hip.score_late_fusion(t16, imp["hist_idx"], imp["hist_off"], bad, imp["cand_off"])

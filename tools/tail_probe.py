@@ -37,7 +37,7 @@ for _ in range(3):
     sc = hip.score_late_fusion(table, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
 torch.cuda.synchronize()
 # the same impressions over the IEEE-half copy of the table (247 MB: Infinity-Cache resident)
-t16 = hip.table_to_f16(table)
+t16 = hip.table_to_f16(table, centre=True)
 out["score_late_fusion_f16"] = {"launches": 3, "table_MB": n_news * D * 2 / 1e6, "impressions": n_imp, "row_reads": occ, "distinct_rows": uniq,
                                 "algorithmic_bytes_per_launch": occ * (D * 2 + 4) + int(imp["cand_off"][-1]) * 4,
                                 "compulsory_bytes_per_launch": uniq * D * 2 + occ * 4 + int(imp["cand_off"][-1]) * 4}
