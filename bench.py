@@ -82,7 +82,9 @@ def parse():
     p.add_argument("--model", default=None, help="override the configuration's PLM architecture preset")
     p.add_argument("--std", type=float, default=0.02, help="std of the seeded PLM weight matrices")
     p.add_argument("--chunk-tokens", type=int, default=65536)
-    p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline sample")
+    p.add_argument("--cpu-impressions", type=int, default=8, help="impressions of the CPU-baseline TIMING sample (warm-up + best of 3)")
+    p.add_argument("--parity-impressions", type=int, default=64,
+                   help="impressions of the oracle parity bridge (SURVEY §8d's slice): the oracle runs them once, every HIP mode is compared")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
     p.add_argument("--no-collate", action="store_true", help="skip the device-side collate leg")
@@ -199,6 +201,17 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
         ref = cpu_reference(O, cfg, weight_sets, fuse_w, pool, imp, nb)
         times.append(time.perf_counter() - t0)
     cpu_s = min(times)
+    n_timed, c_timed, news_timed = nb, int(co[-1]), int(ho[-1] + co[-1])
+    # the parity bridge runs on a larger slice than the timing sample: the oracle once, no repeats
+    nb_par = max(nb, min(int(args.parity_impressions), imp["cand_off"].shape[0] - 1))
+    if nb_par > nb:
+        nb = nb_par
+        co, ho = imp["cand_off"][: nb + 1], imp["hist_off"][: nb + 1]
+        t0 = time.perf_counter()
+        ref = cpu_reference(O, cfg, weight_sets, fuse_w, pool, imp, nb)
+        par_s = time.perf_counter() - t0
+    else:
+        par_s = cpu_s
     labels = torch.from_numpy(imp["labels"][: co[-1]])
     ref_ndcg, _ = O.ndcg_at_k(ref, labels, co.tolist(), 10)
     ref_top = O.topk_indices(ref, co.tolist(), 10)
@@ -215,12 +228,16 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
                      "ndcg10_delta": float(abs(ndcg.double().mean().item() - ref_ndcg))}
     par["score_abs_scale"] = float(ref.abs().nan_to_num(0.0).max())
     par["impressions"] = nb
-    cpu = {"value": float(co[-1] / cpu_s), "unit": "candidates/s", "cores": cores, "kind": "port",
+    par["candidates"] = int(co[-1])
+    par["oracle_s"] = round(par_s, 1)
+    par["what"] = ("every HIP arithmetic mode against the ORACLE (CPU restatement of the reference, mode R) on the same impressions: max |score "
+                   "difference|, fraction of impressions whose top-10 index list is identical to the oracle's, |nDCG@10 difference|")
+    cpu = {"value": float(c_timed / cpu_s), "unit": "candidates/s", "cores": cores, "kind": "port",
            "cpu_model": model, "cores_how": how, "runs_s": [round(t, 2) for t in times],
-           "sample": f"oracle/manner_oracle.py mode R on the first {nb} impressions ({int(ho[-1] + co[-1])} news encodes x "
+           "sample": f"oracle/manner_oracle.py mode R on the first {n_timed} impressions ({news_timed} news encodes x "
                      f"{sum(1 for k in range(len(weight_sets)) if k == 0 or fuse_w[k - 1] != 0)} module(s)), 1-impression warm-up then best of 3 "
-                     f"({cpu_s:.1f} s), torch {torch.__version__} CPU fp32, {cores} threads; SURVEY §8d asks for a 64-impression "
-                     "slice — the cost is linear in impressions, so this slice is extrapolated, bounded to ~30 s of CPU work"}
+                     f"({cpu_s:.1f} s), torch {torch.__version__} CPU fp32, {cores} threads; the cost is linear in impressions, so the timing "
+                     f"sample is bounded to ~30 s of CPU work; the parity bridge (`parity`) runs the oracle once more on {nb} impressions"}
     return cpu, par
 
 
@@ -379,7 +396,7 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
         params = {k: torch.from_numpy(v).to(dev).requires_grad_((emb_trainable or not k.startswith("embeddings.")) and
                                                                    not any(f"layer.{l}." in k for l in frozen)) for k, v in w.items()}
         engine = None if emb_trainable else hip.HipEncoder(cfg, w, precisions=(precision,), device=dev)
-        opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-5)
+        opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-5, fused=True)   # the reference's optimiser class, its fused implementation
         step_no = [0]
 
         def enc(x):
@@ -517,7 +534,7 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
                         return forward(b)
             else:
                 enc.train()
-                opt = torch.optim.AdamW([p for p in enc.parameters() if p.requires_grad], lr=1e-5)
+                opt = torch.optim.AdamW([p for p in enc.parameters() if p.requires_grad], lr=1e-5, fused=True)
 
                 def step(b):
                     scores = forward(b)                                        # dense [B, Cmax]
@@ -1052,6 +1069,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         log("CPU baseline (oracle) + parity on the bounded sample")
         nb = max(2, args.cpu_impressions // K)
+        args.parity_impressions = max(nb, args.parity_impressions // K // (4 if cfg.layers * cfg.hidden > 12 * 768 else 1))   # bounded CPU time
         cpu, par = cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
         result["cpu_baseline"] = cpu
         result["parity"] = par

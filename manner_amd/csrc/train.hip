@@ -167,51 +167,63 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial sums of dgamma = dy * xhat and
 // dbeta = dy over the rows this block visits (deterministic second stage: reduce_partials_kernel).
 // `dy` may alias `dx`.
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 1024;
+constexpr int LN_V4 = LN_MAX / 4;                     // float4 pieces per lane: column 4 (lane + 64 i) .. + 3
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
                                                      float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
                                                      const int* __restrict__ m_total) {
-  __shared__ float red[4][64 * LN_MAX + 1];
+  __shared__ __attribute__((aligned(16))) float red[4][64 * LN_MAX + 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t M = m_total[0];
-  float ag[LN_MAX], ab[LN_MAX], gm[LN_MAX];
+  const int nv = H / 4;                               // float4 pieces per row (H % 4 == 0: check_cfg asks for H % 128 == 0)
+  f32x4 ag[LN_V4], ab[LN_V4], gm[LN_V4];
 #pragma unroll
-  for (int i = 0; i < LN_MAX; ++i) {
-    ag[i] = ab[i] = 0.f;
+  for (int i = 0; i < LN_V4; ++i) {
+    ag[i] = ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int c = lane + 64 * i;
-    gm[i] = c < H ? gamma[c] : 0.f;
+    gm[i] = c < nv ? reinterpret_cast<const f32x4*>(gamma)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < M; m += (int64_t)gridDim.x * 4) {
     const float2 st = stats[m];
-    const float* xr = x + (size_t)m * H;
-    const float* gr = dy + (size_t)m * H;
-    float xh[LN_MAX], g[LN_MAX];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)m * H);
+    const f32x4* gr = reinterpret_cast<const f32x4*>(dy + (size_t)m * H);
+    f32x4 xh[LN_V4], g[LN_V4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX; ++i) {
+    for (int i = 0; i < LN_V4; ++i) {
       const int c = lane + 64 * i;
-      const float d = c < H ? gr[c] : 0.f;
-      xh[i] = c < H ? (xr[c] - st.x) * st.y : 0.f;
-      g[i] = d * gm[i];
-      ag[i] = fmaf(d, xh[i], ag[i]);
-      ab[i] += d;
-      s1 += g[i];
-      s2 = fmaf(g[i], xh[i], s2);
+      const bool ok = c < nv;
+      const f32x4 d = ok ? gr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 xv = ok ? xr[c] : f32x4{st.x, st.x, st.x, st.x};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[i][e] = (xv[e] - st.x) * st.y;
+        g[i][e] = d[e] * gm[i][e];
+        ag[i][e] = fmaf(d[e], xh[i][e], ag[i][e]);
+        ab[i][e] += d[e];
+        s1 += g[i][e];
+        s2 = fmaf(g[i][e], xh[i][e], s2);
+      }
     }
     const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
-    float* out = dx + (size_t)m * H;
+    f32x4* out = reinterpret_cast<f32x4*>(dx + (size_t)m * H);
 #pragma unroll
-    for (int i = 0; i < LN_MAX; ++i) {
+    for (int i = 0; i < LN_V4; ++i) {
       const int c = lane + 64 * i;
-      if (c < H) out[c] = st.y * (g[i] - c1 - xh[i] * c2);
+      if (c < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = st.y * (g[i][e] - c1 - xh[i][e] * c2);
+        out[c] = o;
+      }
     }
   }
   if (!pgamma) return;
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < LN_MAX; ++i) red[wave][lane + 64 * i] = pass ? ab[i] : ag[i];
+    for (int i = 0; i < LN_V4; ++i) *reinterpret_cast<f32x4*>(&red[wave][4 * (lane + 64 * i)]) = pass ? ab[i] : ag[i];
     __syncthreads();
     float* dst = (pass ? pbeta : pgamma) + (size_t)blockIdx.x * H;
     for (int c = threadIdx.x; c < H; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
@@ -1018,12 +1030,38 @@ int add_rows(Ctx& t, const float* a, const float* b, float* out, int width) {
   return MANNER_HIP_OK;
 }
 
-int pack_qkv_weights(Ctx& t, int l) {
-  const size_t H = t.c->hidden;
-  for (int k = 0; k < 3; ++k) {
-    MANNER_HIP_TRY(hipMemcpyAsync(t.wk.wcat + k * H * H, t.lw(l, MANNER_HIP_WL_Q_W + 2 * k), H * H * sizeof(float), hipMemcpyDeviceToDevice, t.s));
-    MANNER_HIP_TRY(hipMemcpyAsync(t.wk.bcat + k * H, t.lw(l, MANNER_HIP_WL_Q_B + 2 * k), H * sizeof(float), hipMemcpyDeviceToDevice, t.s));
+// [Wq; Wk; Wv] -> wcat [3H, H] f32 (+ its 16-bit copy when w16 != NULL), [bq; bk; bv] -> bcat: ONE launch (it was six
+// 5 us copies + a conversion pass per layer and call)
+template <typename TE>
+__global__ __launch_bounds__(256) void pack3_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                                    const float* __restrict__ bq, const float* __restrict__ bk, const float* __restrict__ bv,
+                                                    int H, float* __restrict__ wcat, float* __restrict__ bcat, TE* __restrict__ w16) {
+  const int64_t per = (int64_t)H * H / 4;                    // float4 pieces per matrix
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 3 * per; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i / per);
+    const int64_t j = i - k * per;
+    const f32x4 v = reinterpret_cast<const f32x4*>(k == 0 ? wq : k == 1 ? wk : wv)[j];
+    reinterpret_cast<f32x4*>(wcat)[i] = v;
+    if (w16) {
+      typedef TE v4 __attribute__((ext_vector_type(4)));
+      reinterpret_cast<v4*>(w16)[i] = v4{(TE)v[0], (TE)v[1], (TE)v[2], (TE)v[3]};
+    }
   }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < 3 * H; c += 256) bcat[c] = c < H ? bq[c] : c < 2 * H ? bk[c - H] : bv[c - 2 * H];
+}
+int pack_qkv_weights(Ctx& t, int l, void* w16 = nullptr) {
+  const int H = t.c->hidden;
+  const int64_t pieces = 3 * (int64_t)H * H / 4;
+  const dim3 g((unsigned)((pieces + 255) / 256 < 2048 ? (pieces + 255) / 256 : 2048)), b(256);
+  const float *wq = t.lw(l, MANNER_HIP_WL_Q_W), *wk = t.lw(l, MANNER_HIP_WL_K_W), *wv = t.lw(l, MANNER_HIP_WL_V_W);
+  const float *bq = t.lw(l, MANNER_HIP_WL_Q_B), *bk = t.lw(l, MANNER_HIP_WL_K_B), *bv = t.lw(l, MANNER_HIP_WL_V_B);
+  if (w16 && t.dt() == DT_F16)
+    hipLaunchKernelGGL(pack3_kernel<f16_t>, g, b, 0, t.s, wq, wk, wv, bq, bk, bv, H, t.wk.wcat, t.wk.bcat, static_cast<f16_t*>(w16));
+  else
+    hipLaunchKernelGGL(pack3_kernel<bf16_t>, g, b, 0, t.s, wq, wk, wv, bq, bk, bv, H, t.wk.wcat, t.wk.bcat,
+                       (w16 && t.dt() == DT_BF16) ? static_cast<bf16_t*>(w16) : static_cast<bf16_t*>(nullptr));
+  MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
 
@@ -1062,9 +1100,10 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   const int H = cfg->hidden, I = cfg->intermediate;
   hipStream_t s = t.s;
   const bool mixed = t.dt() != DT_F32;
-  if ((rc = pack_qkv_weights(t, l))) return rc;
+  const bool mfma = t.mfma_attn() && !klen;
+  if ((rc = pack_qkv_weights(t, l, mfma ? t.wk.b16 : nullptr))) return rc;
   const Drop da_m = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-  if (t.mfma_attn() && !klen) {
+  if (mfma) {
     // Q | K | V straight in the 16-bit type (one rounding, at the GEMM's output — what the MFMA attention reads), then the
     // matrix-pipe attention: ctx f32 + its 16-bit copy + {row max, row sum}
     const void* x16 = t.wk.h16a;
@@ -1072,7 +1111,6 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
       if ((rc = convert_f32_to_16(t.dt(), x_in, t.wk.a16, t.Mb * H, s))) return rc;
       x16 = t.wk.a16;
     }
-    if ((rc = convert_f32_to_16(t.dt(), t.wk.wcat, t.wk.b16, (int64_t)3 * H * H, s))) return rc;
     if ((rc = gemm_tn(t.dt(), t.dt(), EPI_BIAS, x16, t.wk.b16, t.wk.bcat, nullptr, L.qkv, t.Mb, 3 * H, H, t.sv.m_total, s))) return rc;
     if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, L.ctx, t.wk.h16b, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc;
   } else {

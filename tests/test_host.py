@@ -412,7 +412,7 @@ def test_training_buffer_sizes_follow_the_documented_rule():
         rows = max(mb, wide) + 64 * 64
         work = [4 * wide * rows] * 2 + [4 * 3 * h * h, 4 * 3 * h, 4 * wide, 4 * mb * wide,                       # a16, b16, wcat, bcat, zero, tmp
                                         4 * mb * h, 4 * mb * h, 4 * mb * wide, 4 * mb * 3 * h, 4 * mb * heads,   # dx, dr, dbig, dqkv, dsum
-                                        4 * wide * max(i, h), 4 * 2 * 512 * wide,                                # dw, part (2 x LN_BWD_BLOCKS rows)
+                                        4 * wide * max(i, h), 4 * 2 * 1024 * wide,                               # dw, part (2 x LN_BWD_BLOCKS rows)
                                         2 * mb * h, 2 * mb * h, 2 * mb * wide,                                   # h16a, h16b, big16
                                         4 * (1024 * 65536 + wide * max(i, h)), 4 * 16]                           # dwp, dims
         want_w = 0
