@@ -430,7 +430,7 @@ int manner_hip_supcon_embeddings(const float* emb, const int64_t* labels, int64_
 /* The small operators of the training step (train_small.hip; f32): what autograd needs below and beside the text encoder
  * for the reference's default `use_entities: True` (configs/model/cr_module.yaml:13) and for early fusion —
  *  - manner_hip_linear_backward: nn.Linear (news_encoder.py:110-113 `linear` on cat[text, entity]; the projections of
- *    nn.MultiheadAttention; AdditiveAttention.linear): y = x W^T + b, x [R, K], W [O, K] (O <= 2000); any of grad_x / grad_w /
+ *    nn.MultiheadAttention; AdditiveAttention.linear): y = x W^T + b, x [R, K], W [O, K]; any of grad_x / grad_w /
  *    grad_b may be NULL; add_to_dx (nullable) [R, K] is added into grad_x;
  *  - manner_hip_additive_pool_backward: AdditiveAttention.forward (attention.py:21-27) — grad_x [B, S, D], grad_w [Q, D],
  *    grad_b [Q], grad_q [Q] from grad_out [B, D]; workspace manner_hip_additive_pool_backward_workspace_bytes;

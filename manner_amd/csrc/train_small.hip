@@ -33,25 +33,36 @@ __global__ __launch_bounds__(256) void dropout_flat_kernel(const float* x, float
 // ---------------------------------------------------------------- nn.Linear backward: y = x W^T + b, x [R, K], W [O, K]
 constexpr int LB_ROWS = 8;
 // dx[r, k] = sum_o dy[r, o] W[o, k]  (+ add[r, k] when `add` != NULL)
+constexpr int LB_OC = 2048;                          // output features staged per pass (8 rows x 2048 floats = 64 KiB of LDS)
 __global__ __launch_bounds__(256) void lin_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int64_t R, int K,
                                                         int O, const float* __restrict__ add, float* __restrict__ dx) {
-  extern __shared__ float ds[];                      // [LB_ROWS][O]
+  extern __shared__ float ds[];                      // [LB_ROWS][min(O, LB_OC)]
   const int64_t r0 = (int64_t)blockIdx.x * LB_ROWS;
   const int nr = (int)min((int64_t)LB_ROWS, R - r0);
-  for (int i = threadIdx.x; i < nr * O; i += 256) ds[i] = dy[r0 * O + i];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) {
+  const int oc = O < LB_OC ? O : LB_OC;
+  // (K <= 256 * 4 per thread pass: the accumulators of one k live across the passes over O)
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int k = k0 + threadIdx.x;
     float acc[LB_ROWS];
 #pragma unroll
     for (int rr = 0; rr < LB_ROWS; ++rr) acc[rr] = 0.f;
-    for (int o = 0; o < O; ++o) {
-      const float w = W[(size_t)o * K + k];
+    for (int o0 = 0; o0 < O; o0 += oc) {
+      const int no = min(oc, O - o0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nr * no; i += 256) { const int rr = i / no, o = i - rr * no; ds[rr * oc + o] = dy[(r0 + rr) * O + o0 + o]; }
+      __syncthreads();
+      if (k < K)
+        for (int o = 0; o < no; ++o) {
+          const float w = W[(size_t)(o0 + o) * K + k];
 #pragma unroll
-      for (int rr = 0; rr < LB_ROWS; ++rr) acc[rr] = fmaf(ds[rr * O + o], w, acc[rr]);
+          for (int rr = 0; rr < LB_ROWS; ++rr) acc[rr] = fmaf(ds[rr * oc + o], w, acc[rr]);
+        }
     }
+    if (k < K) {
 #pragma unroll
-    for (int rr = 0; rr < LB_ROWS; ++rr)
-      if (rr < nr) dx[(r0 + rr) * K + k] = acc[rr] + (add ? add[(r0 + rr) * K + k] : 0.f);
+      for (int rr = 0; rr < LB_ROWS; ++rr)
+        if (rr < nr) dx[(r0 + rr) * K + k] = acc[rr] + (add ? add[(r0 + rr) * K + k] : 0.f);
+    }
   }
 }
 // dW[o, k] = sum_r dy[r, o] x[r, k]: grid (ceil(K / 256), O); rows gathered through `gather` when x is an embedding table
@@ -364,10 +375,9 @@ int manner_hip_linear_backward(const float* x, const float* weight, const float*
     if (grad_b) MANNER_HIP_TRY(hipMemsetAsync(grad_b, 0, (size_t)O * sizeof(float), s));
     return MANNER_HIP_OK;
   }
-  if (!grad_y || O > 2000 || (grad_x && !weight) || (grad_w && !x))
-    return fail(MANNER_HIP_E_INVALID, "linear_backward: bad argument (O <= 2000)");
+  if (!grad_y || (grad_x && !weight) || (grad_w && !x)) return fail(MANNER_HIP_E_INVALID, "linear_backward: null pointer");
   if (grad_x) {
-    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((unsigned)((R + LB_ROWS - 1) / LB_ROWS)), dim3(256), LB_ROWS * O * sizeof(float), s, grad_y,
+    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((unsigned)((R + LB_ROWS - 1) / LB_ROWS)), dim3(256), LB_ROWS * (O < LB_OC ? O : LB_OC) * sizeof(float), s, grad_y,
                        weight, R, K, O, add_to_dx, grad_x);
     MANNER_LAUNCH_CHECK();
   }

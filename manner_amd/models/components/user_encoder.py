@@ -3,7 +3,7 @@
 import torch
 import torch.nn as nn
 
-from manner_amd import hip
+from manner_amd import hip, train
 from manner_amd.models.components.attention import AdditiveAttention
 
 
@@ -20,7 +20,10 @@ class NAMLUserEncoder(nn.Module):
 class NRMSUserEncoder(nn.Module):
     """reference user_encoder.py:24-42.  Batch-faithful: the un-masked batch_first=False MultiheadAttention sees the dense
     [B, Hmax, D] history and so attends ACROSS THE USERS OF THE BATCH at each history slot (zero-padded slots included);
-    the additive pooler then runs over all Hmax slots.  Inference only."""
+    the additive pooler then runs over all Hmax slots.  With grad mode on and anything that requires grad (train() or eval():
+    the module has no dropout) the differentiable operators of manner_amd.train run — in-projection, axis-0 attention,
+    out-projection and pooler, each with its hand-written backward (csrc/train_small.hip) — as
+    baselines/nrms_plm_module.py:119-135 trains it; otherwise the inference kernels."""
 
     def __init__(self, news_embedding_dim: int, num_attention_heads: int, query_vector_dim: int) -> None:
         super().__init__()
@@ -28,9 +31,13 @@ class NRMSUserEncoder(nn.Module):
         self.additive_attention = AdditiveAttention(news_embedding_dim, query_vector_dim)
 
     def forward(self, clicked_news_vector: torch.Tensor) -> torch.Tensor:
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("manner_amd NRMSUserEncoder is inference-only; call .eval() / torch.no_grad()")
         mha = self.multihead_attention
+        if torch.is_grad_enabled() and (clicked_news_vector.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if mha.dropout != 0.0:
+                raise RuntimeError("attention-probability dropout inside nn.MultiheadAttention is not built (the reference uses 0)")
+            user_vector = train.mha_axis0(clicked_news_vector, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+                                          mha.num_heads)
+            return self.additive_attention(user_vector)
         user_vector = hip.mha_axis0(clicked_news_vector, mha.in_proj_weight.detach(), mha.in_proj_bias.detach(),
                                     mha.out_proj.weight.detach(), mha.out_proj.bias.detach(), mha.num_heads)
         return self.additive_attention(user_vector)

@@ -383,7 +383,39 @@ def gen_baselines(seed=53):
                                          "nrms": {"d96": [96, 2], "d128": [128, 2]}, "query_dim": 200}))
 
 
+def gen_train_nrms(seed=58):
+    """Gradients of the reference's own NRMSUserEncoder (user_encoder.py:24-42) in train() mode — it has no dropout — for the
+    parameters and the input, loss = sum(out * R); zero-padded history slots as to_dense_batch leaves them."""
+    from manner.models.components.user_encoder import NRMSUserEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    out = {}
+    rng = np.random.default_rng(seed)
+    for tag, dim, heads, b, hmax in (("d128", 128, 2, 7, 9), ("d768", 768, 16, 5, 12)):
+        mw = make_mha_pool_weights(dim, 200, seed=seed)
+        with torch.enable_grad():
+            ue = NRMSUserEncoder(news_embedding_dim=dim, num_attention_heads=heads, query_vector_dim=200).train()
+            ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
+            x = (rng.standard_normal((b, hmax, dim)) * 0.5).astype(np.float32)
+            x[1, 4:] = 0.0
+            x[3, 1:] = 0.0
+            R = rng.standard_normal((b, dim)).astype(np.float32)
+            xt = torch.from_numpy(x).requires_grad_(True)
+            res = ue(xt)
+            (res * torch.from_numpy(R)).sum().backward()
+            out.update({f"{tag}_x": x, f"{tag}_R": R, f"{tag}_out": res.detach().numpy(), f"{tag}_grad:x": xt.grad.numpy().copy()})
+            # large matrices: the first 8 rows and every 37th row after them (keeps the fixture small)
+            out.update({f"{tag}_grad:{k}": (p.grad.numpy().copy() if p.grad.numel() <= 40000 else
+                                            p.grad.numpy()[np.r_[0:8, 8:p.grad.shape[0]:37]].copy()) for k, p in ue.named_parameters()})
+        print("NRMSUserEncoder.train()", tag, res.shape)
+    np.savez_compressed(os.path.join(HERE, "train_nrms.npz"), **out,
+                        meta=json.dumps({"source": "reference NRMSUserEncoder.train() (user_encoder.py:24-42), loss = sum(out * R), torch " + torch.__version__,
+                                         "seed": seed, "query_dim": 200, "cases": {"d128": [128, 2], "d768": [768, 16]}}))
+
+
 if __name__ == "__main__":
+    if "--train-nrms-only" in sys.argv:
+        gen_train_nrms()
+        sys.exit(0)
     if "--train-entities-only" in sys.argv:
         gen_train_entities()
         sys.exit(0)

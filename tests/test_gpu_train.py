@@ -499,6 +499,40 @@ def test_entity_branch_training_matches_reference(golden_dir):
     assert torch.equal(a, b) and (a - c).abs().max() > 1e-3
 
 
+def test_nrms_user_encoder_training_matches_reference(golden_dir):
+    """NRMSUserEncoder with autograd (reference user_encoder.py:24-42 as baselines/nrms_plm_module.py:119-135
+    trains it): output, input gradient and every parameter gradient against the reference's own module in train() mode
+    (tests/golden/train_nrms.npz), incl. the configured size (768 dims, 16 heads => head_dim 48) and zero-padded history slots."""
+    import json
+    import os
+    from manner_amd.models.components.user_encoder import NRMSUserEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    z = np.load(os.path.join(golden_dir, "train_nrms.npz"))
+    meta = json.loads(str(z["meta"]))
+    for tag, (dim, heads) in meta["cases"].items():
+        mw = make_mha_pool_weights(dim, meta["query_dim"], seed=meta["seed"])
+        ue = NRMSUserEncoder(news_embedding_dim=dim, num_attention_heads=heads, query_vector_dim=meta["query_dim"])
+        ue.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=True)
+        ue = ue.to(DEV).train()
+        x = torch.from_numpy(z[f"{tag}_x"]).to(DEV).requires_grad_(True)
+        out = ue(x)
+        assert out.requires_grad
+        (out * torch.from_numpy(z[f"{tag}_R"]).to(DEV)).sum().backward()
+        assert float((out.detach().cpu() - torch.from_numpy(z[f"{tag}_out"])).abs().max()) < 1e-4
+        assert _rel(x.grad.cpu().numpy(), z[f"{tag}_grad:x"]) < 1e-3
+        for k, p in ue.named_parameters():
+            want = z[f"{tag}_grad:{k}"]
+            got = p.grad.cpu().numpy()
+            if got.shape != want.shape:                      # large matrices are stored as a row sample
+                got = got[np.r_[0:8, 8:got.shape[0]:37]]
+            assert _rel(got, want) < 1e-3, (tag, k, _rel(got, want))
+        # eval() with grad mode on records a graph too (no dropout in this module); no_grad -> the inference kernels, same values
+        ue.eval()
+        assert ue(x.detach().requires_grad_(True)).requires_grad
+        with torch.no_grad():
+            assert float((ue(x.detach()) - out.detach()).abs().max()) < 1e-5
+
+
 def test_module_mirror_caches_the_frozen_prefix_engine():
     """Embeddings and layer 0 frozen on the module mirror: train() runs the prefix on an inference engine that survives
     optimiser steps (only frozen tensors key it) and gives the full path's output."""
