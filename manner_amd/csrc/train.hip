@@ -169,10 +169,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // `dy` may alias `dx`.
 constexpr int LN_BWD_BLOCKS = 1024;
 constexpr int LN_V4 = LN_MAX / 4;                     // float4 pieces per lane: column 4 (lane + 64 i) .. + 3
+// d16 (16-bit modes): also the 16-bit copy of dropout(dx) — the gradient of the GEMM output that sat under this LayerNorm's
+// residual add (r = dropout(y) + x: d y = dropout(d r)); the dropout bits are those of element rowmap[m] * H + c (rowmap:
+// compact [CLS] rows of the last layer) — saves the separate dropout pass over d r
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
                                                      float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
-                                                     const int* __restrict__ m_total) {
+                                                     const int* __restrict__ m_total, Drop drop, Out16 d16,
+                                                     const int32_t* __restrict__ rowmap) {
   __shared__ __attribute__((aligned(16))) float red[4][64 * LN_MAX + 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t M = m_total[0];
@@ -216,6 +220,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = st.y * (g[i][e] - c1 - xh[i][e] * c2);
         out[c] = o;
+        if (d16.dt) {
+          const uint64_t di = (uint64_t)(rowmap ? rowmap[m] : m) * H + 4 * c;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = drop.apply(o[e], di + e);
+          if (d16.dt == DT_F16) reinterpret_cast<f16x4*>(static_cast<f16_t*>(d16.p) + (size_t)m * H)[c] = f16x4{(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+          else reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d16.p) + (size_t)m * H)[c] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
       }
     }
   }
@@ -248,7 +260,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
 // grid (ceil(width / 256), COLSUM_BLOCKS): block (x, b) sums 256 columns over the rows b, b + COLSUM_BLOCKS, ...
 constexpr int COLSUM_BLOCKS = 64;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int width, float* __restrict__ partial,
+template <typename TS>
+__global__ __launch_bounds__(256) void colsum_kernel(const TS* __restrict__ y, int width, float* __restrict__ partial,
                                                      const int* __restrict__ m_total) {
   const int64_t M = m_total[0];
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -257,9 +270,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
   int64_t m = blockIdx.y;
   for (; m + 3 * COLSUM_BLOCKS < M; m += 4 * COLSUM_BLOCKS) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += y[(size_t)(m + u * COLSUM_BLOCKS) * width + c];
+    for (int u = 0; u < 4; ++u) s[u] += (float)y[(size_t)(m + u * COLSUM_BLOCKS) * width + c];
   }
-  for (; m < M; m += COLSUM_BLOCKS) s[0] += y[(size_t)m * width + c];
+  for (; m < M; m += COLSUM_BLOCKS) s[0] += (float)y[(size_t)m * width + c];
   partial[(size_t)blockIdx.y * width + c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
@@ -302,6 +315,29 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* a, const float* 
   }
 }
 
+// 16-bit modes: the two I-wide tensors live in the 16-bit type only (what the GEMMs that consume them read anyway):
+//   forward  g16 = gelu(inter)                         (inter stays f32: the backward's gelu' is exact)
+//   backward dz16 <- dz16 * gelu'(inter)               (dz16 = d g as the data-gradient GEMM wrote it, in place)
+template <typename TE>
+__global__ __launch_bounds__(256) void gelu16_kernel(const float* __restrict__ a, TE* __restrict__ z, int width, const int* __restrict__ m_total,
+                                                     int mode) {
+  typedef TE v4 __attribute__((ext_vector_type(4)));
+  const int64_t total4 = (int64_t)m_total[0] * width / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+    v4 o;
+    if (mode) {
+      const v4 d = reinterpret_cast<const v4*>(z)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (TE)((float)d[e] * gelu_grad(x[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (TE)gelu_exact(x[e]);
+    }
+    reinterpret_cast<v4*>(z)[i] = o;
+  }
+}
+
 // out[n] = dropout(x[cu[n]])  ([CLS] rows; news_encoder.py:34-35) — and the scatter of its gradient
 __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu, int H,
                                                   float* __restrict__ out, Drop drop) {
@@ -331,8 +367,8 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 // out[c][r] = T(in[r][c]) for r < rows_valid, 0 for rows_valid <= r < rows_out  (operands of the gradient GEMMs)
 // `ks` < rows_out: slice-major output for the split weight-gradient GEMMs — slice s = rows [s * ks, (s + 1) * ks) is its own
 // contiguous [cols, ks] matrix at offset s * cols * ks.
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t cols, T* __restrict__ out,
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ in, int64_t cols, T* __restrict__ out,
                                                         int64_t rows_out, const int* __restrict__ rows_valid_dev,
                                                         int64_t rows_valid_host, int64_t ks) {
   __shared__ float tile[32][33];
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
-    tile[ty + 8 * k][tx] = (r < rv && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    tile[ty + 8 * k][tx] = (r < rv && c < cols) ? (float)in[(size_t)r * cols + c] : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -926,28 +962,38 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
 }
 
-template <typename T>
-void launch_transpose(const float* in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host, int64_t ks,
+template <typename TS, typename T>
+void launch_transpose(const void* in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host, int64_t ks,
                       hipStream_t s) {
   dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows_out + 31) / 32));
-  hipLaunchKernelGGL(transpose_kernel<T>, g, dim3(256), 0, s, in, cols, static_cast<T*>(out), rows_out, rv_dev, rv_host, ks);
+  hipLaunchKernelGGL((transpose_kernel<TS, T>), g, dim3(256), 0, s, static_cast<const TS*>(in), cols, static_cast<T*>(out), rows_out, rv_dev,
+                     rv_host, ks);
 }
-// rows_in is documentation: `in` is [rows_in, cols]; ks = 0: one slice
-int transpose_to(Ctx& t, const float* in, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host,
-                 int64_t ks = 0) {
+// `in` is [rows_in, cols] of type in_dt (f32, or — 16-bit modes — already the mode's 16-bit type); ks = 0: one slice
+int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev,
+                 int64_t rv_host, int64_t ks = 0) {
   (void)rows_in;
   if (ks <= 0) ks = rows_out;
-  if (t.dt() == DT_F32) launch_transpose<float>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
-  else if (t.dt() == DT_F16) launch_transpose<f16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
-  else launch_transpose<bf16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  if (in_dt != DT_F32 && in_dt != t.dt()) return fail(MANNER_HIP_E_INVALID, "train: transpose source type %d in mode %d", (int)in_dt, (int)t.dt());
+  if (t.dt() == DT_F32) launch_transpose<float, float>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  else if (t.dt() == DT_F16) {
+    if (in_dt == DT_F32) launch_transpose<float, f16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+    else launch_transpose<f16_t, f16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  } else {
+    if (in_dt == DT_F32) launch_transpose<float, bf16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+    else launch_transpose<bf16_t, bf16_t>(in, cols, out, rows_out, rv_dev, rv_host, ks, t.s);
+  }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
 
-// dX [Mb, K] = dY [Mb, Nout] . W [Nout, K]
-int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, int K, const void* dY16 = nullptr) {
+// dX [Mb, K] = dY [Mb, Nout] . W [Nout, K]  (+ residual [Mb, K] f32 when given: fused into the GEMM's epilogue where the shape
+// allows — *fused tells the caller whether it was).  out_dt: f32, or (16-bit modes) the mode's 16-bit type for the I-wide d g.
+int linear_dgrad(Ctx& t, const float* dY, const float* W, void* dX, int Nout, int K, const void* dY16 = nullptr, DType out_dt = DT_F32,
+                 const float* residual = nullptr, bool* fused = nullptr) {
   int rc;
-  if ((rc = transpose_to(t, W, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc;       // W^T [K, Nout]
+  if (fused) *fused = false;
+  if ((rc = transpose_to(t, W, DT_F32, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc;       // W^T [K, Nout]
   const void* x = dY;
   if (t.dt() != DT_F32) {
     if (!dY16) {
@@ -955,12 +1001,17 @@ int linear_dgrad(Ctx& t, const float* dY, const float* W, float* dX, int Nout, i
       dY16 = t.wk.a16;
     }
     x = dY16;
+    if (residual && out_dt == DT_F32 && t.Mb % 256 == 0 && K % 256 == 0 && Nout >= 128) {
+      if (fused) *fused = true;
+      return gemm_tn(t.dt(), DT_F32, EPI_BIAS_RES_F32, x, t.wk.b16, t.wk.zero, residual, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
+    }
   }
-  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, x, t.wk.b16, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
+  return gemm_tn(t.dt(), out_dt, EPI_BIAS, x, t.wk.b16, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
 }
 
 // dW [Nout, K] = dY [Mb, Nout]^T . X [Mb, K]   (the reduction runs over the token rows; rows >= *m_total contribute zeros)
-int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, int K, int dim_slot) {
+// dy_dt / x_dt: the operands' storage type (f32, or the mode's 16-bit type when the tensor exists in 16 bits only)
+int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt, float* dW, int Nout, int K, int dim_slot) {
   int rc;
   if (t.dt() != DT_F32 && Nout % 256 == 0 && K % 256 == 0) {
     // Few output tiles, one long reduction: split the token axis into `slices` independent GEMMs of one launch
@@ -972,8 +1023,8 @@ int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, i
     if (slices > WGRAD_MAX_SLICES) slices = WGRAD_MAX_SLICES;
     if (slices >= 2) {
       const int64_t ks = round_up((t.Mb + slices - 1) / slices, 64), Mp = ks * slices;
-      if ((rc = transpose_to(t, dY, t.Mb, Nout, t.wk.a16, Mp, t.sv.m_total, 0, ks))) return rc;     // [slices][Nout, ks]
-      if ((rc = transpose_to(t, X, t.Mb, K, t.wk.b16, Mp, t.sv.m_total, 0, ks))) return rc;          // [slices][K, ks]
+      if ((rc = transpose_to(t, dY, dy_dt, t.Mb, Nout, t.wk.a16, Mp, t.sv.m_total, 0, ks))) return rc;     // [slices][Nout, ks]
+      if ((rc = transpose_to(t, X, x_dt, t.Mb, K, t.wk.b16, Mp, t.sv.m_total, 0, ks))) return rc;          // [slices][K, ks]
       if ((rc = set_device_int(t.wk.dims + dim_slot, Nout, t.s))) return rc;
       if ((rc = gemm_tn_batched16(t.dt(), t.wk.a16, t.wk.b16, t.wk.zero, t.wk.dwp, slices, (int64_t)Nout * ks, (int64_t)K * ks,
                                   (int64_t)Nout * K, Nout, K, (int)ks, t.wk.dims + dim_slot, t.s)))
@@ -984,16 +1035,28 @@ int linear_wgrad(Ctx& t, const float* dY, const float* X, float* dW, int Nout, i
       return MANNER_HIP_OK;
     }
   }
-  if ((rc = transpose_to(t, dY, t.Mb, Nout, t.wk.a16, t.Mb, t.sv.m_total, 0))) return rc;  // dY^T [Nout, Mb]
-  if ((rc = transpose_to(t, X, t.Mb, K, t.wk.b16, t.Mb, t.sv.m_total, 0))) return rc;      // X^T  [K, Mb]
+  if ((rc = transpose_to(t, dY, dy_dt, t.Mb, Nout, t.wk.a16, t.Mb, t.sv.m_total, 0))) return rc;  // dY^T [Nout, Mb]
+  if ((rc = transpose_to(t, X, x_dt, t.Mb, K, t.wk.b16, t.Mb, t.sv.m_total, 0))) return rc;      // X^T  [K, Mb]
   if ((rc = set_device_int(t.wk.dims + dim_slot, Nout, t.s))) return rc;
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, t.wk.a16, t.wk.b16, t.wk.zero, nullptr, dW, Nout, K, (int)t.Mb, t.wk.dims + dim_slot, t.s);
 }
 
-int bias_grad(Ctx& t, const float* dY, int width, float* db) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((width + 255) / 256), COLSUM_BLOCKS), dim3(256), 0, t.s, dY, width, t.wk.part, t.sv.m_total);
+int bias_grad(Ctx& t, const void* dY, DType dy_dt, int width, float* db) {
+  const dim3 g((unsigned)((width + 255) / 256), COLSUM_BLOCKS), b(256);
+  if (dy_dt == DT_F32) hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, t.s, static_cast<const float*>(dY), width, t.wk.part, t.sv.m_total);
+  else if (dy_dt == DT_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, g, b, 0, t.s, static_cast<const f16_t*>(dY), width, t.wk.part, t.sv.m_total);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, t.s, static_cast<const bf16_t*>(dY), width, t.wk.part, t.sv.m_total);
   MANNER_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.part, COLSUM_BLOCKS, width, db);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+// gelu between the two FFN GEMMs: fp32 mode f32 -> f32 (out / grad as before); 16-bit modes: the 16-bit-only wide tensor `z`
+int gelu16(Ctx& t, const float* inter, void* z, int width, int mode) {
+  const unsigned grid = t.ew_grid(width / 4 > 0 ? width / 4 : 1);
+  if (t.dt() == DT_F16) hipLaunchKernelGGL(gelu16_kernel<f16_t>, dim3(grid), dim3(256), 0, t.s, inter, static_cast<f16_t*>(z), width, t.sv.m_total, mode);
+  else hipLaunchKernelGGL(gelu16_kernel<bf16_t>, dim3(grid), dim3(256), 0, t.s, inter, static_cast<bf16_t*>(z), width, t.sv.m_total, mode);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -1004,11 +1067,12 @@ int ln_forward(Ctx& t, const float* x, const float* g, const float* b, float* y,
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
-int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const float* gamma, float* dx, float* dgamma, float* dbeta) {
+int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                Drop drop = Drop{0, 0, 0, 1.f}, void* d16 = nullptr, const int32_t* rowmap = nullptr) {
   const int H = t.c->hidden;
   float* pg = dgamma ? t.wk.part : nullptr;
   float* pb = dgamma ? t.wk.part + (size_t)LN_BWD_BLOCKS * H : nullptr;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap);
   MANNER_LAUNCH_CHECK();
   if (dgamma) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, t.s, pg, LN_BWD_BLOCKS, H, dgamma);
@@ -1136,9 +1200,13 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     if ((rc = dropout_add(c, t.wk.tmp, x_c, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr, cu))) return rc;
     if ((rc = ln_forward(c, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
     if ((rc = linear_fwd(c, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
-    hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, c.sv.m_total, 0, c.o16(t.wk.big16));
-    MANNER_LAUNCH_CHECK();
-    if ((rc = linear_fwd(c, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? t.wk.big16 : nullptr))) return rc;
+    if (mixed) {                                           // g exists in the 16-bit type only (the saved slot, half used)
+      if ((rc = gelu16(c, L.inter, L.g, I, 0))) return rc;
+    } else {
+      hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, c.sv.m_total, 0, Out16{nullptr, 0});
+      MANNER_LAUNCH_CHECK();
+    }
+    if ((rc = linear_fwd(c, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? (const void*)L.g : nullptr))) return rc;
     if ((rc = dropout_add(c, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr, cu))) return rc;
     return ln_forward(c, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
   }
@@ -1146,9 +1214,13 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   if ((rc = dropout_add(t, t.wk.tmp, x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
   if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
   if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
-  hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, t.o16(t.wk.big16));
-  MANNER_LAUNCH_CHECK();
-  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? t.wk.big16 : nullptr))) return rc;
+  if (mixed) {
+    if ((rc = gelu16(t, L.inter, L.g, I, 0))) return rc;
+  } else {
+    hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, Out16{nullptr, 0});
+    MANNER_LAUNCH_CHECK();
+  }
+  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? (const void*)L.g : nullptr))) return rc;
   if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
   return ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f), t.wk.h16a);
 }
@@ -1373,24 +1445,53 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     LayerSaved& L = sv.l[l];
     const bool below = l > stop || emb_grads || grad_prefix;       // is d x_in needed?
     const bool mixed = t.dt() != DT_F32;
-    // LN2: dx -> d r2 (wk.dr)
-    if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
-    // r2 = dropout(y2) + h1: d y2 = dropout(d r2) (wk.tmp), d h1 starts as d r2
-    if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.big16, rowmap))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(c, wk.tmp, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(c, wk.tmp, L.g, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
-    if ((rc = linear_dgrad(c, wk.tmp, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I, mixed ? wk.big16 : nullptr))) return rc;                // d g
-    hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, c.sv.m_total, 1, c.o16(wk.big16));   // d inter
-    MANNER_LAUNCH_CHECK();
-    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(c, wk.dbig, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(c, wk.dbig, L.h1, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
-    if ((rc = linear_dgrad(c, wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), wk.tmp, I, H, mixed ? wk.big16 : nullptr))) return rc;
-    if ((rc = add_rows(c, wk.tmp, wk.dr, wk.dx, H))) return rc;                                              // d h1
-    // LN1: d h1 -> d r1 (wk.dr)
-    if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
-    // r1 = dropout(proj) + x_in
-    if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.big16, rowmap))) return rc;    // d proj
-    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(c, wk.tmp, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
+    // 16-bit modes: every GEMM-output gradient that is consumed only by GEMMs / column sums exists in the 16-bit type only —
+    // d y2 and d proj (H wide, wk.h16b: written by the LayerNorm backward together with d r), d g and d inter (I wide, wk.big16:
+    // written by the data-gradient GEMM, then gelu' in place) — and d h1 / d x_in come out of their data-gradient GEMM with the
+    // residual gradient already added (EPI_BIAS_RES_F32).  The fp32 mode keeps every tensor in f32.
+    const DType g16 = mixed ? t.dt() : DT_F32;
+    const float* dy2 = wk.tmp;                               // fp32 mode: d y2 / d proj in f32
+    // LN2: dx -> d r2 (wk.dr); r2 = dropout(y2) + h1: d y2 = dropout(d r2), d h1 starts as d r2
+    if (mixed) {
+      if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B),
+                            make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.h16b, rowmap))) return rc;
+    } else {
+      if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
+      if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr, rowmap))) return rc;
+    }
+    const void* dy2_any = mixed ? (const void*)wk.h16b : (const void*)dy2;
+    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(c, dy2_any, g16, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(c, dy2_any, g16, L.g, g16, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
+    const void* dinter_any;
+    if (mixed) {
+      if ((rc = linear_dgrad(c, nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), wk.big16, H, I, wk.h16b, t.dt()))) return rc;          // d g (16-bit)
+      if ((rc = gelu16(c, L.inter, wk.big16, I, 1))) return rc;                                                         // d inter, in place
+      dinter_any = wk.big16;
+    } else {
+      if ((rc = linear_dgrad(c, dy2, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I))) return rc;                           // d g
+      hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, c.sv.m_total, 1, Out16{nullptr, 0});   // d inter
+      MANNER_LAUNCH_CHECK();
+      dinter_any = wk.dbig;
+    }
+    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(c, dinter_any, g16, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(c, dinter_any, g16, L.h1, DT_F32, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
+    {
+      bool fused = false;                                    // d h1 = d inter . W1 + d r2
+      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), mixed ? wk.dx : wk.tmp, I, H, mixed ? wk.big16 : nullptr,
+                             DT_F32, mixed ? wk.dr : nullptr, &fused)))
+        return rc;
+      if (!fused && (rc = add_rows(c, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H))) return rc;
+    }
+    // LN1: d h1 -> d r1 (wk.dr); r1 = dropout(proj) + x_in
+    if (mixed) {
+      if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B),
+                            make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.h16b, rowmap))) return rc;
+    } else {
+      if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
+      if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr, rowmap))) return rc;    // d proj
+    }
+    const void* dproj_any = mixed ? (const void*)wk.h16b : (const void*)wk.tmp;
+    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(c, dproj_any, g16, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_AO_W)) {
       const float* ctx_rows = L.ctx;
       if (compact) {                                     // the [CLS] rows of ctx, gathered as in the forward
@@ -1398,18 +1499,18 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
         MANNER_LAUNCH_CHECK();
         ctx_rows = wk.dbig;
       }
-      if ((rc = linear_wgrad(c, wk.tmp, ctx_rows, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+      if ((rc = linear_wgrad(c, dproj_any, g16, ctx_rows, DT_F32, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
     }
     const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
                        gl(l, MANNER_HIP_WL_K_B) || gl(l, MANNER_HIP_WL_V_B);
     if (!below && !qkv_w) return MANNER_HIP_OK;
     if (compact) {
       // d ctx of the [CLS] rows -> token rows (every other row of d ctx is zero)
-      if ((rc = linear_dgrad(c, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dqkv, H, H, mixed ? wk.big16 : nullptr))) return rc;
+      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dqkv, H, H, mixed ? wk.h16b : nullptr))) return rc;
       MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
       hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dqkv, sv.cu, H, wk.dx, make_drop(0, 0, 0.f));
       MANNER_LAUNCH_CHECK();
-    } else if ((rc = linear_dgrad(t, wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.big16 : nullptr))) {                 // d ctx
+    } else if ((rc = linear_dgrad(t, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.h16b : nullptr))) {   // d ctx
       return rc;
     }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
@@ -1430,25 +1531,27 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     MANNER_LAUNCH_CHECK();
     }
     if (qkv_w) {
-      if ((rc = bias_grad(t, wk.dqkv, 3 * H, wk.dw))) return rc;
+      if ((rc = bias_grad(t, wk.dqkv, DT_F32, 3 * H, wk.dw))) return rc;
       for (int k = 0; k < 3; ++k)
         if (gl(l, MANNER_HIP_WL_Q_B + 2 * k))
           MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_B + 2 * k), wk.dw + (size_t)k * H, H * sizeof(float), hipMemcpyDeviceToDevice, s));
-      if ((rc = linear_wgrad(t, wk.dqkv, L.x_in, wk.dw, 3 * H, H, 3))) return rc;
+      if ((rc = linear_wgrad(t, mixed ? (const void*)wk.big16 : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3))) return rc;
       for (int k = 0; k < 3; ++k)
         if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
           MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (!below) return MANNER_HIP_OK;
     if ((rc = pack_qkv_weights(t, l))) return rc;
-    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr))) return rc;
     if (compact) {                                       // d x_in = d qkv . W on every row, + d r1 on the [CLS] rows
-      MANNER_HIP_TRY(hipMemcpyAsync(wk.dx, wk.tmp, (size_t)m_bound * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.dx, 3 * H, H, mixed ? wk.big16 : nullptr))) return rc;
       hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dr, sv.cu, H, wk.dx);
       MANNER_LAUNCH_CHECK();
       return MANNER_HIP_OK;
     }
-    return add_rows(t, wk.tmp, wk.dr, wk.dx, H);                                                              // d x_in
+    bool fused = false;                                  // d x_in = d qkv . W + d r1
+    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, mixed ? wk.dx : wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, mixed ? wk.dr : nullptr, &fused)))
+      return rc;
+    return fused ? MANNER_HIP_OK : add_rows(t, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H);
   };
   if (cfg->layers - 1 >= stop) {
     // d x_L of the [CLS] rows, compact: the backward of out[n] = dropout(x_L[cu[n]])
@@ -1476,7 +1579,7 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     }
     if (gemb(MANNER_HIP_W_TYPE_EMB)) {
       MANNER_HIP_TRY(hipMemsetAsync(gemb(MANNER_HIP_W_TYPE_EMB), 0, (size_t)cfg->type_vocab * H * sizeof(float), s));
-      if ((rc = bias_grad(t, wk.dr, H, gemb(MANNER_HIP_W_TYPE_EMB)))) return rc;      // every token is of type 0
+      if ((rc = bias_grad(t, wk.dr, DT_F32, H, gemb(MANNER_HIP_W_TYPE_EMB)))) return rc;      // every token is of type 0
     }
   }
   return MANNER_HIP_OK;
