@@ -23,7 +23,7 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "train_common.h"
 
 namespace manner {
 namespace {
@@ -624,6 +624,12 @@ struct DlnAux {
   // EPI_BIAS only: gridDim.y independent problems of the same shape (problem y reads X + y * batch_x, W + y * batch_w
   // and writes Y + y * batch_y, elements) — the split-K slices of the training path's weight-gradient GEMMs
   int64_t batch_x, batch_w, batch_y;
+  // EPI_BIAS_RES_F32 only (training forward): Y = dropout(X W^T + bias) + R with the training path's counter-based bits
+  // (element index drop_rowmap[m] * N + n, or m * N + n); drop_thr == 0: no dropout
+  uint64_t drop_seed;
+  uint32_t drop_site, drop_thr;
+  float drop_scale;
+  const int32_t* drop_rowmap;
 };
 
 template <typename TE, typename TOut, int EPI, int ABL = 0>
@@ -1035,7 +1041,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
         }
-        if (EPI == EPI_BIAS_RES_F32) raw += resf[q];
+        if (EPI == EPI_BIAS_RES_F32) {
+          if (dln.drop_thr != 0) {                                   // dropout on the GEMM output, then the residual (r = dropout(y) + x)
+            const uint64_t di = (uint64_t)(dln.drop_rowmap ? dln.drop_rowmap[min(m, M - 1)] : m) * N + (nbase + c * OPC);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) raw[e] = drop_bits(dln.drop_seed, dln.drop_site, di + e) >= dln.drop_thr ? raw[e] * dln.drop_scale : 0.f;
+          }
+          raw += resf[q];
+        }
         if (m < M) {
           f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
           // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
@@ -1208,6 +1221,28 @@ int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias,
   else
     hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, float, EPI_BIAS>), g, b, 0, stream, static_cast<const bf16_t*>(X),
                        static_cast<const bf16_t*>(W), bias, static_cast<const bf16_t*>(nullptr), Y, N, K, m_total, n_tiles, aux);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+// Y [m, N] f32 = dropout(X W^T + bias) + R   (16-bit operands, f32 residual / output; 256-tileable shapes, K >= 128): the
+// training forward's attention-output and FFN-output projections with their dropout and residual add in the epilogue
+int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, const float* residual, float* Y, int64_t m_bound, int N,
+                     int K, const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream) {
+  if (!is_16bit(in) || m_bound % G_BM || N % G_BN || K < 128 || (K * 2) % ROW_BYTES || !residual)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_drop_res: m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  const int n_tiles = N / G_BN;
+  const int64_t tiles = (m_bound / G_BM) * n_tiles;
+  const int n_cus = device_cus();
+  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
+  DlnAux aux{};
+  aux.drop_seed = drop.seed; aux.drop_site = drop.site; aux.drop_thr = drop.thr; aux.drop_scale = drop.scale; aux.drop_rowmap = rowmap;
+  if (in == DT_F16)
+    hipLaunchKernelGGL((gemm_tn_x16_kernel<f16_t, float, EPI_BIAS_RES_F32>), g, b, 0, stream, static_cast<const f16_t*>(X), static_cast<const f16_t*>(W),
+                       bias, reinterpret_cast<const f16_t*>(residual), Y, N, K, m_total, n_tiles, aux);
+  else
+    hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, float, EPI_BIAS_RES_F32>), g, b, 0, stream, static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(W),
+                       bias, reinterpret_cast<const bf16_t*>(residual), Y, N, K, m_total, n_tiles, aux);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

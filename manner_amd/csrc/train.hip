@@ -962,6 +962,12 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
 }
 
+// R = dropout(X W^T + bias) + residual (attention-output / FFN-output projection of the forward pass, modeling_bert.py:289-293,
+// 347-351): 16-bit modes on 256-tileable shapes run it as ONE GEMM (dropout and residual add in the epilogue); otherwise GEMM ->
+// wk.tmp, then the elementwise pass.  rowmap: compact [CLS] rows draw the bits of the token rows they stand for.
+int linear_fwd_drop_res(Ctx& t, const float* X, const void* X16, const float* W, const float* bias, const float* residual, float* R, int Nout,
+                        int K, const Drop& drop, const int32_t* rowmap);
+
 template <typename TS, typename T>
 void launch_transpose(const void* in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev, int64_t rv_host, int64_t ks,
                       hipStream_t s) {
@@ -1067,6 +1073,19 @@ int ln_forward(Ctx& t, const float* x, const float* g, const float* b, float* y,
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
+int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16 = nullptr,
+                const int32_t* rowmap = nullptr);
+int linear_fwd_drop_res(Ctx& t, const float* X, const void* X16, const float* W, const float* bias, const float* residual, float* R, int Nout,
+                        int K, const Drop& drop, const int32_t* rowmap) {
+  int rc;
+  if (t.dt() != DT_F32 && X16 && t.Mb % 256 == 0 && Nout % 256 == 0 && K >= 128 && (K * 2) % 128 == 0) {
+    if ((rc = convert_f32_to_16(t.dt(), W, t.wk.b16, (int64_t)Nout * K, t.s))) return rc;
+    return gemm_tn_drop_res(t.dt(), X16, t.wk.b16, bias, residual, R, t.Mb, Nout, K, t.sv.m_total, drop, rowmap, t.s);
+  }
+  if ((rc = linear_fwd(t, X, W, bias, t.wk.tmp, Nout, K, X16))) return rc;
+  return dropout_add(t, t.wk.tmp, residual, R, Nout, drop, nullptr, rowmap);
+}
+
 int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const float* gamma, float* dx, float* dgamma, float* dbeta,
                 Drop drop = Drop{0, 0, 0, 1.f}, void* d16 = nullptr, const int32_t* rowmap = nullptr) {
   const int H = t.c->hidden;
@@ -1082,8 +1101,7 @@ int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const
   }
   return MANNER_HIP_OK;
 }
-int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16 = nullptr,
-                const int32_t* rowmap = nullptr) {
+int dropout_add(Ctx& t, const float* a, const float* res, float* out, int width, Drop drop, void* out16, const int32_t* rowmap) {
   hipLaunchKernelGGL(dropout_add_kernel, dim3(t.ew_grid(width)), dim3(256), 0, t.s, a, res, out, width, t.sv.m_total, drop, t.o16(out16), rowmap);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
@@ -1196,8 +1214,8 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, L.ctx, cu, H, ctx_c);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, x_in, cu, H, x_c);
     MANNER_LAUNCH_CHECK();
-    if ((rc = linear_fwd(c, ctx_c, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H))) return rc;
-    if ((rc = dropout_add(c, t.wk.tmp, x_c, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr, cu))) return rc;
+    if ((rc = linear_fwd_drop_res(c, ctx_c, nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_c, L.r1, H, H,
+                                  make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), cu))) return rc;
     if ((rc = ln_forward(c, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
     if ((rc = linear_fwd(c, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
     if (mixed) {                                           // g exists in the 16-bit type only (the saved slot, half used)
@@ -1206,12 +1224,12 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
       hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, c.sv.m_total, 0, Out16{nullptr, 0});
       MANNER_LAUNCH_CHECK();
     }
-    if ((rc = linear_fwd(c, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? (const void*)L.g : nullptr))) return rc;
-    if ((rc = dropout_add(c, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr, cu))) return rc;
+    if ((rc = linear_fwd_drop_res(c, L.g, mixed ? (const void*)L.g : nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), L.h1, L.r2, H, I,
+                                  make_drop(seed, layer_site(l, SITE_FFN), p_hidden), cu))) return rc;
     return ln_forward(c, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
   }
-  if ((rc = linear_fwd(t, L.ctx, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), t.wk.tmp, H, H, mixed ? t.wk.h16b : nullptr))) return rc;
-  if ((rc = dropout_add(t, t.wk.tmp, x_in, L.r1, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden)))) return rc;
+  if ((rc = linear_fwd_drop_res(t, L.ctx, mixed ? t.wk.h16b : nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_in, L.r1, H, H,
+                                make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr))) return rc;
   if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
   if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
   if (mixed) {
@@ -1220,8 +1238,8 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, Out16{nullptr, 0});
     MANNER_LAUNCH_CHECK();
   }
-  if ((rc = linear_fwd(t, L.g, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), t.wk.tmp, H, I, mixed ? (const void*)L.g : nullptr))) return rc;
-  if ((rc = dropout_add(t, t.wk.tmp, L.h1, L.r2, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden)))) return rc;
+  if ((rc = linear_fwd_drop_res(t, L.g, mixed ? (const void*)L.g : nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), t.lw(l, MANNER_HIP_WL_FF2_B), L.h1, L.r2, H, I,
+                                make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr))) return rc;
   return ln_forward(t, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f), t.wk.h16a);
 }
 

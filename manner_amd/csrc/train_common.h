@@ -35,6 +35,10 @@ enum { SITE_EMB = 0, SITE_CLS = 1, SITE_ATTN = 0, SITE_PROJ = 1, SITE_FFN = 2 };
 __host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (uint32_t)(layer + 1) + (uint32_t)k; }
 
 
+// gemm.hip: Y [m, N] f32 = dropout(X W^T + bias) + R in one GEMM (16-bit operands, 256-tileable shapes, K >= 128)
+int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, const float* residual, float* Y, int64_t m_bound, int N,
+                     int K, const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream);
+
 // Training attention on the matrix pipe (train_attn.hip; 16-bit modes): S <= 128 keys per news, head_dim 64, one wave per
 // (news, head).  qkv16 [m, 3H] = [Q | K | V] of the 16-bit type `dt`.
 //   forward : ctx [m, H] f32 (+ its 16-bit copy ctx16, may be NULL) = dropout(softmax(q k^T / 8)) v;  ml[m, heads] = {row max of the
