@@ -220,9 +220,20 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const TE* __restrict_
 // k-slots pair feature s with feature 32+s for Q and K alike, which is just another summation order — softmax online
 // over 32-key tiles with expf, and the S^T accumulators as the B operand of O^T = V^T P^T, V^T read row-wise from a
 // row-major f32 LDS image (two key rows per ds_read_b32).  All global traffic in whole 256-byte row segments.
+// a3 != NULL (x3 modes): the output rows are written as the out-projection GEMM's split operand [hi | hi | lo] (row stride 3H of
+// the 16-bit type a3_dt) instead of as f32 ctx rows — the f32 tensor and the separate split pass over it never exist.
+template <typename TE>
+__device__ __forceinline__ void store_split4(TE* __restrict__ dst, int H, const f32x4& v) {
+  typename E16<TE>::v4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { hi[e] = (TE)v[e]; lo[e] = (TE)(v[e] - (float)hi[e]); }
+  *reinterpret_cast<typename E16<TE>::v4*>(dst) = hi;
+  *reinterpret_cast<typename E16<TE>::v4*>(dst + H) = hi;
+  *reinterpret_cast<typename E16<TE>::v4*>(dst + 2 * H) = lo;
+}
 template <int NKT>
 __device__ __forceinline__ void attn_wave_f32(const float* __restrict__ qkv, float* __restrict__ ctx, int tok0, int L, int H,
-                                              int head, char* vl) {
+                                              int head, char* vl, void* __restrict__ a3 = nullptr, int a3_dt = 0) {
   const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
   char* ol = vl + NKT * 32 * 256;                 // 8 KiB slab (32 rows x 256 B) behind the V image
   const size_t ld = 3 * (size_t)H;
@@ -331,7 +342,12 @@ __device__ __forceinline__ void attn_wave_f32(const float* __restrict__ qkv, flo
         const int row = 4 * i + r4;
         const int q = 32 * qb + row;
         const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 256 + (c16 << 4));
-        if (q < L) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + head * 64 + 4 * (c16 ^ (row & 15))) = v;
+        if (q < L) {
+          const size_t col = head * 64 + 4 * (c16 ^ (row & 15));
+          if (!a3) *reinterpret_cast<f32x4*>(ctx + (size_t)(tok0 + q) * H + col) = v;
+          else if (a3_dt == DT_F16) store_split4<f16_t>(static_cast<f16_t*>(a3) + (size_t)(tok0 + q) * 3 * H + col, H, v);
+          else store_split4<bf16_t>(static_cast<bf16_t*>(a3) + (size_t)(tok0 + q) * 3 * H + col, H, v);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -340,7 +356,7 @@ __device__ __forceinline__ void attn_wave_f32(const float* __restrict__ qkv, flo
 
 __global__ __launch_bounds__(128, 1) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                                const int32_t* __restrict__ cu, int64_t n_pairs, int heads,
-                                                               int H, int lds_per_wave) {
+                                                               int H, int lds_per_wave, void* __restrict__ a3, int a3_dt) {
   extern __shared__ __attribute__((aligned(16))) char vlds[];
   const int wave = threadIdx.x >> 6;
   const int64_t pair = (int64_t)blockIdx.x * 2 + wave;
@@ -349,10 +365,10 @@ __global__ __launch_bounds__(128, 1) void attn_f32_mfma_kernel(const float* __re
   const int tok0 = __builtin_amdgcn_readfirstlane(cu[n]);
   const int L = __builtin_amdgcn_readfirstlane(cu[n + 1]) - tok0;
   char* vl = vlds + wave * lds_per_wave;
-  if (L <= 32) attn_wave_f32<1>(qkv, ctx, tok0, L, H, head, vl);
-  else if (L <= 64) attn_wave_f32<2>(qkv, ctx, tok0, L, H, head, vl);
-  else if (L <= 96) attn_wave_f32<3>(qkv, ctx, tok0, L, H, head, vl);
-  else attn_wave_f32<4>(qkv, ctx, tok0, L, H, head, vl);
+  if (L <= 32) attn_wave_f32<1>(qkv, ctx, tok0, L, H, head, vl, a3, a3_dt);
+  else if (L <= 64) attn_wave_f32<2>(qkv, ctx, tok0, L, H, head, vl, a3, a3_dt);
+  else if (L <= 96) attn_wave_f32<3>(qkv, ctx, tok0, L, H, head, vl, a3, a3_dt);
+  else attn_wave_f32<4>(qkv, ctx, tok0, L, H, head, vl, a3, a3_dt);
 }
 
 // exact-f32 attention, VALU form (MANNER_HIP_ATTN_F32_VALU=1): one workgroup (128 threads, one per query) per (news, head)
@@ -528,7 +544,7 @@ int attention_cls(DType dt, const void* qcls, const void* kv, void* ctx_cls, con
 }
 
 int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, int64_t n_news, int heads, int H,
-                     int max_len, hipStream_t stream) {
+                     int max_len, hipStream_t stream, void* split_out, DType split_dt) {
   if (H != heads * 64) return fail(MANNER_HIP_E_INVALID, "head_dim must be 64 (H=%d heads=%d)", H, heads);
   if (max_len < 1 || max_len > MANNER_HIP_MAX_LEN)
     return fail(MANNER_HIP_E_INVALID, "padded length %d exceeds the %d-token attention tile", max_len, MANNER_HIP_MAX_LEN);
@@ -564,7 +580,8 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
         lds_raised = true;
       }
       hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(128), 2 * lds_per_wave, stream,
-                         static_cast<const float*>(qkv), static_cast<float*>(ctx), cu, pairs, heads, H, lds_per_wave);
+                         static_cast<const float*>(qkv), static_cast<float*>(ctx), cu, pairs, heads, H, lds_per_wave, split_out,
+                         (int)split_dt);
     }
   }
   MANNER_LAUNCH_CHECK();

@@ -52,7 +52,9 @@ int device_cus();   // compute units of the current device (gemm.hip)
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5,
-                EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */ };
+                EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */,
+                EPI_BIAS_GELU_SPLIT3 = 7 /* x3 modes' FFN1: exact-erf gelu(acc + bias) written as the NEXT GEMM's split operand
+                                            [hi | hi | lo], row stride 3 N of the 16-bit type (the f32 intermediate never exists) */ };
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 static inline bool is_16bit(DType d) { return d != DT_F32; }
 
@@ -131,6 +133,9 @@ int scatter_hidden(DType in, DType out_dt, const void* x, const void* mr, const 
                    const float* gamma, const float* beta, void* out, hipStream_t stream);
 // bf16x3 / f16x3: out [rows, 3K] of the 16-bit type `dt` = [hi | hi | lo] of x [rows, K] f32 (activations) or [hi | lo | hi] (weights); rows >= *m_total skipped
 int split3_rows(DType dt, bool weight, const float* x, void* out, int K, int64_t rows, const int* m_total, hipStream_t stream);
+// x3 modes: LayerNorm that also emits the split operand of the GEMM that consumes its output: x f32 [m, H] and a3 [m, 3H] = [hi | hi | lo]
+int layernorm_rows_split(DType split_dt, const float* pre, const float* gamma, const float* beta, int H, float eps, float* x, void* a3,
+                         int64_t m_bound, const int* m_total, hipStream_t stream);
 int add_vectors(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int set_device_int(int32_t* p, int32_t value, hipStream_t stream);
 int gather_cls(DType in, const void* x, const int32_t* cu, int64_t n_news, int H, float* out, hipStream_t stream);
@@ -139,8 +144,10 @@ int convert_f32_to_16(DType dt, const float* src, void* dst, int64_t n, hipStrea
 
 // ------------------------------------------------------------------ attention (attention.hip)
 // ctx[tok, head*64 + d] = softmax_k(q.k/8) v over the tokens of the same news; qkv [m, 3H] = [Q|K|V].
+// split_out != NULL (dt == DT_F32, MFMA kernel only): the rows are written as the split operand [hi | hi | lo] of the 16-bit type
+// split_dt, row stride 3H, instead of as f32 ctx rows (x3 modes).
 int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, int64_t n_news, int heads,
-                     int H, int max_len, hipStream_t stream);
+                     int H, int max_len, hipStream_t stream, void* split_out = nullptr, DType split_dt = DT_F32);
 
 // last layer: only the [CLS] query of every news attends.  qcls [n_news, H]; kv [m, 2H] = [K|V];
 // ctx_cls [n_news, H].

@@ -132,7 +132,8 @@ struct Workspace {
   void *x, *qkv, *ctx, *ffn;
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
   void *mr_in, *mr_mid, *part;       // deferred LayerNorm: {mean, rstd} per row (layer input / after attention), partial sums
-  void* a3;                          // BF16X3: split copy [M, 3*max(H, I)] bf16 of the current GEMM's f32 A operand
+  void* a3;                          // x3 modes: split copy [M, 3*max(H, I)] (16-bit) of an I-wide (or compact-row) f32 A operand
+  void* a3h;                         // x3 modes: split copy [M, 3H] of the H-wide A operand (layer input / ctx / LN1 output), written by its producer
   // last layer, [CLS] rows only: the rows of several chunks are collected (acc_*) and the tail of the layer — output
   // projection, LayerNorm, FFN, LayerNorm — runs ONCE over them (run_cls_tail) instead of as 5 small launches per chunk
   void *acc_x, *acc_ctx, *acc_x1;    // [cls_cap + 256, H]: layer input (normalised) / attention output / LN1 output of the [CLS] rows
@@ -146,7 +147,7 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   const size_t es = act_bytes(prec);
   const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
   size_t off = 0;
-  if (ws) ws->a3 = nullptr;
+  if (ws) { ws->a3 = nullptr; ws->a3h = nullptr; }
   auto take = [&](size_t bytes) { size_t o = off; off += (size_t)round_up((int64_t)bytes, 256); return base ? base + o : nullptr; };
   char* p;
   p = take((size_t)max_news * 4); if (ws) ws->lens = (int32_t*)p;
@@ -163,7 +164,10 @@ size_t carve(const manner_hip_encoder* e, int64_t max_news, int64_t m_cap, int p
   p = take((size_t)m_cap * 8); if (ws) ws->mr_in = p;
   p = take((size_t)m_cap * 8); if (ws) ws->mr_mid = p;
   p = take((size_t)m_cap * (H / 64) * 8); if (ws) ws->part = p;
-  if (is_x3(prec)) { p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p; }
+  if (is_x3(prec)) {
+    p = take((size_t)m_cap * 3 * (H > I ? H : I) * 2); if (ws) ws->a3 = p;
+    p = take((size_t)m_cap * 3 * H * 2); if (ws) ws->a3h = p;
+  }
   const int64_t cls_cap = m_cap < CLS_CAP ? m_cap : CLS_CAP;     // the tail borrows pre / ffn (m_cap rows) as scratch
   if (ws) ws->cls_cap = cls_cap;
   p = take((size_t)(cls_cap + 256) * H * es); if (ws) ws->acc_x = p;
@@ -259,7 +263,32 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     return gemm_tn(xdt, DT_F32, epi == EPI_BIAS_RES ? EPI_BIAS_RES_F32 : epi, ws.a3, Wm, bias, res, Y, mb, N, 3 * K, mt, s);
   };
   const int full_layers = hidden_layers >= 0 ? hidden_layers : c.layers - 1;
-  for (int l = 0; l < full_layers; ++l) {
+  // x3 modes: the [hi | hi | lo] operand of every GEMM is written by the kernel that PRODUCES the tensor — the LayerNorms emit the
+  // split of their output next to the f32 row, FFN1's epilogue writes gelu(.) straight as FFN2's split operand (the f32
+  // intermediate never exists), the f32 attention writes its rows as the out-projection's split operand — instead of by a
+  // separate pass over the f32 tensor in front of each GEMM (17 % of the mode's time in round 2); only the embedding output
+  // still goes through split3_rows, once per chunk.
+  if (x3) PROF_STEP(MANNER_HIP_PROF_LAYERNORM, split3_rows(xdt, false, static_cast<const float*>(ws.x), ws.a3h, H, m_bound, ws.m_total, s))
+  for (int l = 0; l < full_layers && x3; ++l) {
+    const LayerWeights& w = e->w[prec][l];
+    const LayerParams& p = e->params[l];
+    float* xf = static_cast<float*>(ws.x);
+    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(xdt, DT_F32, EPI_BIAS, ws.a3h, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, 3 * H, ws.m_total, s))
+    static const bool attn_valu = getenv("MANNER_HIP_ATTN_F32_VALU") != nullptr;     // (the A/B VALU kernel writes f32 rows)
+    if (attn_valu) {
+      PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
+      PROF_STEP(MANNER_HIP_PROF_LAYERNORM, split3_rows(xdt, false, static_cast<const float*>(ws.ctx), ws.a3h, H, m_bound, ws.m_total, s))
+    } else {
+      PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s, ws.a3h, xdt))
+    }
+    PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn(xdt, DT_F32, EPI_BIAS_RES_F32, ws.a3h, w.wo, p.bo, ws.x, ws.pre, m_bound, H, 3 * H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows_split(xdt, ws.pre, p.ln1g, p.ln1b, H, c.ln_eps, xf, ws.a3h, m_bound, ws.m_total, s))
+    if (l == 0) phase.mark();
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn(xdt, xdt, EPI_BIAS_GELU_SPLIT3, ws.a3h, w.w1, p.b1, nullptr, ws.a3, m_bound, I, 3 * H, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn(xdt, DT_F32, EPI_BIAS_RES_F32, ws.a3, w.w2, p.b2, ws.x, ws.pre, m_bound, H, 3 * I, ws.m_total, s))
+    PROF_STEP(MANNER_HIP_PROF_LAYERNORM, layernorm_rows_split(xdt, ws.pre, p.ln2g, p.ln2b, H, c.ln_eps, xf, ws.a3h, m_bound, ws.m_total, s))
+  }
+  for (int l = 0; l < full_layers && !x3; ++l) {
     const LayerWeights& w = e->w[prec][l];
     const LayerParams& p = e->params[l];
     PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, w.wqkv, p.bqkv, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total))
@@ -285,7 +314,10 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
     const int64_t n_bound = round_up(n_news, 256);
     const int32_t* n_total = ws.m_total + 1;
     const char* wkv = static_cast<const char*>(w.wqkv) + (size_t)H * (x3 ? (size_t)3 * H * 2 : (size_t)H * es);
-    PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total))
+    if (x3)   // the split of the layer input is already in ws.a3h (written by the previous LayerNorm / the embedding split)
+      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn(xdt, DT_F32, EPI_BIAS, ws.a3h, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, 3 * H, ws.m_total, s))
+    else
+      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm(dt, EPI_BIAS, ws.x, wkv, p.bqkv + H, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total))
     char* ax = static_cast<char*>(ws.acc_x) + (size_t)cls_off * H * es;
     char* actx = static_cast<char*>(ws.acc_ctx) + (size_t)cls_off * H * es;
     PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_rows(dt, ws.x, ws.cu, n_news, H, ax, s))
@@ -502,7 +534,7 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   const size_t ws_each = (workspace_bytes / enc->n_streams) / 256 * 256;   // same chunk size with or without profiling
   const size_t es = act_bytes(precision);
   const size_t per_tok = (size_t)H * 4 + ((size_t)5 * H + enc->cfg.intermediate) * es +
-                         (is_x3(precision) ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) : 0);
+                         (is_x3(precision) ? (size_t)6 * (H > enc->cfg.intermediate ? H : enc->cfg.intermediate) + (size_t)6 * H : 0);
   int64_t m_cap = (int64_t)(ws_each / per_tok) / 256 * 256;
   int64_t n_cap = 0;
   while (m_cap >= 256) {

@@ -983,6 +983,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
     for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
     constexpr bool NORM = EPI == EPI_NORM || EPI == EPI_NORM_GELU;   // deferred LayerNorm of the A operand
+    constexpr bool SPLIT = EPI == EPI_BIAS_GELU_SPLIT3;              // 16-bit [hi | hi | lo] output rows of 3 N elements
+    const size_t ldy = SPLIT ? (size_t)3 * N : (size_t)N;
     f32x4 cv[NORM ? 4 : 1];
     float2 ms[NORM ? 8 : 1];
     if constexpr (NORM) {
@@ -1008,16 +1010,58 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
             if constexpr (NORM) v[e] = fmaf(ms[MB * j + b2].y, fmaf(-ms[MB * j + b2].x, cv[a][e], acc[a][MB * j + b2][e]), bv[a][e]);
             else v[e] = acc[a][MB * j + b2][e] + bv[a][e];
           }
-          if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
+          if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU || SPLIT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);   // f32 out: parity-grade erf
+            for (int e = 0; e < 4; ++e) v[e] = (sizeof(TOut) == 4 || SPLIT) ? gelu_erf(v[e]) : gelu_poly(v[e]);   // f32 out / split: parity-grade erf
           }
           const int c = nl / OPC;
           const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
           store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+          if constexpr (SPLIT) {                       // remainders v - hi, written through the slab in a second pass
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][MB * j + b2][e] = v[e] - (float)(TOut)v[e];
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (SPLIT) {
+        // pass 1: the hi rows go out twice (columns n and N + n); pass 2: the lo rows (columns 2 N + n)
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+          const int row = q * ROWS_PER_INST + row0;
+          const int c = sl ^ (row & (CHUNKS - 1));
+          const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
+          const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+          if (m < M) {
+            TOut* dst = Y + (size_t)m * ldy + nbase + c * OPC;
+            __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst));
+            __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst + N));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b2 = 0; b2 < MB; ++b2) {
+          const int row = 16 * b2 + l15;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int c = (16 * a + 4 * lq) / OPC;
+            const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + 8 * (lq & 1);
+            store4<TOut>(reinterpret_cast<TOut*>(slab + off), acc[a][MB * j + b2][0], acc[a][MB * j + b2][1], acc[a][MB * j + b2][2],
+                         acc[a][MB * j + b2][3]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+          const int row = q * ROWS_PER_INST + row0;
+          const int c = sl ^ (row & (CHUNKS - 1));
+          const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
+          const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+          if (m < M) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + 2 * (size_t)N + nbase + c * OPC));
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
       e16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
       f32x4 resf[EPI == EPI_BIAS_RES_F32 ? SQ : 1];
       if ((EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_F32) && ABL != 1) {   // TOut == float: the slab's residual loads in one batch
@@ -1088,6 +1132,12 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
     case EPI_BIAS_RES:
       hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
       break;
+    case EPI_BIAS_GELU_SPLIT3:
+      if constexpr (sizeof(TOut) == 2) {
+        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU_SPLIT3>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+        break;
+      }
+      return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_GELU_SPLIT3 writes the 16-bit split operand");
     case EPI_BIAS_RES_F32:
       if constexpr (sizeof(TOut) == 4) {
         hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
@@ -1256,6 +1306,8 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   if ((epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_F32) && !residual) return fail(MANNER_HIP_E_INVALID, "gemm residual missing");
   if (epi == EPI_BIAS_RES_F32 && !(is_16bit(in) && out == DT_F32 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
     return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 needs 16-bit operands, f32 output and 256-tileable shapes");
+  if (epi == EPI_BIAS_GELU_SPLIT3 && !(is_16bit(in) && out == in && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128))
+    return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_GELU_SPLIT3 needs 16-bit operands and output and 256-tileable shapes");
   if (out != DT_F32 && out != in) return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {

@@ -117,6 +117,23 @@ __device__ __forceinline__ void wave_layernorm_store(f32x4 v[VEC_PER_LANE], int 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       store_vec<TOut>(dst + c, o);
+      v[i] = o;                                          // the normalised row stays in registers for callers that go on with it
+    }
+  }
+}
+// the x3 modes' split operand of a row held as in wave_layernorm_store: a3[0 .. 3H) = [hi | hi | lo], hi = TE(x), lo = TE(x - hi)
+template <typename TE>
+__device__ __forceinline__ void wave_split3_store(const f32x4 v[VEC_PER_LANE], int H, TE* __restrict__ a3, int lane) {
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      typename E16<TE>::v4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = (TE)v[i][e]; lo[e] = (TE)(v[i][e] - (float)hi[e]); }
+      *reinterpret_cast<typename E16<TE>::v4*>(a3 + c) = hi;
+      *reinterpret_cast<typename E16<TE>::v4*>(a3 + H + c) = hi;
+      *reinterpret_cast<typename E16<TE>::v4*>(a3 + 2 * H + c) = lo;
     }
   }
 }
@@ -175,6 +192,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (c < H) v[i] = *reinterpret_cast<const f32x4*>(src + c);
   }
   wave_layernorm_store<TOut>(v, H, eps, gamma, beta, x + (size_t)row * H, lane);
+}
+
+// x3 modes: LayerNorm + the split operand of the GEMM that consumes it, in one pass over the row
+template <typename TE>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ pre, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int H, float eps, float* __restrict__ x,
+                                                              TE* __restrict__ a3, const int* __restrict__ m_total) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= *m_total) return;
+  const float* src = pre + (size_t)row * H;
+  f32x4 v[VEC_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < VEC_PER_LANE; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) v[i] = *reinterpret_cast<const f32x4*>(src + c);
+  }
+  wave_layernorm_store<float>(v, H, eps, gamma, beta, x + (size_t)row * H, lane);
+  wave_split3_store<TE>(v, H, a3 + (size_t)row * 3 * H, lane);
 }
 
 // ---- deferred LayerNorm (16-bit path): K1 without the normalisation.  The row is rounded to the element type first and
@@ -398,6 +434,16 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
     hipLaunchKernelGGL(layernorm_kernel<f16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<f16_t*>(x), m_total);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, g, b, 0, stream, pre, gamma, beta, H, eps, static_cast<float*>(x), m_total);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int layernorm_rows_split(DType split_dt, const float* pre, const float* gamma, const float* beta, int H, float eps, float* x, void* a3,
+                         int64_t m_bound, const int* m_total, hipStream_t stream) {
+  if (H % 4 || H > MAX_H || !is_16bit(split_dt)) return fail(MANNER_HIP_E_INVALID, "layernorm_rows_split: hidden size %d / dtype unsupported", H);
+  dim3 g((unsigned)((m_bound + 3) / 4)), b(256);
+  if (split_dt == DT_F16) hipLaunchKernelGGL(layernorm_split_kernel<f16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, x, static_cast<f16_t*>(a3), m_total);
+  else hipLaunchKernelGGL(layernorm_split_kernel<bf16_t>, g, b, 0, stream, pre, gamma, beta, H, eps, x, static_cast<bf16_t*>(a3), m_total);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
