@@ -1016,10 +1016,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           }
           const int c = nl / OPC;
           const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
-          store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
-          if constexpr (SPLIT) {                       // remainders v - hi, written through the slab in a second pass
+          if constexpr (SPLIT) {
+            // hi is converted ONCE and the remainder is taken against that very value (a second f32 -> 16-bit conversion of v may
+            // be a different instruction — packed vs scalar — and round a tie the other way: hi + lo would then miss v by an ulp
+            // of hi); the remainders go through the slab in a second pass
+            typedef TOut o4 __attribute__((ext_vector_type(4)));
+            o4 hv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][MB * j + b2][e] = v[e] - (float)(TOut)v[e];
+            for (int e = 0; e < 4; ++e) hv[e] = (TOut)v[e];
+            asm volatile("" : "+v"(hv));                 // opaque: the store and the remainder below use THESE bits
+            *reinterpret_cast<o4*>(slab + off) = hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][MB * j + b2][e] = v[e] - (float)hv[e];
+          } else {
+            store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
           }
         }
       }
