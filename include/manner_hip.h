@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 3
+#define MANNER_HIP_ABI_VERSION 4
 
 enum {
   MANNER_HIP_OK = 0,
@@ -394,6 +394,25 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
                               const float* grad_cls, void* saved, size_t saved_bytes, float* const* grads /*host*/,
                               float* grad_prefix, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
 int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, manner_hip_stream_t stream);
+
+/* The same training path with "full rows" — the PLM inside PLMTextEncoder in train() mode (manner/models/components/
+ * news_encoder.py:132-171: `self.plm_model(**tokenized_text)[0]` = HF last_hidden_state, whose PADDED positions the
+ * reference's un-masked MultiheadAttention / AdditiveAttention mix into the result; trained by baselines/
+ * nrms_plm_module.py:119-135): every position of the padded batch is a row (m = n_news * padded_len), the real tokens
+ * of a news are its attention keys, padded positions embed the pad token (RoBERTa: at position pad_id) and still
+ * produce outputs, no layer is pruned to the [CLS] rows.  hidden / grad_hidden: f32 [n_news * padded_len, H] (row
+ * n * padded_len + t).  saved: manner_hip_train_saved_bytes(cfg, n_news, M, 0), workspace:
+ * manner_hip_train_workspace_bytes(cfg, M), M = n_news * padded_len rounded up to 256.  Dropout sites and the grads
+ * table as in manner_hip_train_forward / _backward (there is no [CLS] dropout here: the caller owns what follows). */
+int manner_hip_train_full_forward(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
+                                  const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t precision,
+                                  float p_hidden, float p_attn, uint64_t seed, float* hidden, void* saved, size_t saved_bytes,
+                                  void* workspace, size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream);
+int manner_hip_train_full_backward(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
+                                   const int64_t* ids, int64_t n_news, int64_t padded_len, int32_t precision, float p_hidden,
+                                   float p_attn, uint64_t seed, const float* grad_hidden, void* saved, size_t saved_bytes,
+                                   float* const* grads /*host*/, void* workspace, size_t workspace_bytes,
+                                   manner_hip_stream_t stream);
 
 /* The rest of the training step (cr_module.py:105-171), f32, ragged order:
  *  - late-fusion scorer on the vectors of every occurrence (training encodes x_hist / x_cand per impression, :107-113):

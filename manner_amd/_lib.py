@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
@@ -70,6 +70,10 @@ SIGNATURES = {
                                            C.c_float, C.c_float, C.c_float, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P, _P]),
     "manner_hip_train_backward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _I64, _I64, _I64, _I32, _I32,
                                             C.c_float, C.c_float, C.c_float, C.c_uint64, _P, _P, _SZ, C.POINTER(_P), _P, _P, _SZ, _P]),
+    "manner_hip_train_full_forward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I32, C.c_float, C.c_float,
+                                                C.c_uint64, _P, _P, _SZ, _P, _SZ, _P, _P]),
+    "manner_hip_train_full_backward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _I64, _I64, _I32, C.c_float, C.c_float,
+                                                 C.c_uint64, _P, _P, _SZ, C.POINTER(_P), _P, _SZ, _P]),
     "manner_hip_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, _I64, _P, _P]),
     "manner_hip_late_fusion_train_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "manner_hip_late_fusion_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),

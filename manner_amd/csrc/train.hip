@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const int64_t* __restric
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t n_news, int lp,
                                                         const int32_t* __restrict__ cu, const float* __restrict__ de, int H,
                                                         int pos_offset, int vocab, int max_pos, float* __restrict__ dword,
-                                                        float* __restrict__ dpos) {
+                                                        float* __restrict__ dpos, const int32_t* __restrict__ klen, int pad_pos) {
   const int64_t idx = blockIdx.x;
   const int64_t n = idx / lp;
   const int t = (int)(idx - n * lp);
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   if (t >= len) return;
   int64_t id = ids[n * lp + t];
   int p = t + pos_offset;
+  if (klen && pad_pos >= 0 && t >= klen[n]) p = pad_pos;      // "full rows": padded positions as embed_sum_kernel places them
   if (id < 0 || id >= vocab) id = 0;
   if (p >= max_pos) p = max_pos - 1;
   const float* src = de + (size_t)(cu[n] + t) * H;
@@ -481,14 +482,16 @@ template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                               const float* __restrict__ ctx, const float2* __restrict__ ml,
                                                               float* __restrict__ dqkv, float* __restrict__ dsum,
-                                                              const int32_t* __restrict__ cu, int heads, int H, Drop drop, Out16 o16) {
+                                                              const int32_t* __restrict__ cu, int heads, int H, Drop drop, Out16 o16,
+                                                              const int32_t* __restrict__ klen) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float ks[HPB * HS], vs[HPB * HS];
   const int hs = threadIdx.x / (2 * RPH), i = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
-  const int base = cu[n], S = cu[n + 1] - base;
-  const bool active = i < S;
+  const int base = cu[n], SQ_ = cu[n + 1] - base;
+  const int S = klen ? min(klen[n], SQ_) : SQ_;             // keys; every row of the news is a query
+  const bool active = i < SQ_;
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
   float q[AH], go[AH], dq[AH];
@@ -538,15 +541,16 @@ template <int AT, int HPB>
 __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                const float2* __restrict__ ml, const float* __restrict__ dsum,
                                                                float* __restrict__ dqkv, const int32_t* __restrict__ cu,
-                                                               int heads, int H, Drop drop, Out16 o16) {
+                                                               int heads, int H, Drop drop, Out16 o16, const int32_t* __restrict__ klen) {
   constexpr int KC = AttnGeom<HPB>::KC, HS = AttnGeom<HPB>::HS, RPH = AT / (2 * HPB);
   __shared__ __attribute__((aligned(16))) float qs[HPB * HS], gs[HPB * HS];
   __shared__ float sm[HPB][KC], sl[HPB][KC], sd[HPB][KC];
   const int hs = threadIdx.x / (2 * RPH), j = (threadIdx.x - hs * 2 * RPH) >> 1, half = threadIdx.x & 1;
   const int h0 = blockIdx.x * HPB, h = h0 + hs;
   const int64_t n = blockIdx.y;
-  const int base = cu[n], S = cu[n + 1] - base;
+  const int base = cu[n], S = cu[n + 1] - base;             // queries: every row; a row past klen is no key: its d k = d v = 0
   const bool active = j < S;
+  const bool is_key = !klen || j < klen[n];
   const size_t ld = (size_t)3 * H;
   const float* rows = qkv + (size_t)base * ld;
   float k[AH], v[AH], dk[AH], dv[AH];
@@ -589,6 +593,10 @@ __global__ __launch_bounds__(AT) void attn_train_bwd_kv_kernel(const float* __re
   }
   if (!active) return;
   const size_t ck = (size_t)(base + j) * ld + H + h * AD + AH * half, cv = ck + H;
+  if (!is_key) {
+#pragma unroll
+    for (int d = 0; d < AH; ++d) dk[d] = dv[d] = 0.f;
+  }
 #pragma unroll
   for (int d = 0; d < AH; ++d) { dqkv[ck + d] = dk[d]; dqkv[cv + d] = dv[d]; }
 #pragma unroll
@@ -1366,11 +1374,14 @@ int manner_hip_encode_full(const manner_hip_encoder_config* cfg, const float* co
   return MANNER_HIP_OK;
 }
 
-int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
-                             const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
-                             int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
-                             float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
-                             size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+// `full` ("full rows", the PLMTextEncoder path): every position of the padded [n_news, padded_len] batch is a row (cu[n] = n * lp),
+// the real tokens are the KEYS of a news (klen = lens), no layer is pruned to the [CLS] rows and the output is HF's
+// last_hidden_state [n_news * padded_len, H] including the padded positions (which the reference's un-masked consumers mix in).
+static int train_forward_impl(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                              const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
+                              int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
+                              float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
+                              size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream, bool full) {
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1385,14 +1396,23 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
   const int H = cfg->hidden, N = (int)n_news;
   (void)N;
   Saved& sv = t.sv;
-  if ((rc = lengths_and_offsets(mask, n_news, padded_len, sv.lens, sv.cu, sv.m_total, m_bound, -1, status, s))) return rc;
+  if (full) {
+    if (start_layer != 0 || m_bound != round_up(n_news * padded_len, 256)) return fail(MANNER_HIP_E_INVALID, "train_full_forward: m_bound must be round_up(n_news * padded_len, 256)");
+    // real lengths (validated as everywhere) = key counts; the packed offsets they imply are scratch (wk.dsum / wk.dims)
+    if ((rc = lengths_and_offsets(mask, n_news, padded_len, sv.lens, reinterpret_cast<int32_t*>(t.wk.dsum), t.wk.dims + 8, m_bound, -1, status, s))) return rc;
+    hipLaunchKernelGGL(full_offsets_kernel, dim3((unsigned)((n_news + 256) / 256)), dim3(256), 0, s, sv.cu, sv.m_total, n_news, (int)padded_len);
+    MANNER_LAUNCH_CHECK();
+  } else if ((rc = lengths_and_offsets(mask, n_news, padded_len, sv.lens, sv.cu, sv.m_total, m_bound, -1, status, s))) {
+    return rc;
+  }
   float* x0 = sv.l[start_layer].x_in;
   const unsigned tok_blocks = (unsigned)(n_news * padded_len);
   if (start_layer == 0) {
-    const int pos_offset = cfg->arch == MANNER_HIP_ARCH_ROBERTA ? cfg->pad_id + 1 : 0;
+    const bool roberta = cfg->arch == MANNER_HIP_ARCH_ROBERTA;
+    const int pos_offset = roberta ? cfg->pad_id + 1 : 0;
     hipLaunchKernelGGL(embed_sum_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu,
                        t.emb(MANNER_HIP_W_WORD_EMB), t.emb(MANNER_HIP_W_POS_EMB), t.emb(MANNER_HIP_W_TYPE_EMB), H, pos_offset,
-                       cfg->vocab, cfg->max_pos, sv.esum, status, nullptr, -1);
+                       cfg->vocab, cfg->max_pos, sv.esum, status, full ? sv.lens : nullptr, (full && roberta) ? cfg->pad_id : -1);
     MANNER_LAUNCH_CHECK();
     if ((rc = ln_forward(t, sv.esum, t.emb(MANNER_HIP_W_EMB_LN_G), t.emb(MANNER_HIP_W_EMB_LN_B), x0, sv.st0,
                          make_drop(seed, SITE_EMB, p_hidden), t.wk.h16a)))
@@ -1400,6 +1420,13 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
   } else {
     hipLaunchKernelGGL(pack_rows_kernel, dim3(tok_blocks), dim3(256), 0, s, prefix_hidden, x0, n_news, (int)padded_len, sv.cu, H, 0);
     MANNER_LAUNCH_CHECK();
+  }
+  if (full) {
+    for (int l = 0; l < cfg->layers; ++l) {
+      float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : cls_out;    // the last LayerNorm writes rows < n_news * padded_len: exactly the output
+      if ((rc = layer_forward(t, l, sv.l[l], sv.l[l].x_in, x_next, sv.cu, sv.lens, p_hidden, p_attn, seed, true, false))) return rc;
+    }
+    return MANNER_HIP_OK;
   }
   for (int l = start_layer; l < cfg->layers; ++l) {
     float* x_next = l + 1 < cfg->layers ? sv.l[l + 1].x_in : t.wk.dx;      // the last layer's output is only needed for its [CLS] rows
@@ -1414,11 +1441,11 @@ int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* 
   return dropout_add(c, t.wk.dx, nullptr, cls_out, H, make_drop(seed, SITE_CLS, p_out));
 }
 
-int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
-                              const int64_t* ids, int64_t n_news, int64_t padded_len, int64_t m_bound, int32_t precision,
-                              int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed, const float* grad_cls,
-                              void* saved, size_t saved_bytes, float* const* grads, float* grad_prefix, void* workspace,
-                              size_t workspace_bytes, manner_hip_stream_t stream) {
+static int train_backward_impl(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                               const int64_t* ids, int64_t n_news, int64_t padded_len, int64_t m_bound, int32_t precision,
+                               int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed, const float* grad_cls,
+                               void* saved, size_t saved_bytes, float* const* grads, float* grad_prefix, void* workspace,
+                               size_t workspace_bytes, manner_hip_stream_t stream, bool full) {
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1532,7 +1559,7 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
       return rc;
     }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-    if (t.mfma_attn()) {
+    if (t.mfma_attn() && !full) {
       // matrix-pipe backward: D = dctx . ctx and the 16-bit copy of dctx (wk.h16a is free in the backward), then d q and d k / d v
       if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.big16, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
                                          (int)padded_len, da, m_bound, sv.m_total, s)))
@@ -1541,8 +1568,8 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
     const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
-    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da, t.o16(wk.big16));  \
-    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da, t.o16(wk.big16)); \
+    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da, t.o16(wk.big16), full ? sv.lens : nullptr);  \
+    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da, t.o16(wk.big16), full ? sv.lens : nullptr); \
   } while (0)
     MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);
 #undef MANNER_ATTN_BWD
@@ -1571,12 +1598,17 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
       return rc;
     return fused ? MANNER_HIP_OK : add_rows(t, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H);
   };
-  if (cfg->layers - 1 >= stop) {
+  if (full) {
+    // d last_hidden_state arrives for every row; no layer was pruned
+    MANNER_HIP_TRY(hipMemcpyAsync(wk.dx, grad_cls, (size_t)n_news * padded_len * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int l = cfg->layers - 1; l >= stop; --l)
+      if ((rc = layer_backward(l, false))) return rc;
+  } else if (cfg->layers - 1 >= stop) {
     // d x_L of the [CLS] rows, compact: the backward of out[n] = dropout(x_L[cu[n]])
     if ((rc = dropout_add(cc, grad_cls, nullptr, wk.dx, H, make_drop(seed, SITE_CLS, p_out)))) return rc;
     if ((rc = layer_backward(cfg->layers - 1, true))) return rc;
   }
-  for (int l = cfg->layers - 2; l >= stop; --l)
+  for (int l = cfg->layers - 2; l >= stop && !full; --l)
     if ((rc = layer_backward(l, false))) return rc;
   const unsigned tok_blocks = (unsigned)(n_news * padded_len);
   if (grad_prefix) {
@@ -1592,7 +1624,8 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     if (gemb(MANNER_HIP_W_POS_EMB)) MANNER_HIP_TRY(hipMemsetAsync(gemb(MANNER_HIP_W_POS_EMB), 0, (size_t)cfg->max_pos * H * sizeof(float), s));
     if (gemb(MANNER_HIP_W_WORD_EMB) || gemb(MANNER_HIP_W_POS_EMB)) {
       hipLaunchKernelGGL(embed_bwd_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu, wk.dr, H, pos_offset,
-                         cfg->vocab, cfg->max_pos, gemb(MANNER_HIP_W_WORD_EMB), gemb(MANNER_HIP_W_POS_EMB));
+                         cfg->vocab, cfg->max_pos, gemb(MANNER_HIP_W_WORD_EMB), gemb(MANNER_HIP_W_POS_EMB), full ? sv.lens : nullptr,
+                         (full && cfg->arch == MANNER_HIP_ARCH_ROBERTA) ? cfg->pad_id : -1);
       MANNER_LAUNCH_CHECK();
     }
     if (gemb(MANNER_HIP_W_TYPE_EMB)) {
@@ -1601,6 +1634,42 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
     }
   }
   return MANNER_HIP_OK;
+}
+
+int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                             const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
+                             int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
+                             float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
+                             size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+  return train_forward_impl(cfg, weights, n_weights, ids, mask, n_news, padded_len, m_bound, precision, start_layer, prefix_hidden, p_hidden,
+                            p_attn, p_out, seed, cls_out, saved, saved_bytes, workspace, workspace_bytes, status, stream, false);
+}
+
+int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                              const int64_t* ids, int64_t n_news, int64_t padded_len, int64_t m_bound, int32_t precision,
+                              int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed, const float* grad_cls,
+                              void* saved, size_t saved_bytes, float* const* grads, float* grad_prefix, void* workspace,
+                              size_t workspace_bytes, manner_hip_stream_t stream) {
+  return train_backward_impl(cfg, weights, n_weights, ids, n_news, padded_len, m_bound, precision, start_layer, p_hidden, p_attn, p_out, seed,
+                             grad_cls, saved, saved_bytes, grads, grad_prefix, workspace, workspace_bytes, stream, false);
+}
+
+int manner_hip_train_full_forward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                                  const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int32_t precision,
+                                  float p_hidden, float p_attn, uint64_t seed, float* hidden, void* saved, size_t saved_bytes,
+                                  void* workspace, size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+  if (n_news <= 0 || padded_len <= 0) return fail(MANNER_HIP_E_INVALID, "train_full_forward: empty batch");
+  return train_forward_impl(cfg, weights, n_weights, ids, mask, n_news, padded_len, round_up(n_news * padded_len, 256), precision, 0, nullptr,
+                            p_hidden, p_attn, 0.f, seed, hidden, saved, saved_bytes, workspace, workspace_bytes, status, stream, true);
+}
+
+int manner_hip_train_full_backward(const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights,
+                                   const int64_t* ids, int64_t n_news, int64_t padded_len, int32_t precision, float p_hidden,
+                                   float p_attn, uint64_t seed, const float* grad_hidden, void* saved, size_t saved_bytes,
+                                   float* const* grads, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream) {
+  if (n_news <= 0 || padded_len <= 0) return fail(MANNER_HIP_E_INVALID, "train_full_backward: empty batch");
+  return train_backward_impl(cfg, weights, n_weights, ids, n_news, padded_len, round_up(n_news * padded_len, 256), precision, 0, p_hidden,
+                             p_attn, 0.f, seed, grad_hidden, saved, saved_bytes, grads, nullptr, workspace, workspace_bytes, stream, true);
 }
 
 int manner_hip_late_fusion_train_forward(const float* hist, const int64_t* hist_off, const float* cand, const int64_t* cand_off,

@@ -325,8 +325,8 @@ class PLMTextEncoder(nn.Module):
 
     Batch-faithful to the reference: its nn.MultiheadAttention is batch_first=False but receives [B, S, D], and neither it
     nor the additive pooler gets a mask, so (a) attention runs ACROSS THE NEWS OF THE CALL at each token position and (b)
-    the hidden states AT PADDED POSITIONS take part in both — ``hip.encode_full`` therefore computes them as HF does.
-    Inference only (eval())."""
+    the hidden states AT PADDED POSITIONS take part in both — ``hip.encode_full`` (and, with autograd, ``train.encode_full_train``)
+    therefore computes them as HF does."""
 
     #: GEMM arithmetic of the PLM in this class: "fp32" (default: these are baselines, not the throughput path), "f16", "bf16"
     precision: str = "fp32"
@@ -343,12 +343,32 @@ class PLMTextEncoder(nn.Module):
                 if "layer." + str(layer) + "." in name:
                     param.requires_grad = False
 
+    #: GEMM arithmetic of the PLM in train() mode ("fp32", "bf16" or "f16": see MannerTextEncoder.train_precision)
+    train_precision: str = "fp32"
+
     def forward(self, tokenized_text) -> torch.Tensor:
-        if self.training:
-            raise RuntimeError("manner_amd PLMTextEncoder is inference-only; call .eval()")
         ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
         if not ids.is_cuda:
             raise RuntimeError("PLMTextEncoder.forward needs GPU tensors — the HIP path has no CPU fallback")
+        if self.training or _wants_graph(self):
+            # train() mode (news_encoder.py:160-171; trained by baselines/nrms_plm_module.py:119-135): the PLM with HF's dropouts and
+            # autograd over "full rows" (padded positions included), dropout, the axis-0 attention, dropout, the pooler — every
+            # operator with its hand-written backward; eval() with a graph: the same operators, dropouts off
+            mha, pool = self.multihead_attention, self.additive_attention
+            if mha.dropout != 0.0:
+                raise RuntimeError("attention-probability dropout inside nn.MultiheadAttention is not built (the reference uses 0)")
+            if not self.training:
+                _warn_eval_graph("PLMTextEncoder")
+            on = 1.0 if self.training else 0.0
+            plm = self.plm_model
+            params = {k: v for k, v in plm.named_parameters() if not k.startswith("pooler.")}
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            x = train.encode_full_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=on * plm.hidden_dropout_prob,
+                                        p_attn=on * plm.attention_probs_dropout_prob, seed=seed)
+            x = train.dropout(x, on * self.dropout.p, seed, site=4)
+            x = train.mha_axis0(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, mha.num_heads)
+            x = train.dropout(x, on * self.dropout.p, seed, site=5)
+            return train.additive_pool(x, pool.linear.weight, pool.linear.bias, pool.query)
         params = {k: v.detach() for k, v in self.plm_model.named_parameters() if not k.startswith("pooler.")}
         hidden = hip.encode_full(self.plm_model.cfg, params, ids, mask, precision=self.precision)       # [B, S, D], pads included
         mha, pool = self.multihead_attention, self.additive_attention

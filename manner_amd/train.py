@@ -142,6 +142,72 @@ def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mas
     return _EncodeTrain.apply(ids, mask, prefix_hidden, opts, *table)
 
 
+class _EncodeFullTrain(torch.autograd.Function):
+    """HF last_hidden_state [N, Lp, H] INCLUDING the padded positions, with autograd into the PLM parameters (the PLM of
+    PLMTextEncoder in train() mode, news_encoder.py:160-171)."""
+
+    @staticmethod
+    def forward(ctx, ids: Tensor, mask: Tensor, opts: dict, *params: Tensor):
+        cfg: EncoderConfig = opts["cfg"]
+        lib = _lib.load()
+        n, lp = ids.shape
+        m_bound = (n * lp + 255) // 256 * 256
+        prec = _lib.PRECISIONS[opts["precision"]]
+        cc = _cfg_c(cfg)
+        dev = ids.device
+        with torch.cuda.device(dev):
+            saved = torch.empty(int(lib.manner_hip_train_saved_bytes(C.byref(cc), n, m_bound, 0)), dtype=torch.uint8, device=dev)
+            ws = torch.empty(int(lib.manner_hip_train_workspace_bytes(C.byref(cc), m_bound)), dtype=torch.uint8, device=dev)
+            out = torch.empty((n, lp, cfg.hidden), dtype=torch.float32, device=dev)
+            weights = [p.detach() for p in params]
+            status = hip.device_status(dev)
+            status.poll()
+            _lib.check(lib.manner_hip_train_full_forward(
+                C.byref(cc), _table(weights), len(weights), hip._ptr(ids), hip._ptr(mask), n, lp, prec, C.c_float(opts["p_hidden"]),
+                C.c_float(opts["p_attn"]), C.c_uint64(opts["seed"]), hip._ptr(out), hip._ptr(saved), saved.numel(), hip._ptr(ws), ws.numel(),
+                hip._ptr(status.word), hip._stream()))
+            status.arm()
+        ctx.opts, ctx.prec = opts, prec
+        ctx.saved_buf, ctx.ws = saved, ws
+        ctx.save_for_backward(ids, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        ids, *params = ctx.saved_tensors
+        opts, cfg = ctx.opts, ctx.opts["cfg"]
+        lib = _lib.load()
+        n, lp = ids.shape
+        need = ctx.needs_input_grad[3:]
+        grads: List[Optional[Tensor]] = [torch.empty_like(p) if r else None for p, r in zip(params, need)]
+        cc = _cfg_c(cfg)
+        with torch.cuda.device(ids.device):
+            g = grad_out.to(torch.float32).contiguous()
+            _lib.check(lib.manner_hip_train_full_backward(
+                C.byref(cc), _table([p.detach() for p in params]), len(params), hip._ptr(ids), n, lp, ctx.prec, C.c_float(opts["p_hidden"]),
+                C.c_float(opts["p_attn"]), C.c_uint64(opts["seed"]), hip._ptr(g), hip._ptr(ctx.saved_buf), ctx.saved_buf.numel(), _table(grads),
+                hip._ptr(ctx.ws), ctx.ws.numel(), hip._stream()))
+        return (None, None, None, *grads)
+
+
+def encode_full_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mask: Tensor, *, precision: str = "fp32",
+                      p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> Tensor:
+    """[N, Lp] ids / mask -> HF ``last_hidden_state`` [N, Lp, H] including the padded positions (``hip.encode_full`` with
+    autograd and HF's dropouts): what ``PLMTextEncoder`` feeds its un-masked attention in train() mode."""
+    if precision not in _TRAIN_PRECISIONS:
+        raise ValueError(f"training precision {precision!r}: one of {_TRAIN_PRECISIONS}")
+    ids, mask = hip._dev(ids, torch.int64, "input_ids").contiguous(), hip._dev(mask, torch.int64, "attention_mask").contiguous()
+    if ids.dim() != 2 or ids.shape != mask.shape:
+        raise ValueError(f"input_ids {tuple(ids.shape)} / attention_mask {tuple(mask.shape)} must be equal 2-D")
+    canon = canonical_weights(cfg, params)
+    table = [canon[name] for name in hip.weight_table_order(cfg)]
+    for name, t in zip(hip.weight_table_order(cfg), table):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError(f"{name}: training needs contiguous float32 GPU parameters")
+    opts = dict(cfg=cfg, precision=precision, p_hidden=float(p_hidden), p_attn=float(p_attn), seed=int(seed) & (2 ** 64 - 1))
+    return _EncodeFullTrain.apply(ids, mask, opts, *table)
+
+
 # ---------------------------------------------------------------------------------------------- scorer and loss
 class _LateFusion(torch.autograd.Function):
     @staticmethod

@@ -412,7 +412,51 @@ def gen_train_nrms(seed=58):
                                          "seed": seed, "query_dim": 200, "cases": {"d128": [128, 2], "d768": [768, 16]}}))
 
 
+def gen_train_plm(seed=59):
+    """Gradients of the reference's own PLMTextEncoder (news_encoder.py:132-171) in train() mode, every dropout probability 0,
+    loss = sum(out * R), on RAGGED token lengths: the padded positions take part in the un-masked attention / pooler, so the
+    PLM's gradient flows through them (and into the pad token's embedding row)."""
+    from manner.models.components.news_encoder import PLMTextEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    from transformers import BatchEncoding
+    out = {}
+    for tag, preset, heads, lengths in (("bert", "tiny-bert", 4, np.array([2, 5, 9, 14, 20, 20, 7])),
+                                        ("roberta", "tiny-roberta", 2, np.array([3, 18, 6, 11, 18]))):
+        cfg = PRESETS[preset]
+        w = make_plm_weights(cfg, seed=seed, std=0.05)
+        ids, mask = synth_news_tokens(len(lengths), cfg, seed=seed, max_len=int(lengths.max()), lengths=lengths)
+        mw = make_mha_pool_weights(cfg.hidden, 200, seed=seed)
+        R = np.random.default_rng(seed).standard_normal((len(lengths), cfg.hidden)).astype(np.float32)
+        with tempfile.TemporaryDirectory() as tmp, torch.enable_grad():
+            enc = PLMTextEncoder(plm_model=hf_model_dir(cfg, w, tmp, no_dropout=True), frozen_layers=[0], text_embedding_dim=cfg.hidden,
+                                 num_attention_heads=heads, query_vector_dim=200, dropout_probability=0.0).train()
+            missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in mw.items()}, strict=False)
+            assert not unexpected and all(m.startswith("plm_model.") for m in missing), (missing, unexpected)
+            res = enc(BatchEncoding({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}))
+            (res * torch.from_numpy(R)).sum().backward()
+            grads, frozen = {}, []
+            for k, p in enc.named_parameters():
+                if k.startswith("plm_model.pooler."):
+                    continue
+                if p.grad is None:
+                    frozen.append(k)
+                    continue
+                g = p.grad.numpy()
+                grads[f"{tag}_grad:{k}"] = (g.copy() if g.size <= 20000 else g[np.r_[0:8, 8:g.shape[0]:37]].copy())
+        out.update({f"{tag}_ids": ids, f"{tag}_mask": mask, f"{tag}_R": R, f"{tag}_out": res.detach().numpy(), **grads})
+        out[f"{tag}_frozen"] = np.array(frozen)
+        print("PLMTextEncoder.train()", preset, res.shape, len(grads), "grad tensors,", len(frozen), "frozen")
+    np.savez_compressed(os.path.join(HERE, "train_plm.npz"), **out,
+                        meta=json.dumps({"source": "reference PLMTextEncoder.train() (news_encoder.py:132-171), all dropout probabilities 0, "
+                                                   "loss = sum(out * R), transformers " + __import__("transformers").__version__,
+                                         "seed": seed, "std": 0.05, "plm": {"bert": ["tiny-bert", 4], "roberta": ["tiny-roberta", 2]},
+                                         "query_dim": 200, "frozen_layers": [0]}))
+
+
 if __name__ == "__main__":
+    if "--train-plm-only" in sys.argv:
+        gen_train_plm()
+        sys.exit(0)
     if "--train-nrms-only" in sys.argv:
         gen_train_nrms()
         sys.exit(0)

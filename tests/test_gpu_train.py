@@ -533,6 +533,75 @@ def test_nrms_user_encoder_training_matches_reference(golden_dir):
             assert float((ue(x.detach()) - out.detach()).abs().max()) < 1e-5
 
 
+def test_plm_text_encoder_training_matches_reference(golden_dir):
+    """PLMTextEncoder in train() mode (reference news_encoder.py:132-171, trained by baselines/
+    nrms_plm_module.py:119-135): the PLM over "full rows" (manner_hip_train_full_forward / _backward: padded positions embed the
+    pad token, attend over the real keys and feed the un-masked attention / pooler), then dropout, axis-0 attention, dropout,
+    pooler.  Output and every gradient against the reference's own module (tests/golden/train_plm.npz, dropouts 0), including
+    which tensors `frozen_layers` leaves without gradient; then dropout on: finite, seed-dependent, reproducible."""
+    import json
+    import os
+    import warnings
+    from manner_amd.models.components.news_encoder import PLMTextEncoder
+    from manner_amd.weights import make_mha_pool_weights
+    z = np.load(os.path.join(golden_dir, "train_plm.npz"))
+    meta = json.loads(str(z["meta"]))
+    for tag, (preset, heads) in meta["plm"].items():
+        cfg = PRESETS[preset]
+        w = make_plm_weights(cfg, seed=meta["seed"], std=meta["std"])
+        mw = make_mha_pool_weights(cfg.hidden, meta["query_dim"], seed=meta["seed"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            enc = PLMTextEncoder(plm_model=preset, frozen_layers=meta["frozen_layers"], text_embedding_dim=cfg.hidden, num_attention_heads=heads,
+                                 query_vector_dim=meta["query_dim"], dropout_probability=0.0)
+        sd = {"plm_model." + k: torch.from_numpy(v) for k, v in w.items()}
+        sd.update({k: torch.from_numpy(v) for k, v in mw.items()})
+        enc.load_state_dict(sd, strict=True)
+        enc = enc.to(DEV).train()
+        enc.plm_model.hidden_dropout_prob = enc.plm_model.attention_probs_dropout_prob = 0.0
+        batch = {"input_ids": torch.from_numpy(z[f"{tag}_ids"]).to(DEV), "attention_mask": torch.from_numpy(z[f"{tag}_mask"]).to(DEV)}
+        out = enc(batch)
+        (out * torch.from_numpy(z[f"{tag}_R"]).to(DEV)).sum().backward()
+        hip.check_status(DEV)
+        assert float((out.detach().cpu() - torch.from_numpy(z[f"{tag}_out"])).abs().max()) < 1e-4
+        frozen = set(z[f"{tag}_frozen"].tolist())
+        checked = 0
+        for k, p in enc.named_parameters():
+            if k.startswith("plm_model.pooler."):
+                continue
+            if k in frozen:
+                assert p.grad is None, k
+                continue
+            want = z[f"{tag}_grad:{k}"]
+            got = p.grad.cpu().numpy()
+            if got.shape != want.shape:
+                got = got[np.r_[0:8, 8:got.shape[0]:37]]
+            if k.endswith("attention.self.key.bias"):           # analytically zero (softmax is shift-invariant)
+                assert np.abs(got).max() < 1e-5 and np.abs(want).max() < 1e-5
+                continue
+            assert _rel(got, want) < 2e-3, (tag, k, _rel(got, want))
+            checked += 1
+        assert checked >= 25
+        # the pad token's embedding row receives gradient through the padded positions, as in the reference
+        pad_row = enc.plm_model.embeddings.word_embeddings.weight.grad[cfg.pad_id]
+        assert float(pad_row.abs().max()) > 0
+        # dropout on: reproducible under the same torch seed, different under another
+        enc.plm_model.hidden_dropout_prob = enc.plm_model.attention_probs_dropout_prob = 0.1
+        enc.dropout.p = 0.2
+        outs = []
+        for sd_ in (3, 3, 4):
+            torch.manual_seed(sd_)
+            outs.append(enc(batch).detach())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and float((outs[0] - outs[2]).abs().max()) > 1e-3
+        # 16-bit GEMM operands track the f32 mode
+        enc.plm_model.hidden_dropout_prob = enc.plm_model.attention_probs_dropout_prob = 0.0
+        enc.dropout.p = 0.0
+        enc.train_precision = "f16"
+        out16 = enc(batch)
+        assert float((out16.detach() - out.detach()).abs().max()) < 2e-2
+        enc.train_precision = "fp32"
+
+
 def test_module_mirror_caches_the_frozen_prefix_engine():
     """Embeddings and layer 0 frozen on the module mirror: train() runs the prefix on an inference engine that survives
     optimiser steps (only frozen tensors key it) and gives the full path's output."""
