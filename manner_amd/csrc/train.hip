@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const int64_t* __restric
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t n_news, int lp,
                                                         const int32_t* __restrict__ cu, const float* __restrict__ de, int H,
                                                         int pos_offset, int vocab, int max_pos, float* __restrict__ dword,
-                                                        float* __restrict__ dpos, const int32_t* __restrict__ klen, int pad_pos) {
+                                                        float* __restrict__ dpos, const int32_t* __restrict__ klen, int pad_pos,
+                                                        int word_pad, int pos_pad) {
   const int64_t idx = blockIdx.x;
   const int64_t n = idx / lp;
   const int t = (int)(idx - n * lp);
@@ -96,10 +97,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   if (id < 0 || id >= vocab) id = 0;
   if (p >= max_pos) p = max_pos - 1;
   const float* src = de + (size_t)(cu[n] + t) * H;
+  // HF builds word_embeddings (and RoBERTa's position_embeddings) with padding_idx = pad_token_id: nn.Embedding never gives that
+  // row a gradient (modeling_bert.py:71, modeling_roberta.py:75-80) — the pad token embedded at the padded positions of the
+  // "full rows" path contributes to the forward only
+  const bool wg = dword && id != word_pad, pg = dpos && p != pos_pad;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = src[c];
-    if (dword) atomicAdd(dword + (size_t)id * H + c, g);
-    if (dpos) atomicAdd(dpos + (size_t)p * H + c, g);
+    if (wg) atomicAdd(dword + (size_t)id * H + c, g);
+    if (pg) atomicAdd(dpos + (size_t)p * H + c, g);
   }
 }
 
@@ -1625,7 +1630,8 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     if (gemb(MANNER_HIP_W_WORD_EMB) || gemb(MANNER_HIP_W_POS_EMB)) {
       hipLaunchKernelGGL(embed_bwd_kernel, dim3(tok_blocks), dim3(256), 0, s, ids, n_news, (int)padded_len, sv.cu, wk.dr, H, pos_offset,
                          cfg->vocab, cfg->max_pos, gemb(MANNER_HIP_W_WORD_EMB), gemb(MANNER_HIP_W_POS_EMB), full ? sv.lens : nullptr,
-                         (full && cfg->arch == MANNER_HIP_ARCH_ROBERTA) ? cfg->pad_id : -1);
+                         (full && cfg->arch == MANNER_HIP_ARCH_ROBERTA) ? cfg->pad_id : -1, cfg->pad_id,
+                         cfg->arch == MANNER_HIP_ARCH_ROBERTA ? cfg->pad_id : -1);
       MANNER_LAUNCH_CHECK();
     }
     if (gemb(MANNER_HIP_W_TYPE_EMB)) {
