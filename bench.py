@@ -1037,8 +1037,13 @@ def main():
     del batches, table_bufs
     if not args.no_table:
         log("table mode")
-        tab, par_scale, held = table_mode(args, conf, cfg, encs, fuse_w, (pool_ids, pool_mask, pool_len), rank, world, dev,
-                                          scale_parity=not args.no_scale_parity)
+        try:
+            tab, par_scale, held = table_mode(args, conf, cfg, encs, fuse_w, (pool_ids, pool_mask, pool_len), rank, world, dev,
+                                              scale_parity=not args.no_scale_parity)
+        except Exception as exc:                       # a side leg must not take the headline line with it
+            import traceback
+            log("table mode FAILED: " + "".join(traceback.format_exception_only(type(exc), exc)).strip())
+            tab, par_scale, held = {"error": repr(exc)}, None, None
         if rank == 0:
             result["table_mode"] = tab
         if rank == 0 and par_scale is not None:

@@ -90,6 +90,9 @@ class MeshTableGather:
         self._cuda = self.table.is_cuda
         self._comm = torch.cuda.Stream(device=device) if (self._cuda and self.ws > 1) else None
         self._works: list = []
+        # gloo has no point-to-point transfers of GPU tensors (the one-GPU rehearsal of the multi-rank logic): the pieces are
+        # then exchanged by ONE all_gather of equal blocks in wait() — same table, no overlap.  RCCL ("nccl") runs the mesh.
+        self._collective_fallback = self.ws > 1 and self._cuda and dist.get_backend() != "nccl"
 
     def piece_rows(self, rank: int, c: int) -> Tuple[int, int]:
         """Table rows [a, b) of piece ``c`` of rank ``rank``'s shard (the same split on every rank)."""
@@ -103,7 +106,7 @@ class MeshTableGather:
 
     def post(self, c: int) -> None:
         """Piece ``c`` of this rank's shard has been ENQUEUED on the current stream: exchange it with every peer."""
-        if self.ws == 1:
+        if self.ws == 1 or self._collective_fallback:
             return
         ops = []
         for k in range(1, self.ws):
@@ -127,6 +130,10 @@ class MeshTableGather:
 
     def wait(self) -> torch.Tensor:
         """The complete table; the current stream is ordered behind every transfer."""
+        if self._collective_fallback:
+            lo, hi = self.shards[self.rank]
+            self.table.copy_(all_gather_table(self.table[lo:hi].clone(), self.shards))
+            return self.table
         for w in self._works:
             w.wait()
         self._works = []
