@@ -321,6 +321,47 @@ __global__ __launch_bounds__(256) void zscore_fuse_kernel(const float* __restric
   const int64_t c0 = off[i], c1 = off[i + 1];
   const float cn = (float)(c1 - c0);
   float pad = 0.f;                                     // what the reference's dense matrix holds in a padded slot
+  // Up to 256 candidates (every MIND impression but a handful): the scores of ALL planes are requested at once and held in
+  // registers, the fused value is accumulated there and written once — one memory round trip per impression instead of
+  // three dependent passes per plane plus a read-modify-write of `out` (the kernel is latency-bound: ~124 B per impression
+  // and plane).  The arithmetic and its order are those of the loop below, so both paths give the same bits.
+  constexpr int ZC = 4, ZK = 9;
+  if (c1 - c0 <= 64 * ZC) {
+    float v[ZK][ZC];
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      if (k >= K || (k > 0 && fw.w[k - 1] == 0.0f)) continue;
+      const float* s = scores + (int64_t)k * plane_stride;
+#pragma unroll
+      for (int t = 0; t < ZC; ++t) { const int64_t j = c0 + lane + 64 * t; v[k][t] = j < c1 ? s[j] : 0.f; }
+    }
+    float acc[ZC] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      if (k >= K) continue;
+      const float wk = k == 0 ? 1.0f : fw.w[k - 1];
+      if (k > 0 && wk == 0.0f) continue;
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < ZC; ++t) if (c0 + lane + 64 * t < c1) a += v[k][t];
+      const float mean = wave_sum(a) / cn;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < ZC; ++t) if (c0 + lane + 64 * t < c1) { const float d = v[k][t] - mean; q += d * d; }
+      const float sd = sqrtf(wave_sum(q) / (cn - 1.0f));
+#pragma unroll
+      for (int t = 0; t < ZC; ++t) {
+        const float z = (v[k][t] - mean) / sd;
+        acc[t] = k == 0 ? z : acc[t] + wk * z;
+      }
+      const float zp = (0.0f - mean) / sd;
+      pad = k == 0 ? zp : pad + wk * zp;
+    }
+#pragma unroll
+    for (int t = 0; t < ZC; ++t) { const int64_t j = c0 + lane + 64 * t; if (j < c1) out[j] = acc[t]; }
+    if (pad_out && lane == 0) pad_out[i] = pad;
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     const float wk = k == 0 ? 1.0f : fw.w[k - 1];
     if (k > 0 && wk == 0.0f) continue;                 // ensemble_module.py:100,105: module skipped

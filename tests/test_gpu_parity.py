@@ -284,6 +284,32 @@ def test_pipeline_kernels_match_golden(golden_dir):
     assert np.abs(n5.cpu().numpy() - z["per5"]).max() < 1e-6
 
 
+def test_zscore_fuse_both_paths_match_float64():
+    """K13 + K14 at the boundaries of the register-resident path (<= 256 candidates) and of the loop behind it: per impression
+    z = (s - mean) / std (unbiased), fused = z_0 + sum_k w_k z_k, the padded-slot value sum_k w_k (0 - mean_k) / std_k —
+    against a float64 evaluation of ensemble_module.py:138-149; a zero weight skips its plane."""
+    sizes = [2, 3, 63, 64, 65, 128, 255, 256, 257, 300, 511, 513, 37]
+    off_np = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    g = np.random.Generator(np.random.PCG64(12))
+    planes = (g.standard_normal((3, off_np[-1])) * np.array([[40.0], [3.0], [0.5]]) + np.array([[700.0], [-20.0], [0.0]])).astype(np.float32)
+    off = _cuda(off_np)
+    for w in ([-0.3, 0.2], [0.0, 0.7], [0.5, 0.0]):
+        fused, pad = hip.zscore_fuse(_cuda(planes), w, off, with_pad_value=True)
+        fused, pad = fused.cpu().numpy().astype(np.float64), pad.cpu().numpy().astype(np.float64)
+        for i, c in enumerate(sizes):
+            a, b = off_np[i], off_np[i + 1]
+            want, wpad = np.zeros(c), 0.0
+            for k, wk in enumerate([1.0] + list(w)):
+                if k > 0 and wk == 0.0:
+                    continue
+                x = planes[k, a:b].astype(np.float64)
+                m, sd = x.mean(), x.std(ddof=1)
+                want += wk * (x - m) / sd
+                wpad += wk * (0.0 - m) / sd
+            assert np.abs(fused[a:b] - want).max() < 2e-4 * max(1.0, np.abs(want).max()), (w, c)
+            assert abs(pad[i] - wpad) < 2e-4 * max(1.0, abs(wpad)), (w, c)
+
+
 def test_zscore_single_candidate_is_nan_and_rank_edge_cases():
     off = torch.tensor([0, 1, 4, 4, 9], dtype=torch.int64, device=DEV)     # c = 1, 3, 0 (empty), 5
     s = torch.tensor([1.0, 3.0, 3.0, 2.0, 0.5, 0.5, 0.7, 0.5, 0.1], device=DEV)
