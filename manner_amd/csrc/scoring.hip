@@ -75,7 +75,22 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
   }
   __syncthreads();
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
-  for (int64_t j = c0 + wave; j < c1; j += 4) {
+  int64_t j = c0 + wave;
+  for (; j + 4 < c1; j += 8) {                       // two candidate rows in flight per wave: the gathers are latency-bound
+    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = checked_row(cand_idx[j + 4], n_rows, status, lane);
+    const float* p0 = table + r0 * D;
+    const float* p1 = table + r1 * D;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(p0 + c), x1 = *reinterpret_cast<const f32x4*>(p1 + c);
+      const f32x4 u = *reinterpret_cast<const f32x4*>(user + c);
+      a0 += (x0[0] * u[0] + x0[1] * u[1]) + (x0[2] * u[2] + x0[3] * u[3]);
+      a1 += (x1[0] * u[0] + x1[1] * u[1]) + (x1[2] * u[2] + x1[3] * u[3]);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { out[j] = a0; out[j + 4] = a1; }
+  }
+  for (; j < c1; j += 4) {
     const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
     const float d = row_dot(table + r * D, user, D, lane);
     if (lane == 0) out[j] = d;
@@ -128,15 +143,33 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
   __syncthreads();
   const float konst = (cpart[0] + cpart[1]) + (cpart[2] + cpart[3]);          // <w, mu> (0 without centring)
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
-  for (int64_t j = c0 + wave; j < c1; j += 4) {
+  auto dot8 = [&](const f16x8& x, const f32x4& u0, const f32x4& u1) {
+    return (((float)x[0] * u0[0] + (float)x[1] * u0[1]) + ((float)x[2] * u0[2] + (float)x[3] * u0[3])) +
+           (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
+  };
+  int64_t j = c0 + wave;
+  for (; j + 4 < c1; j += 8) {                       // two candidate rows in flight per wave
+    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = checked_row(cand_idx[j + 4], n_rows, status, lane);
+    const f16_t* p0 = table + r0 * D;
+    const f16_t* p1 = table + r1 * D;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+      const f16x8 x0 = *reinterpret_cast<const f16x8*>(p0 + c), x1 = *reinterpret_cast<const f16x8*>(p1 + c);
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(user + c), u1 = *reinterpret_cast<const f32x4*>(user + c + 4);
+      a0 += dot8(x0, u0, u1);
+      a1 += dot8(x1, u0, u1);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { out[j] = a0 + konst; out[j + 4] = a1 + konst; }
+  }
+  for (; j < c1; j += 4) {
     const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
     const f16_t* row = table + r * D;
     float a = 0.f;
     for (int c = lane * 8; c < D; c += 512) {
       const f16x8 x = *reinterpret_cast<const f16x8*>(row + c);
       const f32x4 u0 = *reinterpret_cast<const f32x4*>(user + c), u1 = *reinterpret_cast<const f32x4*>(user + c + 4);
-      a += (((float)x[0] * u0[0] + (float)x[1] * u0[1]) + ((float)x[2] * u0[2] + (float)x[3] * u0[3])) +
-           (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
+      a += dot8(x, u0, u1);
     }
     a = wave_sum(a);
     if (lane == 0) out[j] = a + konst;
