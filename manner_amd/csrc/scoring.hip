@@ -348,6 +348,9 @@ struct FuseWeights { float w[8]; };
 __global__ __launch_bounds__(256) void zscore_fuse_kernel(const float* __restrict__ scores, int64_t plane_stride, int K,
                                                           FuseWeights fw, const int64_t* __restrict__ off, int64_t B,
                                                           float* __restrict__ out, float* __restrict__ pad_out) {
+  // no FMA contraction: the reference does `scores += w * z` as separate torch ops (ensemble_module.py:102,107), and near-tied
+  // candidates make the ranking sensitive to the last bit; both paths below then also give identical bits
+#pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= B) return;
