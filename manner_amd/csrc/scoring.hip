@@ -75,9 +75,12 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
   }
   __syncthreads();
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
-  int64_t j = c0 + wave;
-  for (; j + 4 < c1; j += 8) {                       // two candidate rows in flight per wave: the gathers are latency-bound
-    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = checked_row(cand_idx[j + 4], n_rows, status, lane);
+  // two candidate rows in flight per wave (the gathers are latency-bound).  ONE code path for every candidate — an odd last
+  // candidate is paired with itself — so that two occurrences of the same news get bit-identical scores (exact ties must
+  // stay ties for the stable ranking)
+  for (int64_t j = c0 + wave; j < c1; j += 8) {
+    const bool two = j + 4 < c1;
+    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = two ? checked_row(cand_idx[j + 4], n_rows, status, lane) : r0;
     const float* p0 = table + r0 * D;
     const float* p1 = table + r1 * D;
     float a0 = 0.f, a1 = 0.f;
@@ -88,12 +91,7 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
       a1 += (x1[0] * u[0] + x1[1] * u[1]) + (x1[2] * u[2] + x1[3] * u[3]);
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1);
-    if (lane == 0) { out[j] = a0; out[j + 4] = a1; }
-  }
-  for (; j < c1; j += 4) {
-    const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
-    const float d = row_dot(table + r * D, user, D, lane);
-    if (lane == 0) out[j] = d;
+    if (lane == 0) { out[j] = a0; if (two) out[j + 4] = a1; }
   }
 }
 
@@ -147,9 +145,9 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
     return (((float)x[0] * u0[0] + (float)x[1] * u0[1]) + ((float)x[2] * u0[2] + (float)x[3] * u0[3])) +
            (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
   };
-  int64_t j = c0 + wave;
-  for (; j + 4 < c1; j += 8) {                       // two candidate rows in flight per wave
-    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = checked_row(cand_idx[j + 4], n_rows, status, lane);
+  for (int64_t j = c0 + wave; j < c1; j += 8) {      // two candidate rows in flight per wave, one code path (see the f32 kernel)
+    const bool two = j + 4 < c1;
+    const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = two ? checked_row(cand_idx[j + 4], n_rows, status, lane) : r0;
     const f16_t* p0 = table + r0 * D;
     const f16_t* p1 = table + r1 * D;
     float a0 = 0.f, a1 = 0.f;
@@ -160,19 +158,7 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
       a1 += dot8(x1, u0, u1);
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1);
-    if (lane == 0) { out[j] = a0 + konst; out[j + 4] = a1 + konst; }
-  }
-  for (; j < c1; j += 4) {
-    const int64_t r = checked_row(cand_idx[j], n_rows, status, lane);
-    const f16_t* row = table + r * D;
-    float a = 0.f;
-    for (int c = lane * 8; c < D; c += 512) {
-      const f16x8 x = *reinterpret_cast<const f16x8*>(row + c);
-      const f32x4 u0 = *reinterpret_cast<const f32x4*>(user + c), u1 = *reinterpret_cast<const f32x4*>(user + c + 4);
-      a += dot8(x, u0, u1);
-    }
-    a = wave_sum(a);
-    if (lane == 0) out[j] = a + konst;
+    if (lane == 0) { out[j] = a0 + konst; if (two) out[j + 4] = a1 + konst; }
   }
 }
 
