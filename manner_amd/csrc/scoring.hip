@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
   // candidate is paired with itself — so that two occurrences of the same news get bit-identical scores (exact ties must
   // stay ties for the stable ranking)
   for (int64_t j = c0 + wave; j < c1; j += 8) {
+#pragma clang fp contract(off)                        // the two accumulations must round alike (no FMA picked for one of them only)
     const bool two = j + 4 < c1;
     const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = two ? checked_row(cand_idx[j + 4], n_rows, status, lane) : r0;
     const float* p0 = table + r0 * D;
@@ -142,10 +143,12 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
   const float konst = (cpart[0] + cpart[1]) + (cpart[2] + cpart[3]);          // <w, mu> (0 without centring)
   const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
   auto dot8 = [&](const f16x8& x, const f32x4& u0, const f32x4& u1) {
+#pragma clang fp contract(off)
     return (((float)x[0] * u0[0] + (float)x[1] * u0[1]) + ((float)x[2] * u0[2] + (float)x[3] * u0[3])) +
            (((float)x[4] * u1[0] + (float)x[5] * u1[1]) + ((float)x[6] * u1[2] + (float)x[7] * u1[3]));
   };
   for (int64_t j = c0 + wave; j < c1; j += 8) {      // two candidate rows in flight per wave, one code path (see the f32 kernel)
+#pragma clang fp contract(off)
     const bool two = j + 4 < c1;
     const int64_t r0 = checked_row(cand_idx[j], n_rows, status, lane), r1 = two ? checked_row(cand_idx[j + 4], n_rows, status, lane) : r0;
     const f16_t* p0 = table + r0 * D;
