@@ -122,6 +122,47 @@ def main():
             out[op] = ent
         with open(os.path.join(DST, "tail_pmc.json"), "w") as f:
             json.dump(out, f, indent=1)
+    # ---- A/B of chunk size x store policy (tools/ab_r3.sh times + power, tools/ab_pmc_r3.sh counters)
+    ab = {}
+    for fdir in sorted(glob.glob(os.path.join(SRC, "ab_fetch_*"))):
+        if not os.path.isdir(fdir):
+            continue
+        tag = os.path.basename(fdir)[len("ab_fetch_"):]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), fdir, os.path.join(SRC, "ab_write_" + tag)],
+                           capture_output=True, text=True)
+        if r.returncode == 0 and r.stdout.strip():
+            tj = json.loads(r.stdout)
+            ab[tag] = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": v["WRITE_SIZE_KiB"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                           "launches": v["launches"]} for k, v in tj.items() if isinstance(v, dict) and k.startswith(("gemm_", "attention"))}
+    r3 = os.path.join(ROOT, "gpurun_out", "r3")
+    for path in sorted(glob.glob(os.path.join(r3, "ab_ct*_nt*.json"))):
+        tag = os.path.basename(path)[3:-5]
+        try:
+            with open(path) as f:
+                j = json.loads(f.read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        ent = ab.setdefault(tag, {})
+        ent["candidates_per_s_f16"] = j["value"]
+        ent["encoder_mfma_frac_f16"] = j["encoder_mfma_frac"]
+        ent["candidates_per_s_bf16"] = j["bf16_mode"]["value"]
+        ent["encoder_mfma_frac_bf16"] = j["bf16_mode"]["encoder_mfma_frac"]
+        smi = path[:-5] + ".smi"
+        if os.path.exists(smi):
+            import re
+            txt = open(smi).read()
+            pw = [float(x) for x in re.findall(r"Power \(W\): ([0-9.]+)", txt)]
+            ck = [float(x) for x in re.findall(r"sclk.*?\(([0-9]+)Mhz\)", txt)]
+            if pw:
+                ent["socket_power_W_samples"] = {"n": len(pw), "mean": sum(pw) / len(pw), "max": max(pw)}
+            if ck:
+                ent["sclk_MHz_mean"] = sum(ck) / len(ck)
+    if ab:
+        ab["_note"] = ("tag ct<chunk tokens>_nt<1: non-temporal stores of the streaming Q|K|V / FFN outputs (production), 0: default-policy stores>; "
+                       "times + rocm-smi samples from tools/ab_r3.sh (10 timed steps, both streams), counters from tools/ab_pmc_r3.sh (1 step, one stream; "
+                       "bytes per launch as in pmc_traffic.json — for chunks below 65536 tokens a launch is proportionally smaller)")
+        with open(os.path.join(DST, "ab_chunk_nt.json"), "w") as f:
+            json.dump(ab, f, indent=1)
     tr = one("train/**/*kernel_stats.csv")
     if tr:
         shutil.copy(tr, os.path.join(DST, "train_kernel_stats.csv"))
