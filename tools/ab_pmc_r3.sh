@@ -10,8 +10,11 @@ B="python3 bench.py --warmup 1 --steps 1 --no-cpu --no-kernel-profile --no-table
 for v in "65536 1" "32768 1" "32768 0" "16384 0"; do
   set -- $v
   tag="ct$1_nt$2"
-  MANNER_HIP_NT_STORES=$2 MANNER_HIP_STREAMS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/ab_fetch_$tag -- $B --chunk-tokens $1 > $O/ab_fetch_$tag.log 2>&1
-  MANNER_HIP_NT_STORES=$2 MANNER_HIP_STREAMS=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/ab_write_$tag -- $B --chunk-tokens $1 > $O/ab_write_$tag.log 2>&1
+  MANNER_HIP_NT_STORES=$2 MANNER_HIP_STREAMS=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/ab_fetch_$tag -- $B --chunk-tokens $1 > $O/ab_fetch_$tag.log 2>&1
+  echo "$tag fetch done"
+  MANNER_HIP_NT_STORES=$2 MANNER_HIP_STREAMS=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/ab_write_$tag -- $B --chunk-tokens $1 > $O/ab_write_$tag.log 2>&1
+  # summarise on the box and drop the raw per-dispatch tables (gpurun_out/ travels back only below 64 MiB)
+  python3 tools/pmc_traffic.py $O/ab_fetch_$tag $O/ab_write_$tag > $O/ab_pmc_$tag.json
+  rm -rf $O/ab_fetch_$tag $O/ab_write_$tag
   echo "$tag done"
 done
-find $O -name "*kernel_trace.csv" -size +20M -delete

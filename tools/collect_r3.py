@@ -124,16 +124,15 @@ def main():
             json.dump(out, f, indent=1)
     # ---- A/B of chunk size x store policy (tools/ab_r3.sh times + power, tools/ab_pmc_r3.sh counters)
     ab = {}
-    for fdir in sorted(glob.glob(os.path.join(SRC, "ab_fetch_*"))):
-        if not os.path.isdir(fdir):
+    for path in sorted(glob.glob(os.path.join(SRC, "ab_pmc_*.json"))):
+        tag = os.path.basename(path)[len("ab_pmc_"):-5]
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except Exception:
             continue
-        tag = os.path.basename(fdir)[len("ab_fetch_"):]
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), fdir, os.path.join(SRC, "ab_write_" + tag)],
-                           capture_output=True, text=True)
-        if r.returncode == 0 and r.stdout.strip():
-            tj = json.loads(r.stdout)
-            ab[tag] = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": v["WRITE_SIZE_KiB"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
-                           "launches": v["launches"]} for k, v in tj.items() if isinstance(v, dict) and k.startswith(("gemm_", "attention"))}
+        ab[tag] = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": v["WRITE_SIZE_KiB"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                       "launches": v["launches"]} for k, v in tj.items() if isinstance(v, dict) and k.startswith(("gemm_", "attention"))}
     r3 = os.path.join(ROOT, "gpurun_out", "r3")
     for path in sorted(glob.glob(os.path.join(r3, "ab_ct*_nt*.json"))):
         tag = os.path.basename(path)[3:-5]
