@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_r3
 mkdir -p $O
 B="python3 bench.py --warmup 1 --steps 1 --no-cpu --no-kernel-profile --no-table --no-collate --no-small-ops --no-train --no-dropin"
-for v in "65536 1" "32768 1" "32768 0" "16384 0"; do
+for v in "65536 1" "65536 0" "32768 0"; do
   set -- $v
   tag="ct$1_nt$2"
   MANNER_HIP_NT_STORES=$2 MANNER_HIP_STREAMS=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/ab_fetch_$tag -- $B --chunk-tokens $1 > $O/ab_fetch_$tag.log 2>&1
