@@ -215,6 +215,16 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
     labels = torch.from_numpy(imp["labels"][: co[-1]])
     ref_ndcg, _ = O.ndcg_at_k(ref, labels, co.tolist(), 10)
     ref_top = O.topk_indices(ref, co.tolist(), 10)
+    # labels per NEWS: every occurrence of a news inside an impression gets the mean label of its occurrences, so that the order among
+    # exact ties (repeats of one news) cannot move the metric — the figure a draw without repeats (MIND's own impressions) would give
+    lab_news = imp["labels"][: co[-1]].astype(np.float64).copy()
+    for i in range(nb):
+        a_, e_ = int(co[i]), int(co[i + 1])
+        ids_i = imp["cand_idx"][a_:e_]
+        _, inv_i = np.unique(ids_i, return_inverse=True)
+        lab_news[a_:e_] = (np.bincount(inv_i, weights=lab_news[a_:e_]) / np.bincount(inv_i))[inv_i]
+    lab_news = torch.from_numpy(lab_news.astype(np.float32))
+    ref_ndcg_news, _ = O.ndcg_at_k(ref, lab_news, co.tolist(), 10)
     b = StepBatch(imp, 0, nb, torch.from_numpy(pool_ids).to(dev), torch.from_numpy(pool_mask).to(dev), pool_len, dev)
     bufs = [torch.empty((b.ids.shape[0], cfg.hidden), dtype=torch.float32, device=dev) for _ in encs]
     planes = torch.empty((len(encs), b.n_cand), dtype=torch.float32, device=dev)
@@ -247,7 +257,8 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
                      "top10_identical_frac": agree, "top10_news_identical_frac": agree_news,
                      "max_oracle_gap_of_swapped_neighbours": gap,
                      "max_oracle_gap_in_f32_ulps_of_score": gap / (scale * 2.0 ** -23) if scale > 0 else None,
-                     "ndcg10_delta": float(abs(ndcg.double().mean().item() - ref_ndcg))}
+                     "ndcg10_delta": float(abs(ndcg.double().mean().item() - ref_ndcg)),
+                     "ndcg10_delta_per_news_labels": float(abs(O.ndcg_at_k(sc_cpu, lab_news, co.tolist(), 10)[0] - ref_ndcg_news))}
     par["score_abs_scale"] = float(ref.abs().nan_to_num(0.0).max())
     par["impressions"] = nb
     par["candidates"] = int(co[-1])
@@ -255,7 +266,9 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
     par["what"] = ("every HIP arithmetic mode against the ORACLE (CPU restatement of the reference, mode R) on the same impressions: max |score "
                    "difference|, fraction of impressions whose top-10 list is identical to the oracle's (as candidate positions, and as news ids — "
                    "repeated candidates of the synthetic draw are exact ties that only the oracle's rounding noise orders), |nDCG@10 difference| "
-                   "(positions of one news carry different synthetic labels, so a tie broken the other way moves it)")
+                   "(positions of one news carry different synthetic labels, so a tie broken the other way moves it; "
+                   "`ndcg10_delta_per_news_labels` is the same difference with every occurrence of a news carrying the mean label of its occurrences — "
+                   "the order among exact ties then cannot move it)")
     cpu = {"value": float(c_timed / cpu_s), "unit": "candidates/s", "cores": cores, "kind": "port",
            "cpu_model": model, "cores_how": how, "runs_s": [round(t, 2) for t in times],
            "sample": f"oracle/manner_oracle.py mode R on the first {n_timed} impressions ({news_timed} news encodes x "
@@ -417,6 +430,8 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
     out = {"what": train_leg.__doc__.split("  Batch")[0].strip(), "precision": precision + " GEMM operands, f32 accumulation / activations / gradients",
            "impressions_per_step": impressions, "news_per_step": n_hist + n_cand, "tokens_per_step": tokens, "frozen_layers": list(frozen)}
     for variant, emb_trainable in (("reference_default_embeddings_trainable", True), ("embeddings_frozen_cached_prefix", False)):
+        torch.cuda.reset_peak_memory_stats(dev)
+        resident_before = torch.cuda.memory_allocated(dev)   # what earlier legs left allocated (token pool, step batches): not this leg's
         params = {k: torch.from_numpy(v).to(dev).requires_grad_((emb_trainable or not k.startswith("embeddings.")) and
                                                                    not any(f"layer.{l}." in k for l in frozen)) for k, v in w.items()}
         engine = None if emb_trainable else hip.HipEncoder(cfg, w, precisions=(precision,), device=dev)
@@ -456,7 +471,8 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
                         "tflops_algorithmic": flops / dt / 1e12, "frac_of_mfma_peak": flops / dt / 1e12 / (F32_PEAK_TFLOPS if precision == "fp32" else BF16_PEAK_TFLOPS),
                         "impressions_per_s": impressions / dt, "step_ms_each": [round(x * 1e3, 2) for x in per_step],
                         "loss_first_step": first, "loss_last_step": float(last.detach()),
-                        "peak_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+                        "peak_GB": (torch.cuda.max_memory_allocated(dev) - resident_before) / 1e9,
+                        "resident_from_earlier_legs_GB": resident_before / 1e9}
         if engine is not None:
             engine.close()
         del params, opt

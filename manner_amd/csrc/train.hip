@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
 // grid (ceil(width / 256), COLSUM_BLOCKS): block (x, b) sums 256 columns over the rows b, b + COLSUM_BLOCKS, ...
-constexpr int COLSUM_BLOCKS = 64;
+constexpr int COLSUM_BLOCKS = 256;   // (64 left every thread a chain of ~240 dependent-latency row reads at 15 k tokens)
 template <typename TS>
 __global__ __launch_bounds__(256) void colsum_kernel(const TS* __restrict__ y, int width, float* __restrict__ partial,
                                                      const int* __restrict__ m_total) {
