@@ -96,6 +96,91 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
   }
 }
 
+// D == NCB * 256 (768 and 1024: every PLM the reference ships): a lane holds its NCB 16-byte pieces of a WHOLE row, and a wave
+// keeps RIF rows in flight — in the history sum as well, which in the kernel above issues one dependent 16-byte load per lane at
+// a time (22 history rows = 16 serial round trips to L2 / HBM per wave: the scorer was bound by that latency chain, not by bytes).
+// Row -> wave assignment, the order of every addition and the dot product's association are those of the kernel above: the two
+// produce the same bits (zero rows added for the slots past the end: x + 0 is exact and the sums start at +0).
+template <int NCB, int RIF>
+__global__ __launch_bounds__(256) void score_late_fusion_rows_kernel(
+    const float* __restrict__ table, int64_t n_rows, const int32_t* __restrict__ hist_idx, const int64_t* __restrict__ hist_off,
+    const float* __restrict__ user_in, const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off,
+    float* __restrict__ out, int32_t* __restrict__ status) {
+  constexpr int D = NCB * 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  const int64_t b = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave in an SGPR: the index lists are read by scalar loads
+  float* user = sm + 4 * D;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // RIF rows of one list, all in flight: the RIF indices first (wave-uniform, scalar loads: they do not queue behind the rows'
+  // vector loads), then every 16-byte piece of every row, and only then the first use
+  auto fetch = [&](const int32_t* __restrict__ idx, int64_t j, int64_t end, f32x4 (&x)[RIF][NCB]) {
+    int64_t r[RIF];
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) r[q] = idx[j + 4 * q < end ? j + 4 * q : j];
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) {
+      if (j + 4 * q < end) {                            // wave-uniform
+        const float* p = table + checked_row(r[q], n_rows, status, lane) * D + lane * 4;
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) x[q][k] = *reinterpret_cast<const f32x4*>(p + k * 256);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) x[q][k] = zero;
+      }
+    }
+  };
+  const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
+  f32x4 x[RIF][NCB];                                  // rows in flight: history batches, then candidate batches
+  if (user_in) {
+    if (c0 + wave < c1) fetch(cand_idx, c0 + wave, c1, x);
+    for (int c = threadIdx.x * 4; c < D; c += 1024)
+      *reinterpret_cast<f32x4*>(user + c) = *reinterpret_cast<const f32x4*>(user_in + b * D + c);
+  } else {
+    const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] = zero;
+    for (int64_t j = h0 + wave; j < h1; j += 4 * RIF) {
+      fetch(hist_idx, j, h1, x);
+#pragma unroll
+      for (int q = 0; q < RIF; ++q)
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) acc[k] += x[q][k];
+    }
+    // the first candidate batch does not depend on the user vector: its rows travel while the history sums meet in LDS
+    if (c0 + wave < c1) fetch(cand_idx, c0 + wave, c1, x);
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) *reinterpret_cast<f32x4*>(sm + wave * D + k * 256 + lane * 4) = acc[k];
+    __syncthreads();
+    const float hn = (float)(h1 - h0);
+    for (int c = threadIdx.x; c < D; c += 256)
+      user[c] = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+  }
+  __syncthreads();
+  f32x4 u[NCB];
+#pragma unroll
+  for (int k = 0; k < NCB; ++k) u[k] = *reinterpret_cast<const f32x4*>(user + k * 256 + lane * 4);
+  for (int64_t j = c0 + wave; j < c1; j += 4 * RIF) {
+#pragma clang fp contract(off)                        // every candidate's accumulation must round alike (exact ties stay ties)
+    if (j != c0 + wave) fetch(cand_idx, j, c1, x);
+    float a[RIF];
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) {
+      a[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCB; ++k)
+        a[q] += (x[q][k][0] * u[k][0] + x[q][k][1] * u[k][1]) + (x[q][k][2] * u[k][2] + x[q][k][3] * u[k][3]);
+      a[q] = wave_sum(a[q]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < RIF; ++q)
+        if (j + 4 * q < c1) out[j + 4 * q] = a[q];
+    }
+  }
+}
+
 // The same scorer over an IEEE-half copy of the table (manner_hip_score_late_fusion_f16): rows are 2 D bytes, so the MIND-large
 // table (161 013 x 768) is 247 MB and stays resident in the 256 MiB Infinity Cache while the impressions stream their
 // ~50 row gathers each — with the f32 table (495 MB) the Zipf tail of the gathers re-fetches rows from HBM 15.7 times over.
@@ -162,6 +247,112 @@ __global__ __launch_bounds__(256) void score_late_fusion_f16_kernel(
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1);
     if (lane == 0) { out[j] = a0 + konst; if (two) out[j + 4] = a1 + konst; }
+  }
+}
+
+// D == NCB * 256 over the half table: a row is NCB x 512 bytes = NCB 16-byte pieces for each of 32 lanes, so a wave works on TWO
+// rows at a time (lanes 0-31 / 32-63) with every lane loading 16 bytes per instruction, RIF such pairs in flight — as in the f32
+// kernel above the indices come first (scalar loads), then all pieces of all rows, then the first use.  One code path for every
+// candidate (the two halves run the same instructions on their own lanes): occurrences of one news get identical bits.
+template <int NCB, int RIF>
+__global__ __launch_bounds__(256) void score_late_fusion_f16_rows_kernel(
+    const f16_t* __restrict__ table, int64_t n_rows, const int32_t* __restrict__ hist_idx, const int64_t* __restrict__ hist_off,
+    const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off, float* __restrict__ out, int32_t* __restrict__ status,
+    const float* __restrict__ mu) {
+  constexpr int D = NCB * 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  __shared__ float cpart[4];
+  const int64_t b = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  float* user = sm + 4 * D;
+  // rows j0 + 8 q + 2 wave + half (q < RIF) of one list
+  auto fetch = [&](const int32_t* __restrict__ idx, int64_t j0, int64_t end, f16x8 (&x)[RIF][NCB], bool (&ok)[RIF]) {
+    int64_t r[RIF];
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) {
+      const int64_t ja = j0 + 8 * q + 2 * wave, jb = ja + 1;                   // wave-uniform: scalar loads
+      const int64_t ra = idx[ja < end ? ja : end - 1], rb = idx[jb < end ? jb : end - 1];
+      r[q] = half ? rb : ra;
+      ok[q] = (half ? jb : ja) < end;
+    }
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) {
+      if (ok[q]) {
+        const f16_t* p = table + checked_row(r[q], n_rows, status, hl) * D + hl * 8;
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) x[q][k] = *reinterpret_cast<const f16x8*>(p + k * 256);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NCB; ++k)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[q][k][e] = (f16_t)0.f;
+      }
+    }
+  };
+  const int64_t h0 = hist_off[b], h1 = hist_off[b + 1];
+  const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
+  f16x8 x[RIF][NCB];                                  // rows in flight: history batches, then candidate batches
+  bool ok[RIF];
+  {
+    float acc[NCB][8];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int64_t j0 = h0; j0 < h1; j0 += 8 * RIF) {
+      fetch(hist_idx, j0, h1, x, ok);
+#pragma unroll
+      for (int q = 0; q < RIF; ++q)
+#pragma unroll
+        for (int k = 0; k < NCB; ++k)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[k][e] += (float)x[q][k][e];           // zero rows past the end: x + 0 is exact
+    }
+    // the first candidate batch does not depend on the user vector: its rows travel while the history sums meet in LDS
+    if (c0 < c1) fetch(cand_idx, c0, c1, x, ok);
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[k][e] += __shfl_xor(acc[k][e], 32, 64);   // the wave's two rows-in-progress
+      if (half == 0) {
+        float* d = sm + wave * D + k * 256 + hl * 8;
+        *reinterpret_cast<f32x4*>(d) = f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{acc[k][4], acc[k][5], acc[k][6], acc[k][7]};
+      }
+    }
+  }
+  __syncthreads();
+  const float hn = (float)(h1 - h0);
+  float cp = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float u = ((sm[c] + sm[D + c]) + (sm[2 * D + c] + sm[3 * D + c])) / hn;   // torch.div(sum, hist_size)
+    if (mu) { const float m = mu[c]; u += m; cp = fmaf(u, m, cp); }
+    user[c] = u;
+  }
+  cp = wave_sum(cp);
+  if (lane == 0) cpart[wave] = cp;
+  __syncthreads();
+  const float konst = (cpart[0] + cpart[1]) + (cpart[2] + cpart[3]);          // <w, mu> (0 without centring)
+  f32x4 u0[NCB], u1[NCB];
+#pragma unroll
+  for (int k = 0; k < NCB; ++k) {
+    u0[k] = *reinterpret_cast<const f32x4*>(user + k * 256 + hl * 8);
+    u1[k] = *reinterpret_cast<const f32x4*>(user + k * 256 + hl * 8 + 4);
+  }
+  for (int64_t j0 = c0; j0 < c1; j0 += 8 * RIF) {
+#pragma clang fp contract(off)
+    if (j0 != c0) fetch(cand_idx, j0, c1, x, ok);
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCB; ++k)
+        a += (((float)x[q][k][0] * u0[k][0] + (float)x[q][k][1] * u0[k][1]) + ((float)x[q][k][2] * u0[k][2] + (float)x[q][k][3] * u0[k][3])) +
+             (((float)x[q][k][4] * u1[k][0] + (float)x[q][k][5] * u1[k][1]) + ((float)x[q][k][6] * u1[k][2] + (float)x[q][k][7] * u1[k][3]));
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);              // over the 32 lanes of the row
+      if (hl == 0 && ok[q]) out[j0 + 8 * q + 2 * wave + half] = a + konst;
+    }
   }
 }
 
@@ -511,6 +702,25 @@ __global__ __launch_bounds__(256) void aspect_metrics_kernel(const int32_t* __re
   }
 }
 
+// the fused scorer's launch: whole-row kernels for the widths of the shipped PLMs, the column-block kernel otherwise
+void launch_score(const float* table, int64_t n_rows, int D, const int32_t* hist_idx, const int64_t* hist_off, const float* user,
+                  const int32_t* cand_idx, const int64_t* cand_off, int64_t B, float* out, int32_t* status, hipStream_t s) {
+  const size_t lds = 5 * (size_t)D * sizeof(float);
+  // A/B switch, read per launch (tests flip it): 1 = the column-block kernel for every width.  Two rows in flight per wave: 4 and
+  // 6 measured the same or slower (the CU's vector-memory path is saturated at ~74 GB/s per CU either way) at twice the registers.
+  const char* g = getenv("MANNER_HIP_SCORER_GENERIC");
+  const bool generic = g && atoi(g) != 0;
+  if (D == 768 && !generic)
+    hipLaunchKernelGGL((score_late_fusion_rows_kernel<3, 2>), dim3((unsigned)B), dim3(256), lds, s, table, n_rows, hist_idx, hist_off,
+                       user, cand_idx, cand_off, out, status);
+  else if (D == 1024 && !generic)
+    hipLaunchKernelGGL((score_late_fusion_rows_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds, s, table, n_rows, hist_idx, hist_off,
+                       user, cand_idx, cand_off, out, status);
+  else
+    hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), lds, s, table, n_rows, D, hist_idx, hist_off, user,
+                       cand_idx, cand_off, out, status);
+}
+
 }  // namespace
 }  // namespace manner
 
@@ -525,8 +735,7 @@ int manner_hip_score_late_fusion(const float* table, int64_t n_rows, int32_t D, 
   if (!table || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: null pointer");
   // 5 D floats of dynamic LDS must stay within the 64 KiB a kernel gets without raising its limit
   if (D <= 0 || D % 4 || D > 3072 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_late_fusion: D=%d must be a multiple of 4, <= 3072", D);
-  hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
-                     table, n_rows, D, hist_idx, hist_off, (const float*)nullptr, cand_idx, cand_off, out, status);
+  launch_score(table, n_rows, D, hist_idx, hist_off, nullptr, cand_idx, cand_off, B, out, status, (hipStream_t)stream);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -537,8 +746,18 @@ int manner_hip_score_late_fusion_f16(const void* table16, const float* mean, int
   if (B == 0) return MANNER_HIP_OK;
   if (!table16 || !hist_idx || !hist_off || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: null pointer");
   if (D <= 0 || D % 8 || D > 3072 || n_rows <= 0 || (uintptr_t)table16 % 16) return fail(MANNER_HIP_E_INVALID, "score_late_fusion_f16: D=%d must be a multiple of 8, <= 3072, rows 16-byte aligned", D);
-  hipLaunchKernelGGL(score_late_fusion_f16_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
-                     static_cast<const f16_t*>(table16), n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out, status, mean);
+  const char* g = getenv("MANNER_HIP_SCORER_GENERIC");                       // A/B switch, as in launch_score
+  const bool generic = g && atoi(g) != 0;
+  const f16_t* t16 = static_cast<const f16_t*>(table16);
+  if (D == 768 && !generic)
+    hipLaunchKernelGGL((score_late_fusion_f16_rows_kernel<3, 2>), dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                       t16, n_rows, hist_idx, hist_off, cand_idx, cand_off, out, status, mean);
+  else if (D == 1024 && !generic)
+    hipLaunchKernelGGL((score_late_fusion_f16_rows_kernel<4, 2>), dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                       t16, n_rows, hist_idx, hist_off, cand_idx, cand_off, out, status, mean);
+  else
+    hipLaunchKernelGGL(score_late_fusion_f16_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
+                       t16, n_rows, D, hist_idx, hist_off, cand_idx, cand_off, out, status, mean);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -567,8 +786,7 @@ int manner_hip_score_user(const float* table, int64_t n_rows, int32_t D, const f
   if (B == 0) return MANNER_HIP_OK;
   if (!table || !user || !cand_idx || !cand_off || !out) return fail(MANNER_HIP_E_INVALID, "score_user: null pointer");
   if (D <= 0 || D % 4 || D > 3072 || n_rows <= 0) return fail(MANNER_HIP_E_INVALID, "score_user: D=%d must be a multiple of 4, <= 3072", D);
-  hipLaunchKernelGGL(score_late_fusion_kernel, dim3((unsigned)B), dim3(256), 5 * D * sizeof(float), (hipStream_t)stream,
-                     table, n_rows, D, (const int32_t*)nullptr, (const int64_t*)nullptr, user, cand_idx, cand_off, out, status);
+  launch_score(table, n_rows, D, nullptr, nullptr, user, cand_idx, cand_off, B, out, status, (hipStream_t)stream);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

@@ -707,12 +707,13 @@ def test_scorer_gives_identical_scores_to_repeated_candidates():
     """Exact ties must stay ties: the same news at several candidate positions of an impression (it happens in MIND, and the
     reference's bmm gives both occurrences the same bits) gets BIT-identical scores whatever wave / slot of the kernel handles
     the position — the stable ranking then orders the occurrences by position, as torch.argsort(stable) does.  Candidate counts
-    1 .. 19 put every position into every (wave, first / second row of the pair, lone last row) role."""
+    1 .. 39 put every position into every (wave, half-wave, in-flight slot, first / later batch, past-the-end neighbour) role of
+    the whole-row kernels (f32: 8 positions per batch, f16: 16)."""
     n_news, d = 500, 768
     g = torch.Generator(device="cpu").manual_seed(2)
     table = torch.randn((n_news, d), generator=g).to(DEV)
-    hist_sizes = [3] * 19
-    cand_lists = [[7 if (p % 3 != 1) else 100 + p for p in range(c)] for c in range(1, 20)]
+    hist_sizes = [3] * 39
+    cand_lists = [[7 if (p % 3 != 1) else 100 + p for p in range(c)] for c in range(1, 40)]
     ho = np.concatenate([[0], np.cumsum(hist_sizes)]).astype(np.int64)
     co = np.concatenate([[0], np.cumsum([len(c) for c in cand_lists])]).astype(np.int64)
     hidx = np.arange(int(ho[-1]), dtype=np.int32) % n_news
@@ -727,6 +728,39 @@ def test_scorer_gives_identical_scores_to_repeated_candidates():
         first7 = [p for p, n in enumerate(cand_lists[-1]) if n == 7]
         pos = [int(v) for v in top[-1].cpu().tolist() if v in first7]
         assert pos == sorted(pos)                               # occurrences of one news keep their order
+
+
+def test_whole_row_scorer_kernels_equal_the_column_block_kernel(monkeypatch):
+    """D = 768 / 1024 run the whole-row kernels (several rows in flight per wave, the first candidate batch fetched before the
+    history sums meet in LDS); MANNER_HIP_SCORER_GENERIC=1 forces the column-block kernel they replaced.  Same row -> wave
+    assignment, same order of additions: the f32 scores are BIT-identical, on ragged impressions (1 .. 50 history rows, 0 .. 300
+    candidates) and for the given-user entry; the f16-table kernels sum the history in another order (a few f32 ulp)."""
+    rng = np.random.default_rng(17)
+    for d in (768, 1024):
+        n_news = 3000
+        table = torch.from_numpy(rng.standard_normal((n_news, d)).astype(np.float32)).to(DEV)
+        h = np.concatenate([[1, 50, 4, 5, 16, 17, 33], rng.integers(1, 51, 200)]).astype(np.int64)
+        c = np.concatenate([[1, 300, 0, 8, 9, 16, 17], rng.integers(0, 60, 200)]).astype(np.int64)
+        ho, co = np.concatenate([[0], np.cumsum(h)]).astype(np.int64), np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+        hidx, cidx = rng.integers(0, n_news, int(ho[-1])).astype(np.int32), rng.integers(0, n_news, int(co[-1])).astype(np.int32)
+        args = (_cuda(hidx), _cuda(ho), _cuda(cidx), _cuda(co))
+        user = torch.from_numpy(rng.standard_normal((len(h), d)).astype(np.float32)).to(DEV)
+        t16 = hip.table_to_f16(table, centre=True)
+        monkeypatch.delenv("MANNER_HIP_SCORER_GENERIC", raising=False)
+        rows = hip.score_late_fusion(table, *args), hip.score_user(table, user, args[2], args[3]), hip.score_late_fusion(t16, *args)
+        monkeypatch.setenv("MANNER_HIP_SCORER_GENERIC", "1")
+        cols = hip.score_late_fusion(table, *args), hip.score_user(table, user, args[2], args[3]), hip.score_late_fusion(t16, *args)
+        monkeypatch.delenv("MANNER_HIP_SCORER_GENERIC")
+        assert torch.equal(rows[0], cols[0]) and torch.equal(rows[1], cols[1])
+        assert float((rows[2] - cols[2]).abs().max()) < 4e-6 * float(cols[2].abs().max())
+        # and against float64 on the host
+        tc = table.cpu().double()
+        for i in (0, 1, 2, 3, 50, 206):
+            u = tc[hidx[ho[i]:ho[i + 1]].astype(np.int64)].sum(0) / float(h[i])
+            ref = tc[cidx[co[i]:co[i + 1]].astype(np.int64)] @ u
+            if c[i]:
+                assert float((rows[0][co[i]:co[i + 1]].cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    hip.check_status(DEV)
 
 
 def test_scorer_over_the_f16_table_copy():
