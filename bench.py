@@ -93,6 +93,7 @@ def parse():
     p.add_argument("--no-small-ops", action="store_true", help="skip the pooler / dot / z-score kernel legs")
     p.add_argument("--no-train", action="store_true", help="skip the training-step leg (SURVEY §8f-3)")
     p.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (mirror classes under the unchanged CRModule.forward at B = 8 / 64)")
+    p.add_argument("--dropin-only", default="", help="profiling aid: run only this case of the drop-in leg, e.g. 8:train")
     return p.parse_args()
 
 
@@ -481,7 +482,7 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
 
 
 # --------------------------------------------------------------------------------------------------- drop-in leg
-def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8, 64), iters=8):
+def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8, 64), iters=8, only=""):
     """What a maintainer gets from INTEGRATION.md §2 alone: the UNCHANGED `CRModule.forward` /
     `model_step` call pattern (reference cr_module.py:105-131, 140-171) over the mirror classes — two `news_encoder` calls,
     `to_dense_batch` of both sides, the per-row `torch.where` loop for the history sizes, mean, `DotProduct` on the permuted
@@ -565,6 +566,8 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
     for bs in batch_sizes:
         imp = synth_impressions(bs * (iters + 2), n_pool, seed=900 + bs)
         for mode in ("eval", "train"):
+            if only and only != f"{bs}:{mode}":
+                continue
             batches = [make_batch(imp, k * bs, (k + 1) * bs, mode == "train", g) for k in range(iters + 2)]
             if mode == "eval":
                 enc.eval()
@@ -1127,7 +1130,7 @@ def main():
         log("drop-in leg (mirror classes under the unchanged CRModule.forward, B = 8 and 64, eval + train)")
         for e in encs:
             e.close()
-        result["dropin"] = dropin_leg(cfg, model, weight_sets[0], (pool_ids, pool_mask, pool_len), dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16")
+        result["dropin"] = dropin_leg(cfg, model, weight_sets[0], (pool_ids, pool_mask, pool_len), dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16", only=args.dropin_only)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -266,6 +266,144 @@ int launch(Epilogue epi, const void* X, const void* W, const float* bias, const 
 
 
 // ---------------------------------------------------------------------------------------------
+// Small problems (the training path at the reference's batch size: 8 impressions = 1.5 - 8 k tokens per encoder call): the
+// persistent 256x256 kernel below then has 20 - 90 tiles for 256 CUs and a launch lasts one whole tile — 12 - 48 K-steps plus
+// a 128 KB epilogue, 35 - 90 us — whatever the problem size.  This is the 128x128 kernel above with a DEEPER pipeline instead
+// (4 LDS stages = 128 KiB, one workgroup per CU, K-step kt+3 requested while kt is multiplied: the ~2 us a first-touch DMA takes
+// is spread over three K-steps) and 4x the tiles; 16-bit operands, the training path's two epilogues:
+//   EPI_BIAS          Y = X W^T + bias                          (f32 or 16-bit out)
+//   EPI_BIAS_RES_F32  Y = dropout(X W^T + bias) + R             (f32 residual / out, the counter-based bits of train_common.h)
+// Same K order per output element as the big kernels (k ascending, 16 per MFMA).
+template <typename TIn, typename TOut, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_tn_small_kernel(
+    const TIn* __restrict__ X, const TIn* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles, Drop drop, const int32_t* __restrict__ rowmap) {
+  constexpr int STAGES = 4;
+  constexpr int EPC = 16 / sizeof(TIn);
+  constexpr int BK = ROW_BYTES / sizeof(TIn);
+  __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE_BYTES];
+
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const int M = *m_total;
+  if (mt * BM >= M) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rr = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wm = wave & 1;
+
+  const int srow = lane >> 3, sdst = lane & 7;
+  const TIn* wsrc[4];
+  const TIn* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + srow;
+    const int csrc = sdst ^ ((row >> 1) & 7);
+    wsrc[i] = W + (size_t)(nt * BN + row) * K + csrc * EPC;
+    xsrc[i] = X + (size_t)(mt * BM + row) * K + csrc * EPC;
+  }
+  auto stage = [&](int buf, int k0) {                  // 8 LDS-DMA instructions per wave
+    char* base = lds + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wsrc[i] + k0), LDS_PTR(base + (4 * wave + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xsrc[i] + k0), LDS_PTR(base + TILE_BYTES + (4 * wave + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (rr >> 1) & 7;
+  const int woff = (wn * 64 + rr) * ROW_BYTES;
+  const int xoff = TILE_BYTES + (wm * 64 + rr) * ROW_BYTES;
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nk) stage(s0, s0 * BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    // requested so far: K-steps < min(nk, kt + STAGES - 1); K-step kt must have landed, the younger ones may fly on
+    const int ahead = min(nk, kt + STAGES - 1) - (kt + 1);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces of kt landed; everyone left the stage of kt - 1
+    if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK);
+    const char* base = lds + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int coff = ((2 * kc + h) ^ swz) << 4;
+      typename Frag<TIn>::type a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const typename Frag<TIn>::type*>(base + woff + i * 32 * ROW_BYTES + coff);
+        bb[i] = *reinterpret_cast<const typename Frag<TIn>::type*>(base + xoff + i * 32 * ROW_BYTES + coff);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma_chunk<TIn>(a[i], bb[j], acc[i][j]);
+    }
+  }
+
+  // epilogue: acc[i][j][reg] = D[n][m], n = 32i + (reg&3) + 8(reg>>2) + 4h, m = 32j + rr
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = mt * BM + wm * 64 + 32 * j + rr;
+    if (m >= M) continue;
+    const uint64_t drow = EPI == EPI_BIAS_RES_F32 ? (uint64_t)(rowmap ? rowmap[m] : m) * N : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = nt * BN + wn * 64 + 32 * i + 8 * g + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+        if (EPI == EPI_BIAS_RES_F32) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (size_t)m * N + n0);
+          if (drop.thr != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_bits(drop.seed, drop.site, drow + n0 + e) >= drop.thr ? v[e] * drop.scale : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+        store4<TOut>(Y + (size_t)m * N + n0, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// few 256x256 tiles -> the deep-pipeline 128x128 kernel (A/B: MANNER_HIP_GEMM_SMALL_TILES=0 turns it off, =n moves the threshold)
+bool small_problem(int64_t m_bound, int N) {
+  const char* e = getenv("MANNER_HIP_GEMM_SMALL_TILES");          // read per launch: the tests flip it
+  const int thr = e ? atoi(e) : 128;
+  return (m_bound / 256) * (N / 256) <= thr;
+}
+template <typename TIn, typename TOut, int EPI>
+int launch_small(const void* X, const void* W, const float* bias, const float* R, void* Y, int64_t m_bound, int N, int K,
+                 const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream) {
+  const int n_tiles = N / BN;
+  const int64_t grid = (m_bound / BM) * n_tiles;
+  if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
+  hipLaunchKernelGGL((gemm_tn_small_kernel<TIn, TOut, EPI>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const TIn*>(X),
+                     static_cast<const TIn*>(W), bias, R, static_cast<TOut*>(Y), N, K, m_total, n_tiles, drop, rowmap);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Main kernel: 256(m) x 256(n) tile, 8 waves as 2(m) x 4(n), wave tile 128(m) x 64(n) = 4 x 2 MFMA
 // tiles (128 accumulator VGPRs), BK = 128 bytes, two 64 KiB LDS stages.  Per K-step a wave issues
 // 8 LDS-DMA pieces, 24 ds_read_b128 and 32 MFMAs (the 128x128 kernel above: 8 / 16 / 16), and the
@@ -1291,6 +1429,10 @@ int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, 
                      int K, const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream) {
   if (!is_16bit(in) || m_bound % G_BM || N % G_BN || K < 128 || (K * 2) % ROW_BYTES || !residual)
     return fail(MANNER_HIP_E_INVALID, "gemm_tn_drop_res: m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
+  if (small_problem(m_bound, N) && K % 64 == 0) {
+    if (in == DT_F16) return launch_small<f16_t, float, EPI_BIAS_RES_F32>(X, W, bias, residual, Y, m_bound, N, K, m_total, drop, rowmap, stream);
+    return launch_small<bf16_t, float, EPI_BIAS_RES_F32>(X, W, bias, residual, Y, m_bound, N, K, m_total, drop, rowmap, stream);
+  }
   const int n_tiles = N / G_BN;
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int n_cus = device_cus();
@@ -1320,6 +1462,19 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
     return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_GELU_SPLIT3 needs 16-bit operands and output and 256-tileable shapes");
   if (out != DT_F32 && out != in) return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
+  if (!use_v1 && is_16bit(in) && m_bound % G_BM == 0 && N % G_BN == 0 && K % 64 == 0 && small_problem(m_bound, N) &&
+      (epi == EPI_BIAS || epi == EPI_BIAS_RES_F32)) {
+    const Drop none{0, 0, 0, 1.f};
+    const float* rf = static_cast<const float*>(residual);
+    if (epi == EPI_BIAS_RES_F32) {
+      if (in == DT_F16) return launch_small<f16_t, float, EPI_BIAS_RES_F32>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
+      return launch_small<bf16_t, float, EPI_BIAS_RES_F32>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    }
+    if (in == DT_F16 && out == DT_F16) return launch_small<f16_t, f16_t, EPI_BIAS>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    if (in == DT_F16) return launch_small<f16_t, float, EPI_BIAS>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    if (out == DT_BF16) return launch_small<bf16_t, bf16_t, EPI_BIAS>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    return launch_small<bf16_t, float, EPI_BIAS>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+  }
   if (!use_v1 && m_bound % G_BM == 0 && N % G_BN == 0) {
     static const bool use_x32 = getenv("MANNER_HIP_GEMM_X32") != nullptr;   // A/B: bf16 on the 32x32x16 shape
     if (in == DT_F16 && K >= 128) {

@@ -263,6 +263,40 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   out[c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// The same sum for NARROW outputs (bias / LayerNorm gradients: width <= a few thousand, hundreds of partial rows): the kernel above
+// would run 3 - 12 workgroups, each thread walking all partial rows 4 at a time — ~40 us of dependent round trips per call, 100
+// calls per training step.  Here a workgroup owns 64 columns and splits the partial rows over 16 groups (8 loads in flight each);
+// the 16 group sums meet in LDS and are added in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_partials_narrow_kernel(const float* __restrict__ partial, int blocks, int width,
+                                                                      float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < width) {
+    int b = g;
+    for (; b + 7 * 16 < blocks; b += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(b + 16 * u) * width + c];
+    }
+    for (; b < blocks; b += 16) s[0] += partial[(size_t)b * width + c];
+  }
+  red[g][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (g == 0 && c < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][col];
+    out[c] = t;
+  }
+}
+void reduce_partials(hipStream_t s, const float* partial, int blocks, int64_t width, float* out) {
+  if (width <= 16384 && blocks >= 32)
+    hipLaunchKernelGGL(reduce_partials_narrow_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, s, partial, blocks, (int)width, out);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, s, partial, blocks, (int)width, out);
+}
+
 // partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
 // grid (ceil(width / 256), COLSUM_BLOCKS): block (x, b) sums 256 columns over the rows b, b + COLSUM_BLOCKS, ...
 constexpr int COLSUM_BLOCKS = 256;   // (64 left every thread a chain of ~240 dependent-latency row reads at 15 k tokens)
@@ -957,7 +991,7 @@ struct Ctx {
   // matrix pipe (train_attn.hip).  MANNER_HIP_TRAIN_ATTN_VALU=1 keeps the f32 VALU kernels for A/B; the fp32 mode always uses them.
   bool mfma_attn() const {
     static const bool valu = getenv("MANNER_HIP_TRAIN_ATTN_VALU") != nullptr;
-    return dt() != DT_F32 && !valu;
+    return dt() != DT_F32 && !valu && c->hidden == c->heads * 64;          // the MFMA kernels are written for head_dim 64
   }
   unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
 };
@@ -1049,7 +1083,7 @@ int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt,
                                   (int64_t)Nout * K, Nout, K, (int)ks, t.wk.dims + dim_slot, t.s)))
         return rc;
       const int64_t width = (int64_t)Nout * K;
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.dwp, slices, (int)width, dW);
+      reduce_partials(t.s, t.wk.dwp, slices, width, dW);
       MANNER_LAUNCH_CHECK();
       return MANNER_HIP_OK;
     }
@@ -1066,7 +1100,7 @@ int bias_grad(Ctx& t, const void* dY, DType dy_dt, int width, float* db) {
   else if (dy_dt == DT_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, g, b, 0, t.s, static_cast<const f16_t*>(dY), width, t.wk.part, t.sv.m_total);
   else hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, t.s, static_cast<const bf16_t*>(dY), width, t.wk.part, t.sv.m_total);
   MANNER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, t.s, t.wk.part, COLSUM_BLOCKS, width, db);
+  reduce_partials(t.s, t.wk.part, COLSUM_BLOCKS, width, db);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -1107,9 +1141,9 @@ int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap);
   MANNER_LAUNCH_CHECK();
   if (dgamma) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, t.s, pg, LN_BWD_BLOCKS, H, dgamma);
+    reduce_partials(t.s, pg, LN_BWD_BLOCKS, H, dgamma);
     MANNER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, t.s, pb, LN_BWD_BLOCKS, H, dbeta);
+    reduce_partials(t.s, pb, LN_BWD_BLOCKS, H, dbeta);
     MANNER_LAUNCH_CHECK();
   }
   return MANNER_HIP_OK;

@@ -133,6 +133,42 @@ def test_train_mixed_precision_tracks_fp32(precision):
         assert cos > (0.999 if precision == "f16" else 0.99), (k, cos)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_small_problem_gemm_equals_the_persistent_kernel(precision, monkeypatch):
+    """Few 256x256 tiles (the reference's batch of 8 impressions): the training GEMMs run the deep-pipeline 128x128 kernel
+    (gemm_tn_small_kernel: EPI_BIAS with f32 / 16-bit output, EPI_BIAS_RES_F32 with the dropout bits and the f32 residual);
+    MANNER_HIP_GEMM_SMALL_TILES=0 sends the same calls through the persistent 256x256 kernel.  Same operands, same K order, the
+    same dropout masks (they are a function of seed, site and element index, not of the kernel): outputs and every gradient agree
+    to the f32 rounding of a different MFMA shape — including rows past the real token count, which neither kernel may write."""
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=71, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(37, cfg, seed=71, max_len=48)          # ~1 k tokens: 5 row panels of 256, not a multiple
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(4).standard_normal((37, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for tiles in ("0", None):
+        if tiles is None:
+            monkeypatch.delenv("MANNER_HIP_GEMM_SMALL_TILES", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", tiles)
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=5)
+        (out * R).sum().backward()
+        res[tiles] = (out.detach().cpu().numpy(), _grads(params))
+    monkeypatch.delenv("MANNER_HIP_GEMM_SMALL_TILES", raising=False)
+    a, b = res[None], res["0"]
+    assert np.isfinite(a[0]).all() and np.abs(a[0] - b[0]).max() < 2e-3 * max(1.0, np.abs(b[0]).max())
+    for k, g in b[1].items():
+        if g is None:
+            assert a[1][k] is None
+            continue
+        x, y = a[1][k].ravel().astype(np.float64), g.ravel().astype(np.float64)
+        if np.abs(y).max() < 1e-7:
+            continue
+        cos = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
+        assert cos > 0.9995 and abs(np.linalg.norm(x) / np.linalg.norm(y) - 1.0) < 5e-3, (k, cos)
+
+
 def test_train_from_cached_frozen_prefix():
     """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
     starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""bench.py's training-step leg alone, for a rocprofv3 pass that sees nothing else.  Development aid.
+
+    python tools/train_probe.py [bf16|f16|fp32]"""
+import json
+import os
+import sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from manner_amd.config import PRESETS  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+out = bench.train_leg(PRESETS["bert-base-uncased"], torch.device("cuda", 0), prec)
+print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "step_ms_each", "peak_GB")} if isinstance(v, dict) else v)
+                  for k, v in out.items() if k != "what"}))
