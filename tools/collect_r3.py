@@ -67,7 +67,7 @@ def main():
             if c in cs and len(cs[c]) == n:
                 per_class[cls][c] += [cs[c][i] for i in keep]
         per_class[cls]["_kernel"] = [kname[:100]]
-    with open(os.path.join(DST, "sq_counters.csv"), "w", newline="") as f:
+    with open(os.path.join(DST, "sq_counters.csv") if per_class else os.devnull, "w", newline="") as f:   # a tail-only session keeps the old file
         w = csv.writer(f)
         w.writerow(["class", "kernel", "launches_kept"] + names + ["wait_any_frac", "wait_inst_any_frac", "active_inst_any_frac",
                                                                    "mfma_busy_cycles_per_wave_quadcycle", "lds_conflict_per_lds_inst"])
@@ -91,7 +91,7 @@ def main():
             with open(ts, newline="") as f:
                 for r in csv.DictReader(f):
                     dur[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
-        kmap = {"score_late_fusion": ["score_late_fusion_kernel"], "score_late_fusion_f16": ["score_late_fusion_f16_kernel"], "additive_pool": ["pool_logits_kernel", "pool_apply_kernel"],
+        kmap = {"score_late_fusion": ["score_late_fusion_rows_kernel"], "score_late_fusion_f16": ["score_late_fusion_f16_rows_kernel"], "additive_pool": ["pool_logits_kernel", "pool_apply_kernel"],
                 "dot": ["dot_rows_kernel"], "zscore_fuse": ["zscore_fuse_kernel"], "to_dense": ["to_dense_rows_kernel"]}
         out = {"_note": "bytes: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (KiB counters, gfx950 64-byte correction of wide reads, "
                         "MI355X_MICROARCH.md); durations from the --stats pass of the same script; algorithmic bytes from tools/tail_probe.py"}
@@ -99,7 +99,7 @@ def main():
             ent = dict(probe.get(op, {}))
             tot_bytes, tot_us = 0.0, 0.0
             for k in kernels:
-                match = lambda n: k in n and not (k == "score_late_fusion_kernel" and "f16" in n)   # noqa: E731
+                match = lambda n: k in n   # noqa: E731
                 fk = [v for n, v in fetch.items() if match(n)]
                 wk = [v for n, v in write.items() if match(n)]
                 dk = [v for n, v in dur.items() if match(n)]
