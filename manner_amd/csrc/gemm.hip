@@ -768,6 +768,9 @@ struct DlnAux {
   uint32_t drop_site, drop_thr;
   float drop_scale;
   const int32_t* drop_rowmap;
+  // A/B (MANNER_HIP_GEMM_STAGGER=n): row panel p starts (p % 4) * n sleeps of ~2 us late, so that the workgroups of a launch do
+  // not all reach their epilogue — a burst of 128 KB reads + 128 KB writes per CU — at the same moment
+  int stagger;
 };
 
 template <typename TE, typename TOut, int EPI, int ABL = 0>
@@ -809,6 +812,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   };
   int t = slot;
   if (t >= valid_tiles) return;
+  if (dln.stagger > 0) {
+    const int phase = (slot / n_tiles) & 3;
+    for (int i = 0; i < phase * dln.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int kl15 = lane & 15, klq = lane >> 4;        // K-loop copies (the epilogue recomputes its own)
@@ -1397,6 +1404,8 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   dim3 g((unsigned)(tiles < cus ? tiles : cus));
   static const bool plain_stores = getenv("MANNER_HIP_NT_STORES") && atoi(getenv("MANNER_HIP_NT_STORES")) == 0;   // A/B switch
   DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
+  static const int stagger = getenv("MANNER_HIP_GEMM_STAGGER") ? atoi(getenv("MANNER_HIP_GEMM_STAGGER")) : 0;   // A/B switch
+  aux.stagger = stagger;
   if (dt == DT_F16) return launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
   return launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
 }
