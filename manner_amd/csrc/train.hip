@@ -1074,6 +1074,23 @@ int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt,
     const int64_t max_slices = t.Mb / 128;
     if (slices > max_slices) slices = (int)max_slices;
     if (slices > WGRAD_MAX_SLICES) slices = WGRAD_MAX_SLICES;
+    if (slices < 1) slices = 1;
+    const char* tr_env = getenv("MANNER_HIP_WGRAD_TR");                 // A/B switch, read per call (the tests flip it)
+    if (!tr_env || atoi(tr_env) != 0) {
+      // No transposed copies: the row-major 16-bit operands go to LDS as they are and the MFMA fragments are read transposed
+      // (wgrad.hip).  An f32 source is converted (no transposition) first.
+      const int64_t ks = round_up((t.Mb + slices - 1) / slices, 64);
+      const void* dy16 = dY;
+      const void* x16 = X;
+      if (dy_dt == DT_F32) { if ((rc = convert_f32_to_16(t.dt(), static_cast<const float*>(dY), t.wk.a16, t.Mb * Nout, t.s))) return rc; dy16 = t.wk.a16; }
+      if (x_dt == DT_F32) { if ((rc = convert_f32_to_16(t.dt(), static_cast<const float*>(X), t.wk.b16, t.Mb * K, t.s))) return rc; x16 = t.wk.b16; }
+      if ((rc = wgrad_tr(t.dt(), dy16, x16, slices >= 2 ? t.wk.dwp : dW, Nout, K, slices, ks, t.sv.m_total, t.wk.zero, t.s))) return rc;
+      if (slices >= 2) {
+        reduce_partials(t.s, t.wk.dwp, slices, (int64_t)Nout * K, dW);
+        MANNER_LAUNCH_CHECK();
+      }
+      return MANNER_HIP_OK;
+    }
     if (slices >= 2) {
       const int64_t ks = round_up((t.Mb + slices - 1) / slices, 64), Mp = ks * slices;
       if ((rc = transpose_to(t, dY, dy_dt, t.Mb, Nout, t.wk.a16, Mp, t.sv.m_total, 0, ks))) return rc;     // [slices][Nout, ks]

@@ -51,4 +51,9 @@ int attn_train_mfma_backward(DType dt, const void* qkv16, const float* dctx, con
                              void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H, int max_len,
                              Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream);
 
+// wgrad.hip: out [slices][N, K] f32 = per-slice sums over token rows of dY[m, :]^T X[m, :] (row-major 16-bit operands read
+// transposed from LDS; slices == 1 writes dW itself); N, K % 256 == 0, rows_per_slice % 32 == 0, zero_page >= 16 zero bytes
+int wgrad_tr(DType dt, const void* dY, const void* X, float* out, int N, int K, int slices, int64_t rows_per_slice,
+             const int* m_total, const void* zero_page, hipStream_t stream);
+
 }  // namespace manner

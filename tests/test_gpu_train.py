@@ -169,6 +169,39 @@ def test_small_problem_gemm_equals_the_persistent_kernel(precision, monkeypatch)
         assert cos > 0.9995 and abs(np.linalg.norm(x) / np.linalg.norm(y) - 1.0) < 5e-3, (k, cos)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("n_news,max_len", [(37, 48), (300, 40), (5, 12)])
+def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, n_news, max_len, monkeypatch):
+    """Weight gradients dW = dY^T X: wgrad.hip reads the row-major 16-bit operands transposed from LDS (ds_read_b64_tr_b16);
+    MANNER_HIP_WGRAD_TR=0 keeps the older path (two transposing copies + the K-contiguous GEMM).  Same rounded operands, f32
+    accumulation on the matrix pipe in both: the gradients agree to summation order — for token counts that end inside a 32-row
+    stage, inside a slice, below one slice (5 news), and with rows past the token count holding whatever the buffers held."""
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=72, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=72 + n_news, max_len=max_len)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(5).standard_normal((n_news, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for tr in ("0", None):
+        if tr is None:
+            monkeypatch.delenv("MANNER_HIP_WGRAD_TR", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_WGRAD_TR", tr)
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=6)
+        (out * R).sum().backward()
+        res[tr] = (out.detach().cpu().numpy(), _grads(params))
+    monkeypatch.delenv("MANNER_HIP_WGRAD_TR", raising=False)
+    assert np.array_equal(res[None][0], res["0"][0])                      # the forward does not depend on the switch
+    for k, g in res["0"][1].items():
+        if g is None:
+            assert res[None][1][k] is None
+            continue
+        x, y = res[None][1][k].astype(np.float64), g.astype(np.float64)
+        assert np.isfinite(x).all(), k
+        assert np.abs(x - y).max() <= 1e-4 * max(np.abs(y).max(), 1e-6), (k, np.abs(x - y).max(), np.abs(y).max())
+
+
 def test_train_from_cached_frozen_prefix():
     """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
     starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""
