@@ -170,13 +170,16 @@ def test_small_problem_gemm_equals_the_persistent_kernel(precision, monkeypatch)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-@pytest.mark.parametrize("n_news,max_len", [(37, 48), (300, 40), (5, 12)])
-def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, n_news, max_len, monkeypatch):
+@pytest.mark.parametrize("arch,n_news,max_len", [("mini-roberta-large", 37, 48), ("mini-roberta-large", 300, 40), ("mini-roberta-large", 5, 12),
+                                                  ("bert-base-uncased", 120, 64)])
+def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, arch, n_news, max_len, monkeypatch):
     """Weight gradients dW = dY^T X: wgrad.hip reads the row-major 16-bit operands transposed from LDS (ds_read_b64_tr_b16);
     MANNER_HIP_WGRAD_TR=0 keeps the older path (two transposing copies + the K-contiguous GEMM).  Same rounded operands, f32
     accumulation on the matrix pipe in both: the gradients agree to summation order — for token counts that end inside a 32-row
-    stage, inside a slice, below one slice (5 news), and with rows past the token count holding whatever the buffers held."""
-    cfg = PRESETS["mini-roberta-large"]
+    stage, inside a slice, below one slice (5 news), and with rows past the token count holding whatever the buffers held; H = 1024
+    (4 / 12 / 16 column tiles) and the bert-base widths (3 / 9 / 12 column tiles, two layers of the architecture)."""
+    import dataclasses
+    cfg = PRESETS[arch] if arch.startswith("mini") else dataclasses.replace(PRESETS[arch], layers=2)
     w = make_plm_weights(cfg, seed=72, std=0.03, with_pooler=False)
     ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=72 + n_news, max_len=max_len)
     ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)

@@ -12,6 +12,14 @@ import bench  # noqa: E402
 from manner_amd.config import PRESETS  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+if os.environ.get("TRAIN_PROBE_NODROP"):            # what the counter-based dropout bits cost: the same step with every p = 0
+    from manner_amd import train as _T
+    _orig = _T.encode_train
+
+    def _nodrop(*a, **k):
+        k.update(p_hidden=0.0, p_attn=0.0, p_out=0.0)
+        return _orig(*a, **k)
+    _T.encode_train = _nodrop
 out = bench.train_leg(PRESETS["bert-base-uncased"], torch.device("cuda", 0), prec)
 print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "step_ms_each", "peak_GB")} if isinstance(v, dict) else v)
                   for k, v in out.items() if k != "what"}))
