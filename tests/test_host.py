@@ -426,3 +426,27 @@ def test_training_buffer_sizes_follow_the_documented_rule():
         for b in parts:
             want_s = up(want_s) + b
         assert int(lib.manner_hip_train_saved_bytes(C.byref(_cfg_c(cfg)), n, mb, 0)) == want_s + 256, preset
+
+
+def test_every_environment_switch_is_documented():
+    """The library's A/B switches are read with getenv() in csrc/ and os.environ in the package: each one has a line in DESIGN.md
+    (the table of switches in section 4) or INTEGRATION.md, so that a measured alternative cannot hide in the build."""
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for root, _, files in os.walk(os.path.join(ROOT, "manner_amd")):
+        if "lib" in root.split(os.sep) or "__pycache__" in root:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".h", ".py")):
+                with open(os.path.join(root, f), encoding="utf-8") as fh:
+                    txt = fh.read()
+                names |= set(re.findall(r'getenv\("(MANNER_[A-Z0-9_]+)"', txt))
+                names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(MANNER_[A-Z0-9_]+)"', txt))
+    assert len(names) >= 10
+    with open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8") as fh:
+        docs = fh.read()
+    with open(os.path.join(ROOT, "INTEGRATION.md"), encoding="utf-8") as fh:
+        docs += fh.read()
+    missing = sorted(n for n in names if n not in docs)
+    assert not missing, missing
