@@ -643,8 +643,8 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     lo, hi = shards[rank]
     mx_rows = max(h - l for l, h in shards)
     imp = synth_impressions(n_imp, n_news, seed=43)
-    a, b = shard_range(n_imp, rank, world)
     ho, co = imp["hist_off"], imp["cand_off"]
+    a, b = D.balanced_impression_shards(ho, co, world)[rank]    # equal history + candidate occurrences per rank (SURVEY §8e phase C)
     dimp = {"hist_idx": torch.from_numpy(imp["hist_idx"][ho[a]:ho[b]]).to(dev), "hist_off": torch.from_numpy(ho[a:b + 1] - ho[a]).to(dev),
             "cand_idx": torch.from_numpy(imp["cand_idx"][co[a]:co[b]]).to(dev), "cand_off": torch.from_numpy(co[a:b + 1] - co[a]).to(dev)}
     labels = torch.from_numpy(imp["labels"][co[a]:co[b]]).to(dev)

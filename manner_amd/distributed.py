@@ -142,6 +142,22 @@ class MeshTableGather:
         return self.table
 
 
+def balanced_impression_shards(hist_off: np.ndarray, cand_off: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) blocks of impressions with (nearly) equal scorer work sum(h_i + c_i) per rank (SURVEY.md §8e,
+    phase C): the fused scorer reads one table row per history / candidate occurrence, so occurrences — not impressions — are
+    what a rank's time is proportional to.  Every impression lands in exactly one block; blocks may be empty only when there
+    are fewer impressions than ranks."""
+    n = int(len(hist_off)) - 1
+    work = (np.asarray(hist_off[1:], dtype=np.int64) - int(hist_off[0])) + (np.asarray(cand_off[1:], dtype=np.int64) - int(cand_off[0]))
+    total = int(work[-1]) if n > 0 else 0
+    cuts = [0]
+    for r in range(1, world_size):
+        cut = int(np.searchsorted(work, total * r / world_size, side="left")) + 1 if n > 0 else 0   # first impression that crosses the mark stays left
+        cuts.append(min(max(cut, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
 def impression_shard(n_impressions: int) -> Tuple[int, int]:
     rank, ws = world()
     return shard_range(n_impressions, rank, ws)

@@ -450,3 +450,22 @@ def test_every_environment_switch_is_documented():
         docs += fh.read()
     missing = sorted(n for n in names if n not in docs)
     assert not missing, missing
+
+
+def test_impression_blocks_are_balanced_by_occurrences():
+    """SURVEY §8e phase C: ranks score contiguous impression blocks of equal sum(h_i + c_i).  Every impression lands in exactly one
+    block, blocks are ordered, and the heaviest rank is within one impression's work of the mean; degenerate inputs (fewer
+    impressions than ranks, none at all) give empty blocks, never an index outside the list."""
+    from manner_amd.distributed import balanced_impression_shards
+    from manner_amd.synth import synth_impressions
+    imp = synth_impressions(5000, 3000, seed=4)
+    ho, co = imp["hist_off"], imp["cand_off"]
+    per = np.diff(ho) + np.diff(co)
+    for w in (1, 2, 3, 8, 64):
+        sh = balanced_impression_shards(ho, co, w)
+        assert len(sh) == w and sh[0][0] == 0 and sh[-1][1] == 5000
+        assert all(sh[r][1] == sh[r + 1][0] for r in range(w - 1)) and all(a <= b for a, b in sh)
+        work = np.array([per[a:b].sum() for a, b in sh])
+        assert work.sum() == per.sum() and work.max() <= per.sum() / w + per.max()
+    assert balanced_impression_shards(np.array([0, 3]), np.array([0, 5]), 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+    assert balanced_impression_shards(np.array([0]), np.array([0]), 2) == [(0, 0), (0, 0)]
