@@ -18,19 +18,20 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 cfg = PRESETS["bert-base-uncased"]
 dev = torch.device("cuda", 0)
-ids, mask = synth_news_tokens(n, cfg, seed=42, max_len=96, profile="title")
+ids, mask = synth_news_tokens(n, cfg, seed=42, max_len=96, profile="title_abstract")
+lens = mask.sum(1)                                  # host lengths: full 65 536-token chunks, as in bench.py's table mode
 ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
 w = make_plm_weights(cfg, seed=42, std=0.02, with_pooler=False)
 os.environ["MANNER_HIP_STREAMS"] = "1"
 out = {}
 for prec in ("f16", mode):
     enc = hip.HipEncoder(cfg, w, precisions=(prec,), device=dev)
-    enc.encode_cls(ids, mask, precision=prec)
+    enc.encode_cls(ids, mask, precision=prec, host_lengths=lens)
     torch.cuda.synchronize()
     enc.profile(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
-    enc.encode_cls(ids, mask, precision=prec)
+    enc.encode_cls(ids, mask, precision=prec, host_lengths=lens)
     ev[1].record()
     torch.cuda.synchronize()
     prof = enc.profile_read()
