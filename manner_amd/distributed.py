@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -92,7 +94,9 @@ class MeshTableGather:
         self._works: list = []
         # gloo has no point-to-point transfers of GPU tensors (the one-GPU rehearsal of the multi-rank logic): the pieces are
         # then exchanged by ONE all_gather of equal blocks in wait() — same table, no overlap.  RCCL ("nccl") runs the mesh.
-        self._collective_fallback = self.ws > 1 and self._cuda and dist.get_backend() != "nccl"
+        # MANNER_TABLE_EXCHANGE=collective forces that path on RCCL too (one all_gather_into_tensor after the encoding).
+        self._collective_fallback = self.ws > 1 and ((self._cuda and dist.get_backend() != "nccl") or
+                                                     os.environ.get("MANNER_TABLE_EXCHANGE", "mesh") == "collective")
 
     def piece_rows(self, rank: int, c: int) -> Tuple[int, int]:
         """Table rows [a, b) of piece ``c`` of rank ``rank``'s shard (the same split on every rank)."""
