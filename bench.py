@@ -727,7 +727,8 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
                   "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
     st = torch.tensor([times["encode_s"], times["allgather_s"], times["score_s"], times["total_s"], mesh_s or 0.0, coll_s or 0.0],
                       dtype=torch.float64, device=dev)
-    nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a)], dtype=torch.float64, device=dev)
+    _, ndcg5 = hip.rank_ndcg(sc_r, labels, off_r, 5)                                   # SURVEY §8e phase D: (sum nDCG@10, sum nDCG@5, count)
+    nd = torch.tensor([float(res["ndcg"].double().sum()), float(b - a), float(ndcg5.double().sum())], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
         D.allreduce_metric_sums(nd)
@@ -763,7 +764,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
            "allgather_GBps_per_rank": (recv_bytes / mesh_s / 1e9) if world > 1 and mesh_s > 0 else None,
            "allgather_frac_of_xgmi": (recv_bytes / mesh_s / 1e9 / (7 * 153.0)) if world > 1 and mesh_s > 0 else None,
            "world_size_seen": world,
-           "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(),
+           "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(), "ndcg5": nd[2].item() / nd[1].item(),
            "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
                                 "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}
     parity = None
