@@ -18,6 +18,8 @@
 // supplies cached hidden states of a frozen prefix).
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 #include "train_common.h"
 
@@ -989,10 +991,11 @@ struct Ctx {
   Out16 o16(void* p) const { return (p && dt() != DT_F32) ? Out16{p, (int)dt()} : Out16{nullptr, 0}; }
   // 16-bit modes: Q | K | V are kept in the 16-bit type (the f32 slot of the saved buffer, half used) and the attention runs on the
   // matrix pipe (train_attn.hip).  MANNER_HIP_TRAIN_ATTN_VALU=1 keeps the f32 VALU kernels for A/B; the fp32 mode always uses them.
-  bool mfma_attn() const {
-    static const bool valu = getenv("MANNER_HIP_TRAIN_ATTN_VALU") != nullptr;
-    return dt() != DT_F32 && !valu && c->hidden == c->heads * 64;          // the MFMA kernels are written for head_dim 64
-  }
+  // ONE decision per forward, made in setup() (`choose_attn_path`: environment read per call, "full rows" excluded: they need the key
+  // length mask) and RECORDED against the saved buffer; the backward reads the record instead of re-deriving it, because the layout
+  // of L.qkv (16-bit or f32) follows from it.
+  bool attn_mfma = false;
+  bool mfma_attn() const { return attn_mfma; }
   unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
 };
 
@@ -1211,6 +1214,26 @@ int pack_qkv_weights(Ctx& t, int l, void* w16 = nullptr) {
   return MANNER_HIP_OK;
 }
 
+// attention path of a training forward: 1 = matrix pipe with 16-bit Q | K | V (train_attn.hip), 0 = f32 VALU kernels.  The forward
+// records its choice per saved buffer; the backward of the same buffer looks it up (falls back to the rule for a buffer it has
+// never seen, e.g. one produced by another process image).
+static std::mutex g_attn_mu;
+static std::unordered_map<const void*, int> g_attn_path;
+static bool choose_attn_path(const manner_hip_encoder_config* c, int32_t precision, bool full) {
+  const char* v = getenv("MANNER_HIP_TRAIN_ATTN_VALU");                    // read per call: tests compare both paths in one process
+  const bool valu = v && *v && *v != '0';
+  return precision != MANNER_HIP_PREC_F32 && !valu && !full && c->hidden == c->heads * 64;   // the MFMA kernels are written for head_dim 64
+}
+static void record_attn_path(const void* saved, bool mfma) {
+  std::lock_guard<std::mutex> g(g_attn_mu);
+  g_attn_path[saved] = mfma ? 1 : 0;
+}
+static bool recorded_attn_path(const void* saved, bool rule) {
+  std::lock_guard<std::mutex> g(g_attn_mu);
+  auto it = g_attn_path.find(saved);
+  return it == g_attn_path.end() ? rule : it->second != 0;
+}
+
 int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, int64_t N, int64_t Lp, int64_t Mb,
           int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s) {
   int rc;
@@ -1246,7 +1269,7 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   const int H = cfg->hidden, I = cfg->intermediate;
   hipStream_t s = t.s;
   const bool mixed = t.dt() != DT_F32;
-  const bool mfma = t.mfma_attn() && !klen;
+  const bool mfma = t.mfma_attn();
   if ((rc = pack_qkv_weights(t, l, mfma ? t.wk.b16 : nullptr))) return rc;
   const Drop da_m = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
   if (mfma) {
@@ -1445,6 +1468,8 @@ static int train_forward_impl(const manner_hip_encoder_config* cfg, const float*
                   workspace_bytes, s)))
     return rc;
   if (!ids || !mask || !cls_out) return fail(MANNER_HIP_E_INVALID, "train_forward: null pointer");
+  t.attn_mfma = choose_attn_path(cfg, precision, full);
+  record_attn_path(saved, t.attn_mfma);
   if ((start_layer > 0) != (prefix_hidden != nullptr))
     return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
   for (float p : {p_hidden, p_attn, p_out})
@@ -1509,6 +1534,8 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
                   workspace_bytes, s)))
     return rc;
   if (!ids || !grad_cls || !grads) return fail(MANNER_HIP_E_INVALID, "train_backward: null pointer");
+  t.attn_mfma = recorded_attn_path(saved, choose_attn_path(cfg, precision, full));      // what the forward of this buffer chose
+  if (t.attn_mfma && (precision == MANNER_HIP_PREC_F32 || full)) return fail(MANNER_HIP_E_INVALID, "train_backward: the forward of this saved buffer ran another precision / row layout");
   if (grad_prefix && start_layer == 0) return fail(MANNER_HIP_E_INVALID, "train_backward: grad_prefix goes with start_layer > 0");
   const int H = cfg->hidden, I = cfg->intermediate;
   Saved& sv = t.sv;
@@ -1615,7 +1642,7 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
       return rc;
     }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
-    if (t.mfma_attn() && !full) {
+    if (t.mfma_attn()) {
       // matrix-pipe backward: D = dctx . ctx and the 16-bit copy of dctx (wk.h16a is free in the backward), then d q and d k / d v
       if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.big16, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
                                          (int)padded_len, da, m_bound, sv.m_total, s)))

@@ -75,11 +75,16 @@ class _FlagRing:
         self._pending.append((i, ev))
 
     def completed(self, wait: bool = False) -> int:
+        """OR of the finished snapshots.  ``wait``: block for all of them.  Otherwise every snapshot EXCEPT the newest is waited for
+        (those copies were enqueued at least one call earlier — behind work the device has long finished or is about to —
+        so a raised bit surfaces at the call after next at the latest instead of "whenever the event happens to have completed");
+        the newest is taken only if it has already completed, so the host still runs one call ahead of the device."""
         flag, keep = 0, []
-        for i, ev in self._pending:
-            if wait:
+        last = len(self._pending) - 1
+        for j, (i, ev) in enumerate(self._pending):
+            if wait or j < last:
                 ev.synchronize()
-            if wait or ev.query():
+            if wait or j < last or ev.query():
                 flag |= int(self._host[i])
             else:
                 keep.append((i, ev))
@@ -90,9 +95,9 @@ class _FlagRing:
 class DeviceStatus:
     """The int32 status word the scoring kernels raise bits in (``MANNER_HIP_STATUS_*``) where the reference would
     raise an exception (an out-of-range table index).  ``check()`` is blocking; ``poll()`` never is: every ``arm()``
-    enqueues a copy of the word into pinned host memory and an event, and ``poll()`` raises for the snapshots whose
-    event has completed — so a bad batch surfaces at the next call at the latest, without a host synchronisation on
-    the fast path."""
+    enqueues a copy of the word into pinned host memory and an event, and ``poll()`` raises for the snapshots that have
+    completed, waiting for every one but the newest — so a bad batch surfaces at the next call when the device has kept up,
+    at the call after next at the latest, and the host never waits for the call it has just enqueued."""
 
     def __init__(self, device: torch.device):
         self.device = device
@@ -143,8 +148,9 @@ def check_status(device=None) -> None:
 def status_poll(device) -> None:
     """Non-blocking: raise for every armed snapshot of ``device``'s status word whose copy has completed.  The composed
     entry points (hotpath.*, train.encode_train, the module mirrors) call this on the way in and ``status_arm`` on the
-    way out, so an out-of-range index / a token_bound below the mask's token count surfaces at the NEXT call at the
-    latest — without a host synchronisation on the fast path (``check_status`` is the blocking form)."""
+    way out, so an out-of-range index / a token_bound below the mask's token count surfaces at the next call when the device
+    has kept up and at the call AFTER next at the latest (every snapshot but the newest is waited for) — the host still runs one
+    call ahead of the device; ``check_status`` is the blocking form, to be called when a loop ends (epoch end)."""
     device_status(device).poll()
 
 

@@ -56,12 +56,20 @@ def synth_news_tokens(n: int, cfg: EncoderConfig, seed: int = 42, max_len: int =
 
 
 def synth_impressions(n_imp: int, n_news: int, seed: int = 42, max_hist: int = 50,
-                      max_cand: int = 300, zipf_a: float = 1.1) -> Dict[str, np.ndarray]:
+                      max_cand: int = 300, zipf_a: float = 1.1, distinct_candidates: bool = True) -> Dict[str, np.ndarray]:
     """Ragged impressions over a news pool: hist/cand CSR offsets (int64 [B+1]), int32 indices
-    and float32 labels (1 positive + Bernoulli(0.04) extras, >= 1 positive per impression)."""
+    and float32 labels (1 positive + Bernoulli(0.04) extras, >= 1 positive per impression).
+
+    ``distinct_candidates`` (default): the candidates of ONE impression are drawn without replacement — a MIND impression
+    lists distinct news (the reference's ``behaviors.tsv`` rows, mind_dataframe.py:278-288); the Zipf draw with replacement
+    of rounds 1-3 repeated popular news inside an impression, which made exact score ties that only rounding noise orders.
+    Histories keep the plain draw (a click history may repeat; a repeat only re-weights the mean).  Candidate counts are
+    capped at the pool size."""
     g = _rng(seed, 3)
     h = np.clip(np.rint(g.lognormal(np.log(22.0), 0.9, n_imp)), 1, max_hist).astype(np.int64)
     c = np.clip(np.rint(g.lognormal(np.log(24.0), 0.9, n_imp)), 2, max_cand).astype(np.int64)
+    if distinct_candidates:
+        c = np.minimum(c, n_news)
     hist_off = np.concatenate([[0], np.cumsum(h)]).astype(np.int64)
     cand_off = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
     # Zipf(a) popularity over the pool through a seeded rank -> news permutation
@@ -74,6 +82,37 @@ def synth_impressions(n_imp: int, n_news: int, seed: int = 42, max_hist: int = 5
 
     hist_idx = draw(int(hist_off[-1]))
     cand_idx = draw(int(cand_off[-1]))
+    if distinct_candidates:
+        # rejection: every later occurrence of a news inside its impression is redrawn until none is left (the first occurrence keeps
+        # its place, so the popular news stay as popular as the Zipf law makes them); impressions that ask for more than half the pool
+        # (tiny test pools) are completed from a seeded permutation of the news they lack instead of waiting for the tail
+        seg = np.repeat(np.arange(n_imp, dtype=np.int64), c)
+
+        def later_occurrences(elems):
+            """Positions (among ``elems``) holding a news that an earlier position of the same impression already holds."""
+            key = seg[elems] * n_news + cand_idx[elems]
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            return elems[order[1:][ks[1:] == ks[:-1]]]
+
+        def elements_of(imps):
+            cnt = c[imps]
+            start = np.repeat(cand_off[imps] - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
+            return start + np.arange(int(cnt.sum()), dtype=np.int64)
+
+        dup = later_occurrences(np.arange(cand_idx.shape[0], dtype=np.int64))
+        for _ in range(200):                                       # each round only re-examines the impressions it touched
+            if dup.size == 0:
+                break
+            cand_idx[dup] = draw(dup.size)
+            dup = later_occurrences(elements_of(np.unique(seg[dup])))
+        bad = np.unique(seg[dup])
+        for i in bad:                                              # rare (tiny pools): exact completion
+            a, e = int(cand_off[i]), int(cand_off[i + 1])
+            first = np.unique(cand_idx[a:e], return_index=True)[1]
+            keep = cand_idx[a:e][np.sort(first)]
+            rest = np.setdiff1d(np.arange(n_news, dtype=np.int32), keep)
+            cand_idx[a:e] = np.concatenate([keep, g.permutation(rest)[: (e - a) - keep.size]])
     labels = (g.random(int(cand_off[-1])) < 0.04).astype(np.float32)
     labels[cand_off[:-1] + (g.random(n_imp) * c).astype(np.int64)] = 1.0
     return {"hist_idx": hist_idx, "hist_off": hist_off, "cand_idx": cand_idx, "cand_off": cand_off,

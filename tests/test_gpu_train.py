@@ -205,6 +205,51 @@ def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, 
         assert np.abs(x - y).max() <= 1e-4 * max(np.abs(y).max(), 1e-6), (k, np.abs(x - y).max(), np.abs(y).max())
 
 
+@pytest.mark.parametrize("precision,rel,cos_min", [("f16", 2e-2, 0.9999), ("bf16", 8e-2, 0.999)])
+def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, cos_min, monkeypatch):
+    """the matrix-pipe training attention (train_attn.hip; 16-bit Q | K | V, probabilities rounded to 16 bits for the P.V
+    and the gradient products) against the f32 VALU kernels it replaced, IN ONE PROCESS — MANNER_HIP_TRAIN_ATTN_VALU is read per
+    call, the forward records its choice against the saved buffer and the backward follows the record.  Same weights, inputs and
+    dropout bits (counter-based: both paths regenerate the same masks); what differs is one 16-bit rounding of Q | K | V and of the
+    probabilities, so the bound is a 16-bit one — but far tighter than the cos > 0.99 the oracle comparison allows: every tensor's
+    gradient within `rel` of its largest entry and cosine >= `cos_min`; mini-roberta-large (H = 1024, 16 heads) and ragged lengths
+    that end inside a key tile."""
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=75, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(21, cfg, seed=75, max_len=70)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(7).standard_normal((21, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for valu in ("1", None):
+        if valu is None:
+            monkeypatch.delenv("MANNER_HIP_TRAIN_ATTN_VALU", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_TRAIN_ATTN_VALU", valu)
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=9)
+        if valu is None:                                       # the backward must follow the FORWARD's recorded path, not the environment
+            monkeypatch.setenv("MANNER_HIP_TRAIN_ATTN_VALU", "1")
+        (out * R).sum().backward()
+        res[valu] = (out.detach().cpu().numpy(), _grads(params))
+    monkeypatch.delenv("MANNER_HIP_TRAIN_ATTN_VALU", raising=False)
+    a, b = res[None][0].astype(np.float64), res["1"][0].astype(np.float64)
+    print(f"{precision}: output max-abs diff MFMA vs VALU attention {np.abs(a - b).max():.3e} (scale {np.abs(b).max():.2f})")
+    assert np.abs(a - b).max() <= rel * np.abs(b).max()
+    worst = (0.0, 1.0, None)
+    for k, g in res["1"][1].items():
+        if g is None:
+            assert res[None][1][k] is None
+            continue
+        x, y = res[None][1][k].astype(np.float64).ravel(), g.astype(np.float64).ravel()
+        assert np.isfinite(x).all(), k
+        e = np.abs(x - y).max() / max(np.abs(y).max(), 1e-12)
+        c = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-300))
+        if e > worst[0]:
+            worst = (e, c, k)
+        assert e <= rel and c >= cos_min, (k, e, c)
+    print(f"{precision}: worst gradient tensor {worst[2]}: rel-to-max {worst[0]:.3e}, cosine {worst[1]:.6f}")
+
+
 def test_train_from_cached_frozen_prefix():
     """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
     starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""

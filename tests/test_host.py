@@ -5,6 +5,7 @@ import ctypes
 import inspect
 import json
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -122,43 +123,114 @@ def test_synthetic_inputs_are_deterministic_and_well_formed():
     assert np.array_equal(segment_ids(np.array([0, 2, 2, 5])), [0, 0, 2, 2, 2])
 
 
-def test_reference_import_paths_resolve_to_the_mirror():
-    """north_star: "keeping the NewsEncoder / UserEncoder / ClickPredictor operator surface under manner/models" — the
-    exact import statements of the reference's LightningModules (cr_module.py:13-16, a_module.py:15,
-    ensemble_module.py:13) resolve, through the in-tree shim package ``manner/``, to the HIP mirror classes."""
-    import importlib
-    import sys
+REFERENCE = "/root/reference"          # exists in the build container only; the reference never travels to the GPU box
+
+_INSTALL_SCRIPT = r'''
+import importlib.util, json, re, sys
+import manner_amd
+ref = sys.argv[1]
+early = "--early" in sys.argv
+def lines(path, a, b):                          # the reference's OWN import lines, read where they lie (nothing is copied into the repo)
+    with open(path) as f:
+        return [l.rstrip("\n") for l in f.readlines()[a - 1:b]]
+if early:                                        # a reference module imported BEFORE install(): its aliases must be rebound too
+    sys.path.insert(0, ref)
+    import manner.models.components.user_encoder as UE0
+    from manner.models.components.user_encoder import NAMLUserEncoder as UserEncoderEarly
+    import types
+    fake = types.ModuleType("manner.models.fake_caller")          # stands for cr_module, which needs lightning to import
+    fake.UserEncoder = UserEncoderEarly
+    sys.modules["manner.models.fake_caller"] = fake
+report = manner_amd.install(ref)
+out = {"report": report, "skipped_third_party": []}
+ns_cr, ns_naml = {}, {}
+for ns, path, a, b in ((ns_cr, ref + "/manner/models/cr_module.py", 12, 16), (ns_naml, ref + "/manner/models/baselines/naml_plm_module.py", 11, 16)):
+    for l in lines(path, a, b):
+        assert re.match(r"from manner\.[\w.]+ import ", l), l
+        try:
+            exec(l, ns)
+        except ModuleNotFoundError as e:         # a third-party package this image lacks (pytorch_metric_learning, torchmetrics): not ours to stub
+            assert (e.name or "").split(".")[0] != "manner", (l, e)
+            out["skipped_third_party"].append([l, e.name])
+cls = lambda c: c.__module__ + "." + c.__qualname__
+out["cr_module"] = {k: cls(v) for k, v in ns_cr.items() if isinstance(v, type)}
+out["naml_plm_module"] = {k: cls(v) for k, v in ns_naml.items() if isinstance(v, type)}
+import manner, manner.models.components.news_encoder as NE, manner.models.components.attention as AT
+out["manner_file"] = manner.__file__
+out["utils_origin"] = importlib.util.find_spec("manner.utils").origin
+out["data_origin"] = importlib.util.find_spec("manner.data").origin
+out["cr_module_origin"] = importlib.util.find_spec("manner.models.cr_module").origin
+out["kept"] = {n: cls(getattr(NE, n)) for n in ("NAMLNewsEncoder", "LSTURNewsEncoder", "MINERNewsEncoder", "CAUMNewsEncoder")}
+out["kept"].update({n: cls(getattr(AT, n)) for n in ("PolyAttention", "TargetAwareAttention", "DenseAttention")})
+out["naml_inner_additive"] = cls(NE.AdditiveAttention)           # what the reference's NAMLNewsEncoder instantiates
+if early:
+    out["early_alias"] = cls(sys.modules["manner.models.fake_caller"].UserEncoder)
+ue = ns_cr["UserEncoder"](news_embedding_dim=768, query_vector_dim=200)          # the reference's call, cr_module.py:65-68
+out["ue_keys"] = sorted(ue.state_dict())
+manner_amd.uninstall()
+out["after_uninstall"] = cls(NE.MannerNewsEncoder)
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference checkout exists in the build container only")
+@pytest.mark.parametrize("early", [False, True])
+def test_install_binds_the_mirror_into_the_real_reference_tree(early):
+    """VERDICT r3 item 2 — the binding must COEXIST with the reference tree.  In a fresh interpreter with this repository and the
+    reference checkout importable, after ``manner_amd.install()`` the exact import lines of reference manner/models/cr_module.py:12-16
+    give the mirror classes, those of baselines/naml_plm_module.py:11-16 give the mirror ``DotProduct`` / ``NAMLUserEncoder`` and the
+    REFERENCE's own ``NAMLNewsEncoder``; ``manner``, ``manner.utils``, ``manner.data``, ``manner.models.cr_module`` still resolve to the
+    reference's files; the untouched encoders / attentions stay the reference's classes, and the reference's ``NAMLNewsEncoder`` keeps
+    using the reference's ``AdditiveAttention``.  ``early``: a reference module imported before ``install()`` has its aliases rebound."""
+    import json
+    import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    saved = {k: v for k, v in sys.modules.items() if k == "manner" or k.startswith("manner.")}
-    for k in saved:
-        del sys.modules[k]                       # a reference checkout on sys.path must not shadow the shim here
-    sys.path.insert(0, root)
-    try:
-        from manner.models.components.click_predictors import DotProduct
-        from manner.models.components.news_encoder import MannerNewsEncoder
-        from manner.models.components.user_encoder import NAMLUserEncoder as UserEncoder
-        from manner.models.components.attention import AdditiveAttention
-        import manner_amd.models.components.news_encoder as M
-        assert importlib.import_module("manner").__file__.startswith(root)
-        assert MannerNewsEncoder is M.MannerNewsEncoder
-        assert DotProduct.__module__ == "manner_amd.models.components.click_predictors"
-        assert UserEncoder.__module__ == "manner_amd.models.components.user_encoder"
-        assert AdditiveAttention.__module__ == "manner_amd.models.components.attention"
-        # the PLM baselines' imports (baselines/nrms_plm_module.py:15-16)
-        from manner.models.components.news_encoder import PLMTextEncoder as NewsEncoder
-        from manner.models.components.user_encoder import NRMSUserEncoder
-        assert NewsEncoder is M.PLMTextEncoder and NRMSUserEncoder.__module__ == "manner_amd.models.components.user_encoder"
-        nrms = NRMSUserEncoder(news_embedding_dim=768, num_attention_heads=16, query_vector_dim=200)
-        assert sorted(nrms.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query",
-                                             "multihead_attention.in_proj_bias", "multihead_attention.in_proj_weight",
-                                             "multihead_attention.out_proj.bias", "multihead_attention.out_proj.weight"]
-        ue = UserEncoder(news_embedding_dim=768, query_vector_dim=200)          # the reference's call, cr_module.py:65-68
-        assert sorted(ue.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"]
-    finally:
-        sys.path.remove(root)
-        for k in [k for k in sys.modules if k == "manner" or k.startswith("manner.")]:
-            del sys.modules[k]
-        sys.modules.update(saved)
+    env = dict(os.environ, PYTHONPATH=root, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", _INSTALL_SCRIPT, REFERENCE] + (["--early"] if early else []), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    mir = "manner_amd.models.components."
+    assert out["cr_module"]["DotProduct"] == mir + "click_predictors.DotProduct"
+    assert out["cr_module"]["MannerNewsEncoder"] == mir + "news_encoder.MannerNewsEncoder"
+    assert out["cr_module"]["UserEncoder"] == mir + "user_encoder.NAMLUserEncoder"
+    assert out["cr_module"]["MINDRecBatch"].startswith("manner.data.components.mind_batch.")
+    assert out["naml_plm_module"]["NewsEncoder"] == "manner.models.components.news_encoder.NAMLNewsEncoder"      # the reference's own
+    assert out["naml_plm_module"]["DotProduct"] == mir + "click_predictors.DotProduct"
+    assert out["naml_plm_module"]["UserEncoder"] == mir + "user_encoder.NAMLUserEncoder"
+    for k in ("manner_file", "utils_origin", "data_origin", "cr_module_origin"):
+        assert out[k].startswith(REFERENCE + "/manner/"), (k, out[k])
+    assert all(v.startswith("manner.models.components.") for v in out["kept"].values()), out["kept"]
+    assert out["naml_inner_additive"] == "manner.models.components.attention.AdditiveAttention"
+    assert all(e[1].split(".")[0] in ("pytorch_metric_learning", "torchmetrics", "lightning", "torch_geometric") for e in out["skipped_third_party"]), out["skipped_third_party"]
+    assert out["ue_keys"] == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"]
+    assert out["after_uninstall"] == "manner.models.components.news_encoder.MannerNewsEncoder"
+    assert sorted(out["report"]["manner.models.components.news_encoder"]) == ["MannerEntityEncoder", "MannerNewsEncoder", "MannerTextEncoder", "PLMTextEncoder"]
+    if early:
+        assert out["early_alias"] == mir + "user_encoder.NAMLUserEncoder"
+        assert out["report"]["manner.models.fake_caller"] == ["UserEncoder"]
+
+
+def test_install_without_a_reference_checkout_says_so():
+    """No ``manner`` package importable (the GPU box): install() names the problem instead of binding nothing silently; this
+    repository itself ships no ``manner`` package any more (rounds 1-3's shim shadowed the reference tree)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert not os.path.exists(os.path.join(root, "manner"))
+    r = subprocess.run([sys.executable, "-c", "import manner_amd\ntry:\n    manner_amd.install()\nexcept ModuleNotFoundError as e:\n    print('OK', e)"],
+                       env=dict(os.environ, PYTHONPATH=root, PYTHONDONTWRITEBYTECODE="1"), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.startswith("OK manner_amd.install(): the reference package `manner` is not importable"), r.stdout + r.stderr[-2000:]
+
+
+def test_mirror_constructors_follow_the_reference_call_sites():
+    """The PLM baselines' encoders (reference baselines/nrms_plm_module.py:15-16) and the CR-Module's user encoder, constructed as the
+    reference constructs them, expose the reference's state_dict keys."""
+    from manner_amd.models.components.user_encoder import NAMLUserEncoder, NRMSUserEncoder
+    nrms = NRMSUserEncoder(news_embedding_dim=768, num_attention_heads=16, query_vector_dim=200)
+    assert sorted(nrms.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query",
+                                         "multihead_attention.in_proj_bias", "multihead_attention.in_proj_weight",
+                                         "multihead_attention.out_proj.bias", "multihead_attention.out_proj.weight"]
+    ue = NAMLUserEncoder(news_embedding_dim=768, query_vector_dim=200)          # the reference's call, cr_module.py:65-68
+    assert sorted(ue.state_dict()) == ["additive_attention.linear.bias", "additive_attention.linear.weight", "additive_attention.query"]
 
 
 def test_shard_range_partitions():
@@ -227,20 +299,31 @@ def test_bench_starts_its_own_ranks(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["launcher"] == "self" and j["steps"] == 3 and j["dry_run"] is True
     assert j["impressions_all_ranks"] == 512.0 and abs(j["max_rank_time_s"] - 0.002) < 1e-12      # SUM and MAX over both ranks
+    assert j["table_exchange"] == {"default_exchange": "collective", "mesh_equals_collective_on_every_rank": True, "n_news": 161013, "pieces": 4}
+    # the target machine's world size: 8 ranks, the staggered 7-peer mesh with 4 pieces of a 161 013-row table, store agreement
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j8 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j8["n_gpus"] == 8 and j8["world_size_seen"] == 8 and j8["impressions_all_ranks"] == 2048.0 and abs(j8["max_rank_time_s"] - 0.008) < 1e-12
+    assert j8["table_exchange"]["mesh_equals_collective_on_every_rank"] is True
     # a rank that cannot start fails the whole command (non-zero exit), it does not hang the others
     env["MANNER_DIST_BACKEND"] = "no-such-backend"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-def _mesh_worker(rank, world, port, n_news, pieces):
+def _mesh_worker(rank, world, port, n_news, pieces, exchange):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("MANNER_TABLE_EXCHANGE", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from manner_amd import distributed as D
         full = torch.arange(n_news * 6, dtype=torch.float32).reshape(n_news, 6) * 0.5 + 1.0
-        g = D.MeshTableGather(n_news, 6, "cpu", pieces=pieces)
+        g = D.MeshTableGather(n_news, 6, "cpu", pieces=pieces, exchange=exchange, timeout_s=120)
+        assert g.exchange == (exchange or "collective")              # the collective is the default (round 4)
+        assert g.exchange_why == ("requested" if exchange else "default")
         g.table.fill_(-7.0)
         seen = []
         for c in range(pieces):                              # "encode" piece c of the own shard straight into the table, then post it
@@ -259,18 +342,59 @@ def _mesh_worker(rank, world, port, n_news, pieces):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_news,pieces", [(2, 37, 4), (3, 41, 3), (4, 6, 4)])
-def test_mesh_table_gather_overlapped_pieces_gloo(world, n_news, pieces):
-    """SURVEY §8e: the direct full-mesh exchange of the news-embedding table in pieces (each piece posted while the next
-    is being encoded) assembles exactly the table the single all-gather does — uneven last shard, pieces that are empty on
-    some ranks (6 news over 4 ranks x 4 pieces) included."""
+def _free_port():
     import socket
-    import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_mesh_worker, args=(world, port, n_news, pieces), nprocs=world, join=True)
+    return port
+
+
+@pytest.mark.parametrize("world,n_news,pieces,exchange", [(2, 37, 4, "mesh"), (3, 41, 3, "mesh"), (4, 6, 4, "mesh"), (3, 41, 3, None),
+                                                          # the target machine's world size at the MIND-large pool size, which 8 does not divide
+                                                          (8, 161013, 4, "mesh"), (8, 161013, 4, "collective")])
+def test_mesh_table_gather_overlapped_pieces_gloo(world, n_news, pieces, exchange):
+    """SURVEY §8e: the direct full-mesh exchange of the news-embedding table in pieces (each piece posted while the next
+    is being encoded) assembles exactly the table the single all-gather does — uneven last shard, pieces that are empty on
+    some ranks (6 news over 4 ranks x 4 pieces) included; world 8 x 4 pieces x 161 013 news is the shape of the first real run
+    (staggered rank +- k peer order over 7 peers).  The default exchange is the collective; both give the same table."""
+    import torch.multiprocessing as mp
+    mp.spawn(_mesh_worker, args=(world, _free_port(), n_news, pieces, exchange), nprocs=world, join=True)
+
+
+def _stuck_worker(rank, world, port, out_dir):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from manner_amd import distributed as D
+    g = D.MeshTableGather(10, 4, "cpu", pieces=1, exchange="mesh", timeout_s=2.0)
+    g.table.zero_()
+    t0 = time.monotonic()
+    if rank == 0:
+        g.post(0)                                            # rank 1 never posts: a mismatched point-to-point group
+        try:
+            g.wait()
+            res = "returned"
+        except TimeoutError as e:
+            res = "TimeoutError: " + str(e)[:60]
+    else:
+        time.sleep(6.0)
+        res = "idle"
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write(f"{res}|{time.monotonic() - t0:.1f}")
+    os._exit(0)                                              # the group is broken on purpose: no orderly shutdown to wait for
+
+
+def test_mesh_wait_is_bounded(tmp_path):
+    """a peer that never posts its half of the exchange makes wait() raise TimeoutError after `timeout_s`
+    instead of hanging the process until somebody kills it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_stuck_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res, secs = (tmp_path / "r0.txt").read_text().split("|")
+    assert res.startswith("TimeoutError"), res
+    assert 1.5 <= float(secs) < 6.0, secs
 
 
 def test_two_rank_table_allgather_and_impression_sharding_gloo(tmp_path):
@@ -467,5 +591,12 @@ def test_impression_blocks_are_balanced_by_occurrences():
         assert all(sh[r][1] == sh[r + 1][0] for r in range(w - 1)) and all(a <= b for a, b in sh)
         work = np.array([per[a:b].sum() for a, b in sh])
         assert work.sum() == per.sum() and work.max() <= per.sum() / w + per.max()
-    assert balanced_impression_shards(np.array([0, 3]), np.array([0, 5]), 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+    one = balanced_impression_shards(np.array([0, 3]), np.array([0, 5]), 4)          # fewer impressions than ranks: empty blocks, no bad index
+    assert len(one) == 4 and sum(b - a for a, b in one) == 1 and one[0][0] == 0 and one[-1][1] == 1 and all(x[1] == y[0] for x, y in zip(one, one[1:]))
     assert balanced_impression_shards(np.array([0]), np.array([0]), 2) == [(0, 0), (0, 0)]
+    # the cut goes to the CLOSER side of the mark — cumulative work [3, 11, 23] at world 2 splits 11 / 12, not 23 / 0
+    assert balanced_impression_shards(np.array([0, 1, 5, 10]), np.array([0, 2, 6, 13]), 2) == [(0, 2), (2, 3)]
+    # one heavy impression among light ones: with at least as many impressions as ranks nobody is left without work
+    for w in (2, 3, 4):
+        sh = balanced_impression_shards(np.array([0, 1, 2, 3, 4]), np.array([0, 300, 302, 304, 306]), w)
+        assert all(b > a for a, b in sh) and sh[0][0] == 0 and sh[-1][1] == 4 and all(x[1] == y[0] for x, y in zip(sh, sh[1:])), (w, sh)
