@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
@@ -48,6 +48,8 @@ SIGNATURES = {
     "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
     "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
+    "manner_hip_additive_pool_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
+    "manner_hip_additive_pool_fused": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _SZ, _I32, _P]),
     "manner_hip_entity_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
     "manner_hip_entity_encode": (C.c_int, [_P, _I64, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P, _P]),
     "manner_hip_linear": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),

@@ -100,6 +100,12 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
 int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,
                      float* logits, hipStream_t stream);
 
+// K11 in one pass over x (pool.hip): bf16x3 logits on the bf16 matrix pipe from register-resident rows, softmax, weighted sum
+bool pool_fused_supported(int64_t B, int64_t S, int D, int Q);
+size_t pool_fused_workspace_bytes(int D, int Q);
+int pool_fused(const float* x, const float* W, const float* bias, const float* query, int64_t B, int64_t S, int D, int Q, float* out,
+               void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // m_bound: rows the chunk's buffers hold; expect_tokens >= 0: what the caller's host_lengths promised.  A mask that
 // yields more tokens than m_bound is truncated there (cu[n] clamped to m_bound - 1 for a news START, cu[n_news] to m_bound:

@@ -843,6 +843,26 @@ int manner_hip_additive_pool(const float* x, const float* lin_w, const float* li
   return MANNER_HIP_OK;
 }
 
+size_t manner_hip_additive_pool_workspace_bytes(int64_t B, int64_t S, int32_t D, int32_t Q) {
+  const size_t logits = (size_t)(B > 0 ? B : 0) * (size_t)(S > 0 ? S : 1) * sizeof(float) + 256;
+  const size_t packed = (D > 0 && D % 32 == 0 && Q > 0 && Q <= 320) ? pool_fused_workspace_bytes(D, Q) : 0;
+  return logits > packed ? logits : packed;
+}
+
+int manner_hip_additive_pool_fused(const float* x, const float* lin_w, const float* lin_b, const float* query, int64_t B, int64_t S,
+                                   int32_t D, int32_t Q, float* out, void* workspace, size_t workspace_bytes, int32_t strict,
+                                   manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!x || !lin_w || !lin_b || !query || !out || !workspace) return fail(MANNER_HIP_E_INVALID, "additive_pool_fused: null pointer");
+  if (workspace_bytes < manner_hip_additive_pool_workspace_bytes(B, S, D, Q)) return fail(MANNER_HIP_E_WORKSPACE, "additive_pool_fused: workspace too small");
+  const char* env = getenv("MANNER_HIP_POOL_STRICT");                      // read per call (A/B in one process)
+  const bool want_strict = strict != 0 || (env && *env && *env != '0');
+  if (!want_strict && S > 0 && D > 0 && Q > 0 && pool_fused_supported(B, S, D, Q) && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+      (uintptr_t)workspace % 256 == 0)
+    return pool_fused(x, lin_w, lin_b, query, B, S, D, Q, out, workspace, workspace_bytes, (hipStream_t)stream);
+  return manner_hip_additive_pool(x, lin_w, lin_b, query, B, S, D, Q, out, static_cast<float*>(workspace), stream);
+}
+
 int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K, const float* weights, const int64_t* cand_off,
                            int64_t B, float* out, float* pad_value, manner_hip_stream_t stream) {
   if (B == 0) return MANNER_HIP_OK;

@@ -332,7 +332,10 @@ class HipEncoder:
             raise RuntimeError(f"manner_hip input error in an earlier encode call: {_status_message(flag)}")
 
 
-def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Tensor:
+def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor, strict: bool = False) -> Tensor:
+    """AdditiveAttention.forward (reference attention.py:21-27).  Default: the one-pass kernel (x read once, bf16x3 logits on the
+    bf16 matrix pipe, within 1e-4 of the reference) where the shape allows it; ``strict=True`` (or MANNER_HIP_POOL_STRICT=1): the
+    exact-f32 two-pass path."""
     x = _dev(x, torch.float32, "input_vector").contiguous()
     b, s, d = x.shape
     lin_w = _dev(lin_w, torch.float32, "linear.weight").contiguous()
@@ -341,10 +344,13 @@ def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor) -> Ten
     q = lin_w.shape[0]
     assert lin_w.shape == (q, d) and lin_b.shape == (q,) and query.shape == (q,)
     out = torch.empty((b, d), dtype=torch.float32, device=x.device)
-    scratch = torch.empty((b, max(s, 1)), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = int(lib.manner_hip_additive_pool_workspace_bytes(b, s, d, q))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+    off = (-ws.data_ptr()) % 256
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().manner_hip_additive_pool(_ptr(x), _ptr(lin_w), _ptr(lin_b), _ptr(query), b, s, d, q,
-                                                        _ptr(out), _ptr(scratch), _stream()))
+        _lib.check(lib.manner_hip_additive_pool_fused(_ptr(x), _ptr(lin_w), _ptr(lin_b), _ptr(query), b, s, d, q, _ptr(out),
+                                                      ws.data_ptr() + off, nbytes, 1 if strict else 0, _stream()))
     return out
 
 

@@ -346,7 +346,7 @@ class _AdditivePool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor):
         ctx.save_for_backward(x, lin_w, lin_b, query)
-        return hip.additive_pool(x, lin_w, lin_b, query)
+        return hip.additive_pool(x, lin_w, lin_b, query, strict=True)      # the backward recomputes the exact-f32 pre-activations
 
     @staticmethod
     def backward(ctx, g: Tensor):

@@ -242,6 +242,12 @@ def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, 
             continue
         x, y = res[None][1][k].astype(np.float64).ravel(), g.astype(np.float64).ravel()
         assert np.isfinite(x).all(), k
+        if k.endswith("attention.self.key.bias"):
+            # d loss / d key-bias is EXACTLY zero in exact arithmetic (adding a constant to every key shifts each softmax row's logits by
+            # the same q.b: sum_j dS_ij = 0), so both paths return rounding residue: compared against the query bias' scale, not each other
+            qs = np.abs(res["1"][1][k.replace("key.bias", "query.bias")]).max()
+            assert np.abs(x).max() <= 2e-2 * qs and np.abs(y).max() <= 2e-2 * qs, (k, np.abs(x).max(), np.abs(y).max(), qs)
+            continue
         e = np.abs(x - y).max() / max(np.abs(y).max(), 1e-12)
         c = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-300))
         if e > worst[0]:
