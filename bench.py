@@ -744,6 +744,20 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
         f16_table[name] = {"scorer_kernel_ms_rank0": ms16, "convert_ms": conv_ms, "speedup_vs_f32_table": scorer_ms / ms16,
                            "vs_f32_table_scores": ranking_agreement(s16_one, s32_one, labels, off_r)}
     del t16, s32_one, s16_one
+    # SURVEY §8e phase C as ONE launch (hip.score_fuse_rank: the K score planes stay in LDS) against the K + 2 launches it replaces, same
+    # impressions, same tables; the two give the same bits (tests/test_gpu_parity.py::test_phase_c_in_one_launch_equals_the_three_kernel_path)
+    phase_c = None
+    if b > a and cfg.hidden in (768, 1024):
+        fus = hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10, fused=True)
+        sep = hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10, fused=False)
+        same_bits = bool(torch.equal(fus["scores"].nan_to_num(0.0), sep["scores"].nan_to_num(0.0)) and torch.equal(fus["topk"], sep["topk"])
+                         and torch.equal(fus["ndcg"].nan_to_num(0.0), sep["ndcg"].nan_to_num(0.0)))
+        ms_f = timed_ms(lambda: hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10, fused=True))
+        ms_s = timed_ms(lambda: hotpath.score_impressions(tables, dimp, weights=fuse_w, labels=labels, k=10, fused=False))
+        phase_c = {"one_launch_ms": ms_f, "separate_launches_ms": ms_s, "launches_replaced": K + (2 if K > 1 else 1), "bit_identical": same_bits,
+                   "impressions_rank0": int(b - a), "what": "gather-mean-dot x K modules + z-score + weighted fusion + stable top-10 + nDCG@10 + MRR per "
+                   "impression in one kernel (planes in LDS) vs score_late_fusion x K -> zscore_fuse -> rank_ndcg"}
+        del fus, sep
     metrics_ms = {"rank_ndcg_mrr": timed_ms(lambda: hip.rank_ndcg(sc_r, labels, off_r, 10, with_mrr=True)),
                   "auc": timed_ms(lambda: hip.auc(sc_r.nan_to_num(0.0), labels)),
                   "eval_loss_supcon": timed_ms(lambda: hip.eval_loss(sc_r, labels, off_r, supcon=True, temperature=0.36, reduce=False))}
@@ -788,7 +802,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
                        "xGMI peak = 7 links x 153 GB/s; the mesh form is measured in `mesh_exchange`"},
            "allgather_GBps_per_rank": (recv_bytes / coll_s / 1e9) if world > 1 and coll_s > 0 else None,
            "allgather_frac_of_xgmi": (recv_bytes / coll_s / 1e9 / (7 * 153.0)) if world > 1 and coll_s > 0 else None,
-           "world_size_seen": world,
+           "world_size_seen": world, "phase_c": phase_c,
            "encode_ms": 1e3 * enc_s, "score_ms": 1e3 * sc_s, "ndcg10": nd[0].item() / nd[1].item(), "ndcg5": nd[2].item() / nd[1].item(),
            "metrics_ms_rank0": {**metrics_ms, "candidates": n_c,
                                 "auc_Mpairs_per_s": n_c / metrics_ms["auc"] / 1e3, "rank_Mpairs_per_s": n_c / metrics_ms["rank_ndcg_mrr"] / 1e3}}

@@ -294,6 +294,22 @@ int manner_hip_zscore_fuse(const float* scores, int64_t plane_stride, int32_t K,
 int manner_hip_rank_ndcg(const float* scores, const float* labels, const int64_t* cand_off, int64_t B,
                          int32_t k, int32_t* topk_idx, float* ndcg, float* mrr, manner_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- Phase C in one launch (ABI v5)
+ * EnsembleModule.forward over K per-module tables — manner/models/ensemble_module.py:95-151 — and the ranking consumer of
+ * cr_module.py:267-273 in ONE kernel: for every impression gather-mean-dot against each active module's table (weights[k-1] == 0
+ * skips module k as the reference does), per-impression z-score and weighted fusion (K == 1: the CR-Module's raw late-fusion scores,
+ * cr_module.py:105-131), stable ranking, top-k, nDCG@k, MRR.  The K score planes stay in LDS.  BIT-IDENTICAL to
+ * manner_hip_score_late_fusion x K -> manner_hip_zscore_fuse -> manner_hip_rank_ndcg (same code, same order of operations).
+ *   tables: K HOST pointers to device tables f32 [n_rows, D] (D = 768 or 1024); weights: K-1 host floats; scores f32 [total_candidates]
+ *   out; pad_value [B] or NULL; topk_idx int32 [B, k] or NULL; ndcg / mrr f32 [B] or NULL (need labels); workspace
+ *   manner_hip_score_fuse_rank_workspace_bytes(K, total_candidates) bytes (touched only by impressions with more than 320 candidates). */
+size_t manner_hip_score_fuse_rank_workspace_bytes(int32_t K, int64_t total_candidates);
+int manner_hip_score_fuse_rank(const float* const* tables, int32_t K, const float* weights, int64_t n_rows, int32_t D,
+                               const int32_t* hist_idx, const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off,
+                               int64_t B, int64_t total_candidates, const float* labels, int32_t k, float* scores, float* pad_value,
+                               int32_t* topk_idx, float* ndcg, float* mrr, void* workspace, size_t workspace_bytes, int32_t* status,
+                               manner_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- aspect metrics
  * Replaces Diversity / Personalization @k — manner/metrics/functional.py:8-28, 31-62, 65-70 grouped per
  * impression as manner/metrics/base.py:92-129 and torchmetrics RetrievalMetric.compute do (constructed at

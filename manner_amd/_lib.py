@@ -62,6 +62,9 @@ SIGNATURES = {
     "manner_hip_to_dense": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P]),
     "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P, _P]),
     "manner_hip_rank_ndcg": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "manner_hip_score_fuse_rank_workspace_bytes": (_SZ, [_I32, _I64]),
+    "manner_hip_score_fuse_rank": (C.c_int, [C.POINTER(_P), _I32, C.POINTER(C.c_float), _I64, _I32, _P, _P, _P, _P, _I64, _I64, _P, _I32, _P, _P,
+                                             _P, _P, _P, _P, _SZ, _P, _P]),
     "manner_hip_aspect_metrics": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "manner_hip_auc_workspace_bytes": (_SZ, [_I64]),
     "manner_hip_auc": (C.c_int, [_P, _P, _I64, _I32, _P, _SZ, _P, _P, _P]),

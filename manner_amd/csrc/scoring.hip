@@ -101,14 +101,14 @@ __global__ __launch_bounds__(256) void score_late_fusion_kernel(
 // a time (22 history rows = 16 serial round trips to L2 / HBM per wave: the scorer was bound by that latency chain, not by bytes).
 // Row -> wave assignment, the order of every addition and the dot product's association are those of the kernel above: the two
 // produce the same bits (zero rows added for the slots past the end: x + 0 is exact and the sums start at +0).
-template <int NCB, int RIF>
-__global__ __launch_bounds__(256) void score_late_fusion_rows_kernel(
+// The body is shared by the stand-alone scorer kernel (emit = a store into the ragged score vector) and by the fused Phase-C kernel
+// below (emit = a store into the impression's LDS plane): one code path, so the two give the same bits.  `sm`: 5 D floats of LDS.
+template <int NCB, int RIF, typename Emit>
+__device__ __forceinline__ void score_rows_body(
     const float* __restrict__ table, int64_t n_rows, const int32_t* __restrict__ hist_idx, const int64_t* __restrict__ hist_off,
     const float* __restrict__ user_in, const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off,
-    float* __restrict__ out, int32_t* __restrict__ status) {
+    const int64_t b, float* sm, int32_t* __restrict__ status, Emit emit) {
   constexpr int D = NCB * 256;
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
-  const int64_t b = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave in an SGPR: the index lists are read by scalar loads
   float* user = sm + 4 * D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -176,9 +176,19 @@ __global__ __launch_bounds__(256) void score_late_fusion_rows_kernel(
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < RIF; ++q)
-        if (j + 4 * q < c1) out[j + 4 * q] = a[q];
+        if (j + 4 * q < c1) emit(j + 4 * q, a[q]);
     }
   }
+}
+
+template <int NCB, int RIF>
+__global__ __launch_bounds__(256) void score_late_fusion_rows_kernel(
+    const float* __restrict__ table, int64_t n_rows, const int32_t* __restrict__ hist_idx, const int64_t* __restrict__ hist_off,
+    const float* __restrict__ user_in, const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off,
+    float* __restrict__ out, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][D] wave partials + [D] user
+  score_rows_body<NCB, RIF>(table, n_rows, hist_idx, hist_off, user_in, cand_idx, cand_off, (int64_t)blockIdx.x, sm, status,
+                            [&](int64_t j, float v) { out[j] = v; });
 }
 
 // The same scorer over an IEEE-half copy of the table (manner_hip_score_late_fusion_f16): rows are 2 D bytes, so the MIND-large
@@ -658,6 +668,183 @@ __global__ __launch_bounds__(256) void rank_ndcg_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- Phase C in ONE launch (round 4)
+// EnsembleModule.forward over K module tables (reference manner/models/ensemble_module.py:95-151) + the ranking consumer
+// (cr_module.py:267-273): per impression, for every active module gather-mean-dot over that module's table (score_rows_body: the very
+// code of the stand-alone scorer), the per-impression z-score and the weighted fusion (the arithmetic of zscore_fuse_kernel, in its
+// order), then the stable ranking, top-k, nDCG@k and MRR (the arithmetic of rank_ndcg_kernel, in its order) — ONE workgroup per
+// impression, the K score planes live in LDS and never reach HBM (the three-kernel path writes and re-reads K + 1 planes and pays K + 2
+// launches).  Outputs are BIT-IDENTICAL to manner_hip_score_late_fusion x K -> manner_hip_zscore_fuse -> manner_hip_rank_ndcg.
+// Impressions with more than PC_CAP candidates (MIND caps an impression at 300) keep their planes in the caller's scratch and are
+// fused and ranked by wave 0 alone with the stand-alone kernels' loops.
+constexpr int PC_CAP = 320, PC_MAXK = 9;          // MIND caps an impression at 300 candidates; LDS per workgroup decides how many gathers a CU keeps in flight
+struct TablePtrs { const float* t[PC_MAXK]; };
+
+template <int NCB, int RIF>
+__global__ __launch_bounds__(256) void score_fuse_rank_kernel(
+    TablePtrs tabs, int K, int fuse, FuseWeights fw, int64_t n_rows, const int32_t* __restrict__ hist_idx, const int64_t* __restrict__ hist_off,
+    const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_off, const float* __restrict__ labels, int topn,
+    float* __restrict__ out, float* __restrict__ pad_out, int32_t* __restrict__ topk, float* __restrict__ ndcg, float* __restrict__ mrr,
+    float* __restrict__ scratch, int64_t total, int32_t* __restrict__ status) {
+  constexpr int D = NCB * 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [5 D] of the scorer body | [max(K, 2)][PC_CAP] planes | fused | labels
+  __shared__ int bestw[4];
+  float* planes = sm + 5 * D;
+  float* fsm = planes + (K > 2 ? K : 2) * PC_CAP;
+  float* lsm = fsm + PC_CAP;
+  float* dterm = planes;                                // the planes are dead once the fusion is done (a barrier lies between)
+  float* iterm = planes + PC_CAP;
+  const int64_t b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t c0 = cand_off[b], c1 = cand_off[b + 1];
+  const int c = (int)(c1 - c0);
+  const bool in_lds = c <= PC_CAP;
+  for (int k = 0; k < K; ++k) {
+    if (k > 0 && fw.w[k - 1] == 0.0f) continue;        // ensemble_module.py:100,105: module skipped
+    __syncthreads();                                    // the previous module's user vector has been read by every wave
+    float* dst = in_lds ? planes + k * PC_CAP : scratch + (int64_t)k * total + c0;
+    score_rows_body<NCB, RIF>(tabs.t[k], n_rows, hist_idx, hist_off, nullptr, cand_idx, cand_off, b, sm, status,
+                              [&](int64_t j, float v) { dst[j - c0] = v; });
+  }
+  __syncthreads();
+  if (!in_lds) {
+    // ---- rare: more than PC_CAP candidates.  Wave 0 runs the stand-alone kernels' loops over the scratch planes.
+    if (wave != 0) return;
+    __threadfence_block();
+    float pad = 0.f;
+    const float cn = (float)c;
+    float* o = out + c0;
+    if (!fuse) {
+      for (int j = lane; j < c; j += 64) o[j] = scratch[c0 + j];
+    } else {
+#pragma clang fp contract(off)
+      for (int k = 0; k < K; ++k) {
+        const float wk = k == 0 ? 1.0f : fw.w[k - 1];
+        if (k > 0 && wk == 0.0f) continue;
+        const float* s = scratch + (int64_t)k * total + c0;
+        float a = 0.f;
+        for (int j = lane; j < c; j += 64) a += s[j];
+        const float mean = wave_sum(a) / cn;
+        float q = 0.f;
+        for (int j = lane; j < c; j += 64) { const float d = s[j] - mean; q += d * d; }
+        const float sd = sqrtf(wave_sum(q) / (cn - 1.0f));
+        for (int j = lane; j < c; j += 64) {
+          const float z = (s[j] - mean) / sd;
+          o[j] = k == 0 ? z : o[j] + wk * z;
+        }
+        const float zp = (0.0f - mean) / sd;
+        pad = k == 0 ? zp : pad + wk * zp;
+      }
+    }
+    if (pad_out && lane == 0) pad_out[b] = pad;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const float* s = o;
+    const float* l = labels ? labels + c0 : nullptr;
+    if (topk)
+      for (int r = lane; r < topn; r += 64) if (r >= c) topk[b * topn + r] = -1;
+    float dcg = 0.f, idcg = 0.f, pos = 0.f;
+    int best = 0x7fffffff;
+    for (int a = lane; a < c; a += 64) {
+      const float sa = s[a];
+      int rank = 0;
+      for (int j = 0; j < c; ++j) rank += ranks_before(s[j], j, sa, a) ? 1 : 0;
+      if (rank < topn && topk) topk[b * topn + rank] = a;
+      if (l) {
+        const float la = l[a];
+        if (rank < topn) dcg += la / log2f((float)rank + 2.0f);
+        if (la > 0.f) best = min(best, rank);
+        int lrank = 0;
+        for (int j = 0; j < c; ++j) lrank += ranks_before(l[j], j, la, a) ? 1 : 0;
+        if (lrank < topn) idcg += la / log2f((float)lrank + 2.0f);
+        pos += la;
+      }
+    }
+    if (ndcg && l) {
+      dcg = wave_sum(dcg); idcg = wave_sum(idcg); pos = wave_sum(pos);
+      if (lane == 0) ndcg[b] = pos == 0.f ? 0.f : dcg / idcg;
+    }
+    if (mrr && l) {
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) best = min(best, __shfl_xor(best, o2, 64));
+      if (lane == 0) mrr[b] = best == 0x7fffffff ? 0.f : 1.0f / (float)(best + 1);
+    }
+    return;
+  }
+  // ---- z-score + fusion: wave 0, lane-strided sums and xor-butterfly reductions exactly as zscore_fuse_kernel (the reference does
+  // `scores += w * z` as separate torch ops: no FMA contraction)
+  if (wave == 0) {
+#pragma clang fp contract(off)
+    float pad = 0.f;
+    const float cn = (float)c;
+    if (!fuse) {
+      for (int j = lane; j < c; j += 64) fsm[j] = planes[j];
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const float wk = k == 0 ? 1.0f : fw.w[k - 1];
+        if (k > 0 && wk == 0.0f) continue;
+        const float* s = planes + k * PC_CAP;
+        float a = 0.f;
+        for (int j = lane; j < c; j += 64) a += s[j];
+        const float mean = wave_sum(a) / cn;               // sum(scores, dim=1) / cand_size  (:147)
+        float q = 0.f;
+        for (int j = lane; j < c; j += 64) { const float d = s[j] - mean; q += d * d; }
+        const float sd = sqrtf(wave_sum(q) / (cn - 1.0f)); // torch.std: unbiased; c == 1 -> NaN  (:143)
+        for (int j = lane; j < c; j += 64) {
+          const float z = (s[j] - mean) / sd;
+          fsm[j] = k == 0 ? z : fsm[j] + wk * z;           // scores += w * z  (:102,:107)
+        }
+        const float zp = (0.0f - mean) / sd;               // what the reference's dense matrix holds in a padded slot
+        pad = k == 0 ? zp : pad + wk * zp;
+      }
+    }
+    if (pad_out && lane == 0) pad_out[b] = pad;
+  }
+  if (labels)
+    for (int j = threadIdx.x; j < c; j += 256) lsm[j] = labels[c0 + j];
+  __syncthreads();
+  for (int j = threadIdx.x; j < c; j += 256) out[c0 + j] = fsm[j];
+  // ---- ranking: every thread ranks its candidates (integer counts: order-free); the per-candidate DCG terms go to LDS and wave 0
+  // adds them per lane in rank_ndcg_kernel's order (candidate lane, lane + 64, ...) before the same butterfly reductions
+  if (topk)
+    for (int r = threadIdx.x; r < topn; r += 256) if (r >= c) topk[b * topn + r] = -1;
+  int best = 0x7fffffff;
+  for (int a = threadIdx.x; a < c; a += 256) {
+    const float sa = fsm[a];
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += ranks_before(fsm[j], j, sa, a) ? 1 : 0;
+    if (rank < topn && topk) topk[b * topn + rank] = a;
+    if (labels) {
+      const float la = lsm[a];
+      dterm[a] = rank < topn ? la / log2f((float)rank + 2.0f) : -1.0f;       // -1: "no term" (a term is never negative: labels >= 0)
+      if (la > 0.f) best = min(best, rank);
+      int lrank = 0;
+      for (int j = 0; j < c; ++j) lrank += ranks_before(lsm[j], j, la, a) ? 1 : 0;
+      iterm[a] = lrank < topn ? la / log2f((float)lrank + 2.0f) : -1.0f;
+    }
+  }
+  if (!labels) return;
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) best = min(best, __shfl_xor(best, o2, 64));
+  if (lane == 0) bestw[wave] = best;
+  __syncthreads();
+  if (wave != 0) return;
+  float dcg = 0.f, idcg = 0.f, pos = 0.f;
+  for (int a = lane; a < c; a += 64) {
+    if (dterm[a] >= 0.f) dcg += dterm[a];
+    if (iterm[a] >= 0.f) idcg += iterm[a];
+    pos += lsm[a];
+  }
+  if (ndcg) {
+    dcg = wave_sum(dcg); idcg = wave_sum(idcg); pos = wave_sum(pos);
+    if (lane == 0) ndcg[b] = pos == 0.f ? 0.f : dcg / idcg;   // empty_target_action="neg" -> 0
+  }
+  if (mrr && lane == 0) {
+    const int bb = min(min(bestw[0], bestw[1]), min(bestw[2], bestw[3]));
+    mrr[b] = bb == 0x7fffffff ? 0.f : 1.0f / (float)(bb + 1);
+  }
+}
+
 // ---------------------------------------------------------------- aspect Diversity / Personalization @k
 // (reference manner/metrics/functional.py:8-28, 31-62, 65-70 over the per-impression grouping of
 // manner/metrics/base.py:92-129).  One wave per impression, lane c owns aspect class c (<= 64 classes):
@@ -883,6 +1070,41 @@ int manner_hip_aspect_metrics(const int32_t* topk_idx, const int32_t* cand_aspec
     return fail(MANNER_HIP_E_INVALID, "aspect_metrics: bad argument (2 <= num_classes <= 64)");
   hipLaunchKernelGGL(aspect_metrics_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, topk_idx, cand_aspect,
                      hist_aspect, cand_off, hist_off, B, k, num_classes, diversity, personalization);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+size_t manner_hip_score_fuse_rank_workspace_bytes(int32_t K, int64_t total_candidates) {
+  return (size_t)(K > 0 ? K : 0) * (size_t)(total_candidates > 0 ? total_candidates : 0) * sizeof(float) + 256;
+}
+
+int manner_hip_score_fuse_rank(const float* const* tables, int32_t K, const float* weights, int64_t n_rows, int32_t D, const int32_t* hist_idx,
+                               const int64_t* hist_off, const int32_t* cand_idx, const int64_t* cand_off, int64_t B, int64_t total_candidates,
+                               const float* labels, int32_t k, float* scores, float* pad_value, int32_t* topk_idx, float* ndcg, float* mrr,
+                               void* workspace, size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream) {
+  if (B == 0) return MANNER_HIP_OK;
+  if (!tables || K < 1 || K > PC_MAXK || (K > 1 && !weights) || !hist_idx || !hist_off || !cand_idx || !cand_off || !scores || k < 1 ||
+      ((ndcg || mrr) && !labels) || !workspace)
+    return fail(MANNER_HIP_E_INVALID, "score_fuse_rank: bad argument (1 <= K <= %d)", PC_MAXK);
+  if (D != 768 && D != 1024) return fail(MANNER_HIP_E_INVALID, "score_fuse_rank: D=%d (768 or 1024; other widths: the separate kernels)", D);
+  if (n_rows <= 0 || total_candidates < 0) return fail(MANNER_HIP_E_INVALID, "score_fuse_rank: bad sizes");
+  if (workspace_bytes < manner_hip_score_fuse_rank_workspace_bytes(K, total_candidates)) return fail(MANNER_HIP_E_WORKSPACE, "score_fuse_rank: workspace too small");
+  TablePtrs tp{};
+  FuseWeights fw{};
+  for (int i = 0; i < K; ++i) {
+    if (!tables[i]) return fail(MANNER_HIP_E_INVALID, "score_fuse_rank: table %d is NULL", i);
+    tp.t[i] = tables[i];
+    if (i > 0) fw.w[i - 1] = weights[i - 1];
+  }
+  const int fuse = K > 1 ? 1 : 0;                        // one table: the CR-Module's raw late-fusion scores (cr_module.py:105-131)
+  const size_t lds = (size_t)(5 * D + ((K > 2 ? K : 2) + 2) * PC_CAP) * sizeof(float);
+  float* scratch = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  if (D == 768)
+    hipLaunchKernelGGL((score_fuse_rank_kernel<3, 2>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, tp, K, fuse, fw, n_rows, hist_idx,
+                       hist_off, cand_idx, cand_off, labels, k, scores, pad_value, topk_idx, ndcg, mrr, scratch, total_candidates, status);
+  else
+    hipLaunchKernelGGL((score_fuse_rank_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, tp, K, fuse, fw, n_rows, hist_idx,
+                       hist_off, cand_idx, cand_off, labels, k, scores, pad_value, topk_idx, ndcg, mrr, scratch, total_candidates, status);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }

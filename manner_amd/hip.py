@@ -604,6 +604,40 @@ def rank_ndcg(scores: Tensor, labels: Optional[Tensor], cand_off: Tensor, k: int
     return (topk, ndcg, mrr) if with_mrr else (topk, ndcg)
 
 
+def score_fuse_rank(tables: Sequence[Tensor], weights: Sequence[float], hist_idx: Tensor, hist_off: Tensor, cand_idx: Tensor, cand_off: Tensor,
+                    labels: Optional[Tensor] = None, k: int = 10, with_pad_value: bool = False):
+    """SURVEY §8e phase C in ONE launch (manner_hip_score_fuse_rank): K module tables [n, D] (D = 768 / 1024, float32) -> fused ragged
+    scores [sum c_i] (K == 1: the raw late-fusion scores), top-k positions int32 [B, k], nDCG@k and MRR float32 [B] (with labels);
+    bit-identical to score_late_fusion x K -> zscore_fuse -> rank_ndcg.  Returns a dict like hotpath.score_impressions."""
+    tables = [_dev(t, torch.float32, "table").contiguous() for t in tables]
+    kk = len(tables)
+    assert kk >= 1 and len(weights) == kk - 1 and all(t.shape == tables[0].shape for t in tables)
+    dev = tables[0].device
+    hist_idx, cand_idx = _dev(hist_idx, torch.int32, "hist_idx").contiguous(), _dev(cand_idx, torch.int32, "cand_idx").contiguous()
+    hist_off, cand_off = _dev(hist_off, torch.int64, "hist_off").contiguous(), _dev(cand_off, torch.int64, "cand_off").contiguous()
+    nb, total = hist_off.numel() - 1, int(cand_idx.numel())
+    scores = torch.empty((total,), dtype=torch.float32, device=dev)
+    topk = torch.empty((nb, k), dtype=torch.int32, device=dev)
+    pad = torch.empty((nb,), dtype=torch.float32, device=dev) if with_pad_value else None
+    ndcg = mrr = None
+    if labels is not None:
+        labels = _dev(labels, torch.float32, "labels").contiguous()
+        ndcg, mrr = torch.empty((nb,), dtype=torch.float32, device=dev), torch.empty((nb,), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nbytes = int(lib.manner_hip_score_fuse_rank_workspace_bytes(kk, total))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    tp = (C.c_void_p * kk)(*[t.data_ptr() for t in tables])
+    w = (C.c_float * max(1, kk - 1))(*[float(v) for v in weights])
+    with torch.cuda.device(dev):
+        _lib.check(lib.manner_hip_score_fuse_rank(tp, kk, w, tables[0].shape[0], tables[0].shape[1], _ptr(hist_idx), _ptr(hist_off), _ptr(cand_idx),
+                                                  _ptr(cand_off), nb, total, _ptr(labels), k, _ptr(scores), _ptr(pad), _ptr(topk), _ptr(ndcg),
+                                                  _ptr(mrr), ws.data_ptr(), nbytes, _ptr(device_status(dev).word), _stream()))
+    res = {"scores": scores, "topk": topk, "ndcg": ndcg, "mrr": mrr}
+    if with_pad_value:
+        res["pad"] = pad
+    return res
+
+
 def aspect_metrics(topk: Tensor, cand_aspect: Tensor, cand_off: Tensor, num_classes: int,
                    hist_aspect: Optional[Tensor] = None, hist_off: Optional[Tensor] = None):
     """Aspect Diversity@k (and, with the history aspects, Personalization@k) per impression from the

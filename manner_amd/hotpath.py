@@ -169,12 +169,26 @@ def encode_table(encoder: hip.HipEncoder, ids: Tensor, mask: Tensor, precision: 
 
 
 def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights: Sequence[float] = (),
-                      labels: Optional[Tensor] = None, k: int = 10) -> Dict[str, Tensor]:
+                      labels: Optional[Tensor] = None, k: int = 10, fused: Optional[bool] = None) -> Dict[str, Tensor]:
     """Score impressions against per-module tables, fuse, rank.  ``imp``: hist_idx/cand_idx int32,
     hist_off/cand_off int64 (device).  With a single table and no weights the scores are the raw
-    late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion."""
-    planes = []
+    late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion.
+    ``fused`` (default: whenever the tables are float32 with D = 768 / 1024): SURVEY §8e phase C as ONE launch
+    (``hip.score_fuse_rank``: the K score planes stay in LDS); ``fused=False`` (or MANNER_PHASE_C=separate): K scorer launches ->
+    ``zscore_fuse`` -> ``rank_ndcg``.  The two give the same bits."""
+    import os
     hip.status_poll(tables[0].device)                 # an out-of-range news index of an earlier call raises here (IndexError in the reference)
+    can_fuse = all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] in (768, 1024) for t in tables) \
+        and 1 <= len(tables) <= 9
+    if fused is None:
+        fused = can_fuse and os.environ.get("MANNER_PHASE_C", "fused") != "separate"
+    if fused:
+        if not can_fuse:
+            raise ValueError("score_impressions(fused=True): float32 tables with D = 768 or 1024 only")
+        res = hip.score_fuse_rank(tables, list(weights), imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"], labels=labels, k=k)
+        hip.status_arm(tables[0].device)
+        return res
+    planes = []
     for j, t in enumerate(tables):
         if j > 0 and weights[j - 1] == 0:
             continue

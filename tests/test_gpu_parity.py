@@ -813,6 +813,57 @@ def test_scorer_gives_identical_scores_to_repeated_candidates():
         assert pos == sorted(pos)                               # occurrences of one news keep their order
 
 
+@pytest.mark.parametrize("D", [768, 1024])
+@pytest.mark.parametrize("weights", [(), (-0.3,), (-0.3, 0.2), (0.0, 0.7), (0.5, 0.0, -0.2)])
+def test_phase_c_in_one_launch_equals_the_three_kernel_path(D, weights):
+    """SURVEY §8e phase C / VERDICT r3 item 6: manner_hip_score_fuse_rank — gather-mean-dot over K module tables, per-impression
+    z-score, weighted fusion, stable top-k, nDCG@k and MRR in ONE kernel, the K score planes in LDS — against
+    score_late_fusion x K -> zscore_fuse -> rank_ndcg (reference ensemble_module.py:95-151, cr_module.py:267-273): scores, top-k
+    lists, nDCG@10 / @5, MRR and the padded-slot value BIT-IDENTICAL.  Ragged impressions: 1 .. 50 history rows, candidate counts 1
+    (NaN z-scores, as in the reference), 2, 64, 65, 256, 257, 300, 320 (the last one in LDS), 321 and 700 (scratch path), repeated
+    candidates (exact ties), a zero weight (module skipped), no labels."""
+    K = 1 + len(weights)
+    n_news = 3000
+    g = torch.Generator(device="cpu").manual_seed(13 * K + D)
+    tables = [(torch.randn((n_news, D), generator=g) * (1.0 + 0.5 * k) + 0.3 * k).to(DEV) for k in range(K)]
+    rng = np.random.default_rng(5)
+    cands = [1, 2, 3, 37, 64, 65, 128, 256, 257, 300, 320, 321, 700] + rng.integers(2, 120, size=40).tolist()
+    hists = rng.integers(1, 51, size=len(cands)).tolist()
+    ho = np.concatenate([[0], np.cumsum(hists)]).astype(np.int64)
+    co = np.concatenate([[0], np.cumsum(cands)]).astype(np.int64)
+    hidx = rng.integers(0, n_news, size=int(ho[-1])).astype(np.int32)
+    cidx = rng.integers(0, n_news, size=int(co[-1])).astype(np.int32)
+    cidx[co[5]:co[5] + 6] = cidx[co[5]]                                         # exact ties inside one impression
+    labels = (rng.random(int(co[-1])) < 0.1).astype(np.float32)
+    labels[co[:-1]] = 1.0
+    labels[co[7]:co[8]] = 0.0                                                   # an impression without a positive: nDCG 0 (empty_target_action="neg")
+    imp = {"hist_idx": _cuda(hidx), "hist_off": _cuda(ho), "cand_idx": _cuda(cidx), "cand_off": _cuda(co)}
+    for lab in (_cuda(labels), None):
+        for k in (10, 5):
+            a = hotpath.score_impressions(tables, imp, weights=weights, labels=lab, k=k, fused=True)
+            b = hotpath.score_impressions(tables, imp, weights=weights, labels=lab, k=k, fused=False)
+            hip.check_status(DEV)
+            sa, sb = a["scores"].cpu(), b["scores"].cpu()
+            assert torch.equal(torch.isnan(sa), torch.isnan(sb))
+            assert torch.equal(sa.nan_to_num(0.0), sb.nan_to_num(0.0)), float((sa - sb).abs().nan_to_num(0.0).max())
+            assert torch.equal(a["topk"].cpu(), b["topk"].cpu())
+            if lab is not None:
+                for key in ("ndcg", "mrr"):
+                    xa, xb = a[key].cpu(), b[key].cpu()
+                    assert torch.equal(torch.isnan(xa), torch.isnan(xb)) and torch.equal(xa.nan_to_num(0.0), xb.nan_to_num(0.0)), key
+            else:
+                assert a["ndcg"] is None and a["mrr"] is None
+    # the padded-slot value of the dense ensemble output (ensemble_module.py:145-149)
+    if K > 1:
+        used = [w for w in weights if w != 0]
+        planes = torch.stack([hip.score_late_fusion(t, imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"])
+                              for j, t in enumerate(tables) if j == 0 or weights[j - 1] != 0])
+        _, pad_ref = hip.zscore_fuse(planes, used, imp["cand_off"], with_pad_value=True)
+        res = hip.score_fuse_rank(tables, list(weights), imp["hist_idx"], imp["hist_off"], imp["cand_idx"], imp["cand_off"], with_pad_value=True)
+        pa, pb = res["pad"].cpu(), pad_ref.cpu()
+        assert torch.equal(torch.isnan(pa), torch.isnan(pb)) and torch.equal(pa.nan_to_num(0.0), pb.nan_to_num(0.0))
+
+
 def test_whole_row_scorer_kernels_equal_the_column_block_kernel(monkeypatch):
     """D = 768 / 1024 run the whole-row kernels (several rows in flight per wave, the first candidate batch fetched before the
     history sums meet in LDS); MANNER_HIP_SCORER_GENERIC=1 forces the column-block kernel they replaced.  Same row -> wave
