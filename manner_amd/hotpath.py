@@ -173,15 +173,21 @@ def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights:
     """Score impressions against per-module tables, fuse, rank.  ``imp``: hist_idx/cand_idx int32,
     hist_off/cand_off int64 (device).  With a single table and no weights the scores are the raw
     late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion.
-    ``fused`` (default: whenever the tables are float32 with D = 768 / 1024): SURVEY §8e phase C as ONE launch
-    (``hip.score_fuse_rank``: the K score planes stay in LDS); ``fused=False`` (or MANNER_PHASE_C=separate): K scorer launches ->
-    ``zscore_fuse`` -> ``rank_ndcg``.  The two give the same bits."""
+    ``fused``: SURVEY §8e phase C as ONE launch (``hip.score_fuse_rank``: float32 tables with D = 768 / 1024, the K score planes stay in
+    LDS) or as K scorer launches -> ``zscore_fuse`` -> ``rank_ndcg``; the two give the same bits.  Default (MANNER_PHASE_C=auto): one
+    launch for a single table or tables that fit the Infinity Cache together, separate launches otherwise; MANNER_PHASE_C=fused /
+    separate force either."""
     import os
     hip.status_poll(tables[0].device)                 # an out-of-range news index of an earlier call raises here (IndexError in the reference)
     can_fuse = all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] in (768, 1024) for t in tables) \
         and 1 <= len(tables) <= 9
     if fused is None:
-        fused = can_fuse and os.environ.get("MANNER_PHASE_C", "fused") != "separate"
+        # One launch wins where the K tables stay cache-resident together (or K = 1: -15 % at the MIND-small shape); with three 495 MB
+        # tables it interleaves 1.5 GB of row gathers per impression where the separate launches sweep ONE table at a time through the
+        # 256 MiB Infinity Cache: 14.9 vs 13.6 ms for the MIND-large dev set (profiles/r4_final) — so the default follows the footprint.
+        env = os.environ.get("MANNER_PHASE_C", "auto")
+        small = len(tables) == 1 or sum(t.numel() * 4 for t in tables) <= 256 * 2 ** 20
+        fused = can_fuse and env != "separate" and (env == "fused" or small)
     if fused:
         if not can_fuse:
             raise ValueError("score_impressions(fused=True): float32 tables with D = 768 or 1024 only")

@@ -91,13 +91,18 @@ def main():
             with open(ts, newline="") as f:
                 for r in csv.DictReader(f):
                     dur[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
-        kmap = {"score_late_fusion": ["score_late_fusion_rows_kernel"], "score_late_fusion_f16": ["score_late_fusion_f16_rows_kernel"], "additive_pool": ["pool_logits_kernel", "pool_apply_kernel"],
-                "dot": ["dot_rows_kernel"], "zscore_fuse": ["zscore_fuse_kernel"], "to_dense": ["to_dense_rows_kernel"]}
+        kmap = {"score_late_fusion": ["score_late_fusion_rows_kernel"], "score_late_fusion_f16": ["score_late_fusion_f16_rows_kernel"],
+                "additive_pool": ["pool_fused_kernel", "pool_pack_w_kernel", "pool_w_max_kernel"] if "additive_pool_strict" in probe else ["pool_logits_kernel", "pool_apply_kernel"],
+                "additive_pool_strict": ["pool_logits_kernel", "pool_apply_kernel"],
+                "dot": ["dot_rows_kernel"], "zscore_fuse": ["zscore_fuse_kernel"], "to_dense": ["to_dense_rows_kernel"],
+                "phase_c_one_launch": ["score_fuse_rank_kernel"]}
         out = {"_note": "bytes: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (KiB counters, gfx950 64-byte correction of wide reads, "
                         "MI355X_MICROARCH.md); durations from the --stats pass of the same script; algorithmic bytes from tools/tail_probe.py"}
         for op, kernels in kmap.items():
             ent = dict(probe.get(op, {}))
             tot_bytes, tot_us = 0.0, 0.0
+            if op not in probe:
+                continue
             for k in kernels:
                 match = lambda n: k in n   # noqa: E731
                 fk = [v for n, v in fetch.items() if match(n)]

@@ -3,14 +3,15 @@
 #   bash tools/profile_leg_r3.sh train [bf16]        the training-step leg (2 variants x (2 warm-up + 5 timed) steps)
 #   bash tools/profile_leg_r3.sh dropin 8:train      one case of the drop-in leg (2 warm-up + 8 timed steps)
 # prints the total kernel time and the top kernels; raw output under gpurun_out/r3/leg_prof.
-set -e
+set -eu
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 LEG=${1:-train}
 ARG=${2:-}
-O=$GRAFT_REPO_ROOT/gpurun_out/r3/leg_prof
-rm -rf $O && mkdir -p $O
+O="$GRAFT_REPO_ROOT/gpurun_out/r3/leg_prof"
+rm -rf "$O" && mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o leg -- python3 $GRAFT_REPO_ROOT/tools/${LEG}_probe.py $ARG > $O/leg.json 2> $O/err.log
-find $O -name "*kernel_trace.csv" -size +20M -delete
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o leg -- python3 "$GRAFT_REPO_ROOT/tools/${LEG}_probe.py" $ARG > "$O/leg.json" 2> "$O/err.log"
+find "$O" -name "*kernel_trace.csv" -size +20M -delete
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/**/*kernel_stats.csv", recursive=True)[0]

@@ -53,7 +53,11 @@ W, bq, q = torch.randn((Q, D), device=dev, generator=g) * 0.05, torch.zeros(Q, d
 for _ in range(3):
     hip.additive_pool(x, W, bq, q)
 out["additive_pool"] = {"launches": 3, "algorithmic_bytes_per_launch": x.numel() * 4 + B * D * 4 + (Q * D + 2 * Q) * 4,
-                        "kernels": "pool_logits_kernel (reads x once) + pool_apply_kernel (reads x again)"}
+                        "kernels": "round 4: pool_fused_kernel (x read ONCE, resident as scaled f16 hi/lo pairs) + pool_w_max / pool_pack_w (W, a few hundred KB)"}
+for _ in range(3):
+    hip.additive_pool(x, W, bq, q, strict=True)
+out["additive_pool_strict"] = {"launches": 3, "algorithmic_bytes_per_launch": x.numel() * 4 + B * D * 4 + (Q * D + 2 * Q) * 4,
+                               "kernels": "pool_logits_kernel (reads x once, f32 matrix pipe) + pool_apply_kernel (reads x again)"}
 del x
 user, cand = torch.randn((B, 1, D), device=dev, generator=g), torch.randn((B, C, D), device=dev, generator=g)
 for _ in range(3):
@@ -72,6 +76,23 @@ width = int(np.diff(imp["cand_off"][: nb + 1]).max())
 for _ in range(3):
     hip.to_dense(cv, off[: nb + 1].contiguous(), width)
 out["to_dense"] = {"launches": 3, "algorithmic_bytes_per_launch": cv.numel() * 4 + nb * width * D * 4}
+del cand, cv, planes
+torch.cuda.synchronize()
+# SURVEY 8e phase C: one launch (planes in LDS) vs K + 2 launches, K = 3 MIND-large-shaped tables (3 x 495 MB), 131 072 impressions
+from manner_amd import hotpath  # noqa: E402
+tabs = [torch.randn((n_news, D), device=dev, generator=g) for _ in range(3)]
+labels = torch.from_numpy(imp["labels"]).to(dev)
+k_bytes = 3 * (occ * (D * 4 + 4)) + total * 4 + total * 4 + n_imp * (10 * 4 + 8)
+for _ in range(3):
+    fus = hotpath.score_impressions(tabs, dimp, weights=(-0.3, 0.2), labels=labels, k=10, fused=True)
+out["phase_c_one_launch"] = {"launches": 3, "tables": 3, "impressions": n_imp, "algorithmic_bytes_per_launch": k_bytes,
+                             "kernels": "score_fuse_rank_kernel"}
+for _ in range(3):
+    sep = hotpath.score_impressions(tabs, dimp, weights=(-0.3, 0.2), labels=labels, k=10, fused=False)
+out["phase_c_separate"] = {"launches": 3, "tables": 3, "impressions": n_imp,
+                           "algorithmic_bytes_per_launch": k_bytes + 2 * 3 * total * 4 + 2 * total * 4,
+                           "kernels": "3 x score_late_fusion_rows_kernel + zscore_fuse_kernel + rank_ndcg_kernel (the planes and the fused scores round-trip HBM)"}
+out["phase_c_one_launch"]["bit_identical_to_separate"] = bool(torch.equal(fus["scores"].nan_to_num(0.0), sep["scores"].nan_to_num(0.0)) and torch.equal(fus["topk"], sep["topk"]))
 torch.cuda.synchronize()
 hip.check_status(dev)
 print(json.dumps(out))
