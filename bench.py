@@ -389,9 +389,9 @@ def small_ops_leg(dev, B=4096, S=50, D=768, Q=200, C=37):
     diff = float((hip.additive_pool(x, W, bq, q) - hip.additive_pool(x, W, bq, q, strict=True)).abs().max())
     out["additive_pool"] = {"shape": {"B": B, "S": S, "D": D, "Q": Q}, "ms": ms, "algorithmic_bytes": nbytes,
                             "GB/s": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBS,
-                            "logit_tflops_bf16x3": 3 * flops / ms / 1e9, "frac_of_bf16_mfma_peak": 3 * flops / ms / 1e9 / BF16_PEAK_TFLOPS,
+                            "logit_tflops_f16x3": 3 * flops / ms / 1e9, "frac_of_f16_mfma_peak": 3 * flops / ms / 1e9 / BF16_PEAK_TFLOPS,
                             "max_abs_diff_vs_strict": diff,
-                            "bound": "HBM (x read ONCE, kept on the CU as bf16 hi/lo pairs; logits as bf16x3 products on the bf16 matrix pipe: csrc/pool.hip)",
+                            "bound": "HBM by design (x read ONCE, kept on the CU as power-of-two-scaled f16 hi/lo pairs; logits as x3 split products on the f16 matrix pipe: csrc/pool.hip); measured: the W stream per MFMA (DESIGN.md section 4, round 4)",
                             "strict_f32_two_pass": {"ms": ms_strict, "GB/s": nbytes / ms_strict / 1e6, "frac_of_8TBps": nbytes / ms_strict / 1e6 / HBM_PEAK_GBS,
                                                     "logit_tflops_f32": flops / ms_strict / 1e9, "frac_of_f32_mfma_peak": flops / ms_strict / 1e9 / F32_PEAK_TFLOPS,
                                                     "bound": "f32 MFMA (exact f32 x.W^T: 0.5 kFLOP per byte of x) — and the second pass re-reads x"}}

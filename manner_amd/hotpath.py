@@ -175,18 +175,19 @@ def score_impressions(tables: Sequence[Tensor], imp: Dict[str, Tensor], weights:
     late-fusion dot products (CRModule.forward); otherwise the ensemble's z-scored fusion.
     ``fused``: SURVEY §8e phase C as ONE launch (``hip.score_fuse_rank``: float32 tables with D = 768 / 1024, the K score planes stay in
     LDS) or as K scorer launches -> ``zscore_fuse`` -> ``rank_ndcg``; the two give the same bits.  Default (MANNER_PHASE_C=auto): one
-    launch for a single table or tables that fit the Infinity Cache together, separate launches otherwise; MANNER_PHASE_C=fused /
+    launch for one or two tables or tables that fit the Infinity Cache together, separate launches otherwise; MANNER_PHASE_C=fused /
     separate force either."""
     import os
     hip.status_poll(tables[0].device)                 # an out-of-range news index of an earlier call raises here (IndexError in the reference)
     can_fuse = all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] in (768, 1024) for t in tables) \
         and 1 <= len(tables) <= 9
     if fused is None:
-        # One launch wins where the K tables stay cache-resident together (or K = 1: -15 % at the MIND-small shape); with three 495 MB
-        # tables it interleaves 1.5 GB of row gathers per impression where the separate launches sweep ONE table at a time through the
-        # 256 MiB Infinity Cache: 14.9 vs 13.6 ms for the MIND-large dev set (profiles/r4_final) — so the default follows the footprint.
+        # One launch wins for one or two tables (K = 1: 0.99 vs 1.13 ms MIND-small, 5.8 vs 7.0 ms on the 660 MB roberta-large table;
+        # K = 2: 1.82 vs 1.91 ms) and for tables that stay cache-resident together; with three 495 MB tables it interleaves 1.5 GB of row
+        # gathers per impression where the separate launches sweep ONE table at a time through the 256 MiB Infinity Cache: 15.0 vs 13.6 ms
+        # for the MIND-large dev set (profiles/r4_final/bench_config3.json) — so the default follows the footprint.
         env = os.environ.get("MANNER_PHASE_C", "auto")
-        small = len(tables) == 1 or sum(t.numel() * 4 for t in tables) <= 256 * 2 ** 20
+        small = len(tables) <= 2 or sum(t.numel() * 4 for t in tables) <= 256 * 2 ** 20
         fused = can_fuse and env != "separate" and (env == "fused" or small)
     if fused:
         if not can_fuse:
