@@ -410,6 +410,16 @@ int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t
  * the last bits, vary between runs — as torch's CUDA embedding backward). */
 size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer);
 size_t manner_hip_train_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t m_bound);
+/* ABI v5 — optional cache of the 16-bit weight copies the 16-bit training modes make on every call (round 4).  Registers, for the NEXT
+ * manner_hip_train_forward / _backward call of THIS thread (consumed by it; ignored in fp32 mode), 2 * n_weights caller-owned device
+ * buffers (host array `slots`, entries may be NULL = not cached) and as many host flags `valid` (in / out):
+ *   slot 2 i     the mode's 16-bit copy of weight i of the table, same layout          (read by the forward GEMMs)
+ *   slot 2 i + 1 the 16-bit copy of its transpose                                      (read by the data-gradient GEMMs)
+ *   at a layer's query weight: the packed [3H, H] Q | K | V copy / its [H, 3H] transpose; at its query bias, slot 2 i: f32 [3H] biases.
+ * valid[s] == 0: the library fills slot s on first use and sets the flag; != 0: it reads the slot and launches nothing.  Meant for
+ * FROZEN weights (reference news_encoder.py:24-27 freezes layers by name): the caller clears a flag when the weight's contents change
+ * and keeps the buffers alive until the stream has passed the call.  slots == NULL: no cache (the default). */
+int manner_hip_train_weight_cache(void* const* slots /*host*/, int32_t* valid /*host, in/out*/, int32_t n_slots);
 int manner_hip_train_forward(const manner_hip_encoder_config* cfg, const float* const* weights /*host*/, int32_t n_weights,
                              const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, int64_t m_bound,
                              int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "manner_hip_eval_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P]),
     "manner_hip_train_saved_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64, _I32]),
     "manner_hip_train_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64]),
+    "manner_hip_train_weight_cache": (C.c_int, [C.POINTER(_P), C.POINTER(_I32), _I32]),
     "manner_hip_train_forward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _P,
                                            C.c_float, C.c_float, C.c_float, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P, _P]),
     "manner_hip_train_backward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _I64, _I64, _I64, _I32, _I32,

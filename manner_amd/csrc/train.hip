@@ -996,8 +996,40 @@ struct Ctx {
   // of L.qkv (16-bit or f32) follows from it.
   bool attn_mfma = false;
   bool mfma_attn() const { return attn_mfma; }
+  // Optional cache of 16-bit weight copies across calls (manner_hip_train_weight_cache; round 4): slot 2 i = the mode's 16-bit copy of
+  // weight i of the table in its own layout, slot 2 i + 1 = its transpose (what the data-gradient GEMMs read); at a layer's Q weight:
+  // the packed [3H, H] Q | K | V copy and its transpose, at its Q bias (slot 2 i): the f32 [3H] bias concatenation.  A slot the caller
+  // left NULL is not cached; valid[s] == 0: filled on first use and marked.  FROZEN weights only — the caller clears `valid` when a
+  // weight's contents change.
+  void* const* wc_slots = nullptr;
+  int32_t* wc_valid = nullptr;
+  int wc_n = 0, n_w = 0;
+  int index_of(const float* W) const {
+    for (int i = 0; i < n_w; ++i) if (w[i] == W) return i;
+    return -1;
+  }
+  void* slot(int s) const { return (wc_slots && s >= 0 && s < wc_n) ? wc_slots[s] : nullptr; }
   unsigned ew_grid(int64_t width) const { const int64_t b = (Mb * width + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); }
 };
+
+int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev,
+                 int64_t rv_host, int64_t ks = 0);
+// The mode's 16-bit copy of weight matrix W [rows, cols] f32 (tr: of its transpose [cols, rows]) — from the caller's cache slot when
+// one was registered for it (filled here on first use), else converted into `scratch`.  wi: W's index in the weight table (-1: look it up).
+int weight16(Ctx& t, const float* W, int rows, int cols, bool tr, void* scratch, const void** out, int wi = -1) {
+  if (wi < 0) wi = t.index_of(W);
+  const int si = wi < 0 ? -1 : 2 * wi + (tr ? 1 : 0);
+  void* dst = t.slot(si);
+  if (dst && t.wc_valid[si]) { *out = dst; return MANNER_HIP_OK; }
+  int rc;
+  void* to = dst ? dst : scratch;
+  if (tr) rc = transpose_to(t, W, DT_F32, rows, cols, to, rows, nullptr, rows, 0);
+  else rc = convert_f32_to_16(t.dt(), W, to, (int64_t)rows * cols, t.s);
+  if (rc) return rc;
+  if (dst) t.wc_valid[si] = 1;
+  *out = to;
+  return MANNER_HIP_OK;
+}
 
 // Y [Mb, Nout] = X [Mb, K] . W [Nout, K]^T + bias      (f32 in / out; operands rounded to the 16-bit type in the mixed modes)
 // X16: the producer's 16-bit copy of X when there is one (else X is converted here)
@@ -1008,8 +1040,9 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
     if ((rc = convert_f32_to_16(t.dt(), X, t.wk.a16, t.Mb * K, t.s))) return rc;
     X16 = t.wk.a16;
   }
-  if ((rc = convert_f32_to_16(t.dt(), W, t.wk.b16, (int64_t)Nout * K, t.s))) return rc;
-  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, t.wk.b16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
+  const void* w16;
+  if ((rc = weight16(t, W, Nout, K, false, t.wk.b16, &w16))) return rc;
+  return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, w16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
 }
 
 // R = dropout(X W^T + bias) + residual (attention-output / FFN-output projection of the forward pass, modeling_bert.py:289-293,
@@ -1027,7 +1060,7 @@ void launch_transpose(const void* in, int64_t cols, void* out, int64_t rows_out,
 }
 // `in` is [rows_in, cols] of type in_dt (f32, or — 16-bit modes — already the mode's 16-bit type); ks = 0: one slice
 int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev,
-                 int64_t rv_host, int64_t ks = 0) {
+                 int64_t rv_host, int64_t ks) {
   (void)rows_in;
   if (ks <= 0) ks = rows_out;
   if (in_dt != DT_F32 && in_dt != t.dt()) return fail(MANNER_HIP_E_INVALID, "train: transpose source type %d in mode %d", (int)in_dt, (int)t.dt());
@@ -1046,10 +1079,12 @@ int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t c
 // dX [Mb, K] = dY [Mb, Nout] . W [Nout, K]  (+ residual [Mb, K] f32 when given: fused into the GEMM's epilogue where the shape
 // allows — *fused tells the caller whether it was).  out_dt: f32, or (16-bit modes) the mode's 16-bit type for the I-wide d g.
 int linear_dgrad(Ctx& t, const float* dY, const float* W, void* dX, int Nout, int K, const void* dY16 = nullptr, DType out_dt = DT_F32,
-                 const float* residual = nullptr, bool* fused = nullptr) {
+                 const float* residual = nullptr, bool* fused = nullptr, int wi = -1) {
   int rc;
   if (fused) *fused = false;
-  if ((rc = transpose_to(t, W, DT_F32, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc;       // W^T [K, Nout]
+  const void* wt = t.wk.b16;                                                                        // W^T [K, Nout]
+  if (t.dt() == DT_F32) { if ((rc = transpose_to(t, W, DT_F32, Nout, K, t.wk.b16, Nout, nullptr, Nout))) return rc; }
+  else if ((rc = weight16(t, W, Nout, K, true, t.wk.b16, &wt, wi))) return rc;
   const void* x = dY;
   if (t.dt() != DT_F32) {
     if (!dY16) {
@@ -1059,10 +1094,10 @@ int linear_dgrad(Ctx& t, const float* dY, const float* W, void* dX, int Nout, in
     x = dY16;
     if (residual && out_dt == DT_F32 && t.Mb % 256 == 0 && K % 256 == 0 && Nout >= 128) {
       if (fused) *fused = true;
-      return gemm_tn(t.dt(), DT_F32, EPI_BIAS_RES_F32, x, t.wk.b16, t.wk.zero, residual, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
+      return gemm_tn(t.dt(), DT_F32, EPI_BIAS_RES_F32, x, wt, t.wk.zero, residual, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
     }
   }
-  return gemm_tn(t.dt(), out_dt, EPI_BIAS, x, t.wk.b16, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
+  return gemm_tn(t.dt(), out_dt, EPI_BIAS, x, wt, t.wk.zero, nullptr, dX, t.Mb, K, Nout, t.sv.m_total, t.s);
 }
 
 // dW [Nout, K] = dY [Mb, Nout]^T . X [Mb, K]   (the reduction runs over the token rows; rows >= *m_total contribute zeros)
@@ -1146,8 +1181,9 @@ int linear_fwd_drop_res(Ctx& t, const float* X, const void* X16, const float* W,
                         int K, const Drop& drop, const int32_t* rowmap) {
   int rc;
   if (t.dt() != DT_F32 && X16 && t.Mb % 256 == 0 && Nout % 256 == 0 && K >= 128 && (K * 2) % 128 == 0) {
-    if ((rc = convert_f32_to_16(t.dt(), W, t.wk.b16, (int64_t)Nout * K, t.s))) return rc;
-    return gemm_tn_drop_res(t.dt(), X16, t.wk.b16, bias, residual, R, t.Mb, Nout, K, t.sv.m_total, drop, rowmap, t.s);
+    const void* w16;
+    if ((rc = weight16(t, W, Nout, K, false, t.wk.b16, &w16))) return rc;
+    return gemm_tn_drop_res(t.dt(), X16, w16, bias, residual, R, t.Mb, Nout, K, t.sv.m_total, drop, rowmap, t.s);
   }
   if ((rc = linear_fwd(t, X, W, bias, t.wk.tmp, Nout, K, X16))) return rc;
   return dropout_add(t, t.wk.tmp, residual, R, Nout, drop, nullptr, rowmap);
@@ -1234,6 +1270,9 @@ static bool recorded_attn_path(const void* saved, bool rule) {
   return it == g_attn_path.end() ? rule : it->second != 0;
 }
 
+struct WCacheArg { void* const* slots = nullptr; int32_t* valid = nullptr; int n = 0; };
+static thread_local WCacheArg g_next_wcache;
+
 int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, int64_t N, int64_t Lp, int64_t Mb,
           int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s) {
   int rc;
@@ -1245,6 +1284,15 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
     if (!weights[i]) return fail(MANNER_HIP_E_INVALID, "train: weight %d is NULL", i);
   if (!saved || !ws) return fail(MANNER_HIP_E_INVALID, "train: null buffer");
   t.c = cfg; t.w = weights; t.N = N; t.Lp = Lp; t.Mb = Mb; t.prec = precision; t.s = s;
+  t.n_w = n_weights;
+  if (g_next_wcache.slots) {                           // registered for THIS call by manner_hip_train_weight_cache (same thread)
+    if (g_next_wcache.n == 2 * n_weights && precision != MANNER_HIP_PREC_F32) {
+      t.wc_slots = g_next_wcache.slots;
+      t.wc_valid = g_next_wcache.valid;
+      t.wc_n = g_next_wcache.n;
+    }
+    g_next_wcache = WCacheArg{};
+  }
   Bump bs(saved), bw(ws);
   plan_saved(bs, t.sv, *cfg, N, Mb, start);
   plan_work(bw, t.wk, *cfg, Mb);
@@ -1270,7 +1318,24 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   hipStream_t s = t.s;
   const bool mixed = t.dt() != DT_F32;
   const bool mfma = t.mfma_attn();
-  if ((rc = pack_qkv_weights(t, l, mfma ? t.wk.b16 : nullptr))) return rc;
+  // the packed Q | K | V weight (16-bit) and bias: from the caller's cache for a frozen layer (no launch at all once filled)
+  const int wiq = MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + MANNER_HIP_WL_Q_W, wibq = MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + MANNER_HIP_WL_Q_B;
+  const void* qkv_w16 = t.wk.b16;
+  const float* qkv_b = t.wk.bcat;
+  void* cw = mfma ? t.slot(2 * wiq) : nullptr;
+  float* cb = mfma ? static_cast<float*>(t.slot(2 * wibq)) : nullptr;
+  if (cw && cb && t.wc_valid[2 * wiq] && t.wc_valid[2 * wibq]) {
+    qkv_w16 = cw;
+    qkv_b = cb;
+  } else {
+    if ((rc = pack_qkv_weights(t, l, mfma ? (cw && cb ? cw : t.wk.b16) : nullptr))) return rc;
+    if (cw && cb) {
+      MANNER_HIP_TRY(hipMemcpyAsync(cb, t.wk.bcat, (size_t)3 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+      t.wc_valid[2 * wiq] = t.wc_valid[2 * wibq] = 1;
+      qkv_w16 = cw;
+      qkv_b = cb;
+    }
+  }
   const Drop da_m = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
   if (mfma) {
     // Q | K | V straight in the 16-bit type (one rounding, at the GEMM's output — what the MFMA attention reads), then the
@@ -1280,7 +1345,7 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
       if ((rc = convert_f32_to_16(t.dt(), x_in, t.wk.a16, t.Mb * H, s))) return rc;
       x16 = t.wk.a16;
     }
-    if ((rc = gemm_tn(t.dt(), t.dt(), EPI_BIAS, x16, t.wk.b16, t.wk.bcat, nullptr, L.qkv, t.Mb, 3 * H, H, t.sv.m_total, s))) return rc;
+    if ((rc = gemm_tn(t.dt(), t.dt(), EPI_BIAS, x16, qkv_w16, qkv_b, nullptr, L.qkv, t.Mb, 3 * H, H, t.sv.m_total, s))) return rc;
     if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, L.ctx, t.wk.h16b, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc;
   } else {
     if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H, mixed && x_in_has_16 ? t.wk.h16a : nullptr))) return rc;
@@ -1342,6 +1407,12 @@ __global__ void full_offsets_kernel(int32_t* __restrict__ cu, int32_t* __restric
 using namespace manner;
 
 extern "C" {
+
+int manner_hip_train_weight_cache(void* const* slots, int32_t* valid, int32_t n_slots) {
+  if ((slots == nullptr) != (valid == nullptr) || n_slots < 0) return fail(MANNER_HIP_E_INVALID, "train_weight_cache: slots and valid come together");
+  g_next_wcache = WCacheArg{slots, valid, slots ? n_slots : 0};
+  return MANNER_HIP_OK;
+}
 
 size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer) {
   if (!cfg || n_news <= 0 || m_bound <= 0 || start_layer < 0 || start_layer >= cfg->layers || cfg->layers > 64) return 0;
@@ -1669,15 +1740,18 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
           MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (!below) return MANNER_HIP_OK;
-    if ((rc = pack_qkv_weights(t, l))) return rc;
+    // W^T of the packed Q | K | V weight: from the caller's cache for a frozen layer (then neither the pack nor the transpose runs)
+    const int wiq = MANNER_HIP_W_EMB_COUNT + l * MANNER_HIP_WL_COUNT + MANNER_HIP_WL_Q_W;
+    const bool qkv_t_cached = mixed && t.slot(2 * wiq + 1) && t.wc_valid[2 * wiq + 1];
+    if (!qkv_t_cached && (rc = pack_qkv_weights(t, l))) return rc;
     if (compact) {                                       // d x_in = d qkv . W on every row, + d r1 on the [CLS] rows
-      if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.dx, 3 * H, H, mixed ? wk.big16 : nullptr))) return rc;
+      if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.dx, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, nullptr, nullptr, wiq))) return rc;
       hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dr, sv.cu, H, wk.dx);
       MANNER_LAUNCH_CHECK();
       return MANNER_HIP_OK;
     }
     bool fused = false;                                  // d x_in = d qkv . W + d r1
-    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, mixed ? wk.dx : wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, mixed ? wk.dr : nullptr, &fused)))
+    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, mixed ? wk.dx : wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, mixed ? wk.dr : nullptr, &fused, wiq)))
       return rc;
     return fused ? MANNER_HIP_OK : add_rows(t, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H);
   };

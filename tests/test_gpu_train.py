@@ -256,6 +256,59 @@ def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, 
     print(f"{precision}: worst gradient tensor {worst[2]}: rel-to-max {worst[0]:.3e}, cosine {worst[1]:.6f}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_frozen_weight_copy_cache_is_bit_identical_and_follows_weight_updates(precision, monkeypatch):
+    """Round 4: the 16-bit copies (and transposes, and the Q|K|V pack) of FROZEN weights are kept across calls
+    (manner_hip_train_weight_cache, train._WeightCopyCache) instead of being rebuilt by every forward / backward.  Same kernels make
+    the copies, so outputs and every gradient are BIT-identical with the cache on, off, cold and warm; a frozen weight that is
+    modified in place (load_state_dict, an optimizer that does touch it) bumps its version counter and the cache follows; a weight
+    that requires grad is never cached.  mini-roberta-large (256-tileable: the GEMM paths that read the cached copies), layer 0 frozen."""
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=81, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(19, cfg, seed=81, max_len=40)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(8).standard_normal((19, cfg.hidden)).astype(np.float32)).to(DEV)
+
+    def run(params):
+        for p in params.values():
+            p.grad = None
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=4)
+        (out * R).sum().backward()
+        return out.detach().cpu().numpy(), _grads(params)
+
+    def frozen_params():
+        return {k: torch.from_numpy(v).to(DEV).requires_grad_("layer.0." not in k) for k, v in w.items()}
+
+    monkeypatch.setenv("MANNER_TRAIN_WEIGHT_CACHE", "0")
+    ref_out, ref_g = run(frozen_params())
+    monkeypatch.delenv("MANNER_TRAIN_WEIGHT_CACHE")
+    params = frozen_params()
+    train._WCACHE._entries.clear()
+    for attempt in ("cold", "warm", "warm again"):
+        out, g = run(params)
+        assert np.array_equal(out, ref_out), attempt
+        for k in ref_g:
+            assert (g[k] is None) == (ref_g[k] is None) and (g[k] is None or np.array_equal(g[k], ref_g[k])), (attempt, k)
+    ents = train._WCACHE._entries
+    assert ents and all(key[2] == 0 for key in ents) and all(sum(e["valid"]) >= 1 for e in ents.values())      # only layer 0 is frozen: only it is cached
+    # an in-place update of a frozen weight: the cache must not serve the old copy
+    with torch.no_grad():
+        params["encoder.layer.0.intermediate.dense.weight"].mul_(1.25)
+        params["encoder.layer.0.attention.self.key.weight"].add_(0.01)
+    w2 = dict(w)
+    w2["encoder.layer.0.intermediate.dense.weight"] = w["encoder.layer.0.intermediate.dense.weight"] * np.float32(1.25)
+    w2["encoder.layer.0.attention.self.key.weight"] = w["encoder.layer.0.attention.self.key.weight"] + np.float32(0.01)
+    monkeypatch.setenv("MANNER_TRAIN_WEIGHT_CACHE", "0")
+    fresh = {k: torch.from_numpy(v).to(DEV).requires_grad_("layer.0." not in k) for k, v in w2.items()}
+    new_out, new_g = run(fresh)
+    monkeypatch.delenv("MANNER_TRAIN_WEIGHT_CACHE")
+    out, g = run(params)
+    assert not np.array_equal(new_out, ref_out)
+    assert np.array_equal(out, new_out)
+    for k in new_g:
+        assert g[k] is None and new_g[k] is None or np.array_equal(g[k], new_g[k]), k
+
+
 def test_train_from_cached_frozen_prefix():
     """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
     starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""
