@@ -288,7 +288,13 @@ def test_frozen_weight_copy_cache_is_bit_identical_and_follows_weight_updates(pr
         out, g = run(params)
         assert np.array_equal(out, ref_out), attempt
         for k in ref_g:
-            assert (g[k] is None) == (ref_g[k] is None) and (g[k] is None or np.array_equal(g[k], ref_g[k])), (attempt, k)
+            assert (g[k] is None) == (ref_g[k] is None), (attempt, k)
+            if g[k] is None:
+                continue
+            if k.startswith("embeddings.") and "LayerNorm" not in k:       # scatter-added with float atomics: equal to rounding, not to the bit
+                assert np.abs(g[k] - ref_g[k]).max() <= 1e-5 * max(np.abs(ref_g[k]).max(), 1e-6), (attempt, k)
+            else:
+                assert np.array_equal(g[k], ref_g[k]), (attempt, k)
     ents = train._WCACHE._entries
     assert ents and all(key[2] == 0 for key in ents) and all(sum(e["valid"]) >= 1 for e in ents.values())      # only layer 0 is frozen: only it is cached
     # an in-place update of a frozen weight: the cache must not serve the old copy
@@ -306,7 +312,12 @@ def test_frozen_weight_copy_cache_is_bit_identical_and_follows_weight_updates(pr
     assert not np.array_equal(new_out, ref_out)
     assert np.array_equal(out, new_out)
     for k in new_g:
-        assert g[k] is None and new_g[k] is None or np.array_equal(g[k], new_g[k]), k
+        if g[k] is None or new_g[k] is None:
+            assert g[k] is None and new_g[k] is None, k
+        elif k.startswith("embeddings.") and "LayerNorm" not in k:
+            assert np.abs(g[k] - new_g[k]).max() <= 1e-5 * max(np.abs(new_g[k]).max(), 1e-6), k
+        else:
+            assert np.array_equal(g[k], new_g[k]), k
 
 
 def test_train_from_cached_frozen_prefix():
