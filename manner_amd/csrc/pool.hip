@@ -41,11 +41,17 @@
 // out[B, D] is written.  Shapes other than D = 768 with S <= 128 and Q <= 320, or unaligned pointers, take the two-pass path, which
 // also stays as the strict-f32 mode (MANNER_HIP_POOL_STRICT=1).
 //
-// Measured (B = 4096, S = 50, D = 768, Q = 200): 0.43 ms against 1.0 ms for the two-pass path.  In-kernel stamps (a diagnostic build):
-// of a wave's 100 k cycles, 19 % wait for its 48 KiB of x (every CU asks for 384 KiB at once), 65 % are the three passes at ~1 000
-// cycles per k-step for 240 cycles of its own MFMAs — each 1 KiB LDS-DMA piece costs its issuing wave 100-190 cycles (2.5 per wave and
-// step) and the W stream through L2 -> LDS is 2.7 GB per call; the f16 matrix pipe is 30 % busy.  What would move it further is fewer
-// W bytes per MFMA — more rows per workgroup — which the 256-VGPR operand limit forbids.
+// Measured (B = 4096, S = 50, D = 768, Q = 200): 0.41-0.43 ms against 1.0 ms for the two-pass path; by unit count 0.18 ms + 0.10 ms per
+// full pass of 5 unit tiles.  In-kernel s_memtime sums (the MANNER_POOL_DIAG build, tools/pool_diag.sh; 4-wave workgroups): of a
+// wave's ~100 k cycles 19 % wait for its 48 KiB of x (every CU asks for 384 KiB at once), 4 % scale + split, 9 % logits / softmax /
+// weighted sum, and 68 % are the three passes — per ring stage (2 k-steps, 480 cycles of the wave's own MFMAs): 730 cycles fragment
+// reads + MFMAs (the SIMD partner's MFMAs included), **1 020 cycles ISSUING the stage's five 1 KiB LDS-DMA pieces** (180-200 cycles of
+// wave time per global_load_lds, the same whether the pieces go out right after the barrier or after the matrix work), 130 in the
+// barrier, 120 waiting for the pieces.  The W stream is what bounds the kernel — through the issue cost of LDS-DMA, not through L2
+// bandwidth (8-wave workgroups halve the pieces per wave and the L2 -> LDS bytes, and wait that much longer in the barrier: same
+// time).  Staging W through registers instead (global_load + ds_write: ~25 cycles of issue per piece) needs 10-20 VGPRs per wave that
+// do not exist next to 192 operand registers under hipcc's 256-arch-VGPR operand limit; fewer W bytes per MFMA needs more rows per
+// workgroup — the same limit.
 #include <math.h>
 #include <stdlib.h>
 
@@ -142,6 +148,19 @@ __global__ __launch_bounds__(256) void pool_pack_w_kernel(const float* __restric
     bq[u] = u < Q ? make_float2(bias[u], query[u]) : make_float2(0.f, 0.f);
 }
 
+#ifndef POOL_EARLY_ALL
+#define POOL_EARLY_ALL 0
+#endif
+#ifdef MANNER_POOL_DIAG   // diagnostic build only (tools/pool_diag.sh): in-kernel s_memtime sums per phase of the pass loop
+#define PD_DECL unsigned long long pd_t[6] = {0, 0, 0, 0, 0, 0}, pd_a = 0, pd_b = 0
+#define PD_A() pd_a = __builtin_amdgcn_s_memtime()
+#define PD_B(i) do { pd_b = __builtin_amdgcn_s_memtime(); pd_t[i] += pd_b - pd_a; pd_a = pd_b; } while (0)
+#else
+#define PD_DECL
+#define PD_A()
+#define PD_B(i)
+#endif
+
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f16x8& d, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
@@ -150,8 +169,9 @@ __device__ __forceinline__ void lds_read128(f16x8& d, uint32_t addr) {
 template <int KS, int NW, int R, int SPS>
 __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
     const float* __restrict__ x, const f16x8* __restrict__ Wp, const float2* __restrict__ bq, const int32_t* __restrict__ kw_p, int n_pass,
-    int n_tiles, int64_t B, int S, int SP, float* __restrict__ out) {
+    int n_tiles, int64_t B, int S, int SP, float* __restrict__ out, unsigned long long* __restrict__ diag) {
   constexpr int TP = PF_TP, D = 32 * KS, NT = 64 * NW;
+  PD_DECL;
   constexpr int STEP_B = TP * 2 * 1024;                // bytes of one k-step of packed W: TP slots x {hi, lo} x 1 KiB
   constexpr int STAGE = SPS * STEP_B;                  // a ring stage = SPS k-steps: ONE barrier per stage
   constexpr int PCS = SPS * 2 * TP;                    // LDS-DMA pieces (1 KiB) per stage
@@ -241,6 +261,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
 #pragma unroll
     for (int u = 0; u < KST; ++u) {
       const int gs = pass * KST + u;
+      PD_A();
       // this wave's pieces of stage gs have landed (the pieces of the R - 2 younger stages may fly)
       if (gs + R - 1 < total) {
         if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * (P_LO + 1)) : "memory");
@@ -248,7 +269,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      PD_B(0);
       __builtin_amdgcn_s_barrier();                     // everybody's pieces of gs landed; everybody finished reading stage gs - 1
+      PD_B(1);
+      // The stage of ring step gs - 1 (nobody reads it any more) takes step gs + R - 1.  8-wave workgroups: the two waves of a SIMD (w and
+      // w + 4) issue their LDS-DMA pieces at OPPOSITE ends of the stage — waves 4-7 here, waves 0-3 after the matrix work — so that one
+      // partner's issue time lies under the other's MFMAs instead of both stalling the pipe at the same moment.
+      const bool early = POOL_EARLY_ALL || (NW == 8 && wave >= 4);
+      if (early && gs + R - 1 < total) issue(gs + R - 1);
+      PD_B(2);
 #pragma unroll
       for (int hs = 0; hs < SPS; ++hs) {
       const int t = u * SPS + hs;
@@ -256,31 +285,30 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
       // LDS load hipcc cannot tell the stage being read from the stages the LDS-DMA is still filling and puts s_waitcnt vmcnt(0) in
       // front of it — every step then waited for the pieces issued a moment ago (1 600 cycles per step instead of ~500).
       const uint32_t sa = ring_lds + (uint32_t)((u % R) * STAGE + hs * STEP_B) + (uint32_t)lane * 16u;
-      f16x8 wh, wl;
-      lds_read128<0>(wh, sa);
-      lds_read128<1024>(wl, sa);
+      // two fragment buffers used alternately (compile-time indices): copying "next" into "current" cost 8 v_mov per slot — 2 900 VALU
+      // instructions per wave, as much issue time as the MFMAs themselves
+      f16x8 fh[2], fl[2];
+      lds_read128<0>(fh[0], sa);
+      lds_read128<1024>(fl[0], sa);
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
-        f16x8 nh, nl;
+        const int cur = sl & 1, nxt = cur ^ 1;
         if (sl + 1 < NSL) {
-          lds_read128<0>(nh, sa + (uint32_t)((2 * sl + 2) * 1024));
-          lds_read128<1024>(nl, sa + (uint32_t)((2 * sl + 2) * 1024));
-          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wh), "+v"(wl));
+          lds_read128<0>(fh[nxt], sa + (uint32_t)((2 * sl + 2) * 1024));
+          lds_read128<1024>(fl[nxt], sa + (uint32_t)((2 * sl + 2) * 1024));
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[cur]), "+v"(fl[cur]));
         } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh), "+v"(wl));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[cur]), "+v"(fl[cur]));
         }
-        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc[sl], 0, 0, 0);
-        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[t], acc[sl], 0, 0, 0);
-        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[sl], 0, 0, 0);
-        if (sl + 1 < NSL) {
-          wh = nh;
-          wl = nl;
-        }
+        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur], xh[t], acc[sl], 0, 0, 0);
+        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur], xl[t], acc[sl], 0, 0, 0);
+        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur], xh[t], acc[sl], 0, 0, 0);
       }
       }
-      // the stage of ring step gs - 1 (everybody passed this step's barrier, so nobody reads it any more) takes step gs + R - 1; issued
-      // AFTER the stage's matrix work, under the SIMD partner's
-      if (gs + R - 1 < total) issue(gs + R - 1);
+      PD_B(3);
+      // (4-wave workgroups and waves 0-3: AFTER the stage's matrix work, under the SIMD partner's)
+      if (!early && gs + R - 1 < total) issue(gs + R - 1);
+      PD_B(4);
     }
     // acc[sl][i] 2^-(kx + kw) = z[unit 16 (pass TP + sl) + 4 g + i][row r of the strip]: tanh(z + bias) q, summed over this lane's units
 #pragma unroll
@@ -360,6 +388,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
     for (int k = 1; k < 4 * SP; ++k) a += *reinterpret_cast<const f32x4*>(parts + (size_t)(b_l * SP * 4 + k) * D + c4);
     *reinterpret_cast<f32x4*>(out + (b0 + b_l) * D + c4) = a;
   }
+#ifdef MANNER_POOL_DIAG
+  if (diag && lane == 0 && blockIdx.x % 41 == 0 && blockIdx.x / 41 < 64)
+    for (int i = 0; i < 6; ++i) diag[((blockIdx.x / 41) * NW + wave) * 6 + i] = pd_t[i];
+#endif
 }
 
 }  // namespace
@@ -398,15 +430,19 @@ int pool_fused(const float* x, const float* W, const float* bias, const float* q
   MANNER_LAUNCH_CHECK();
   // S <= 64: 4-wave workgroups, two per CU (one's loads and epilogue run under the other's matrix work); 64 < S <= 128: 8 waves.
   // MANNER_HIP_POOL_NW=8 forces the 8-wave form for every S (A/B: 0.436 vs 0.432 ms at B = 4096, S = 50).
+  unsigned long long* diag = nullptr;
+#ifdef MANNER_POOL_DIAG
+  if (const char* de = getenv("MANNER_HIP_POOL_DIAG")) diag = reinterpret_cast<unsigned long long*>(strtoull(de, nullptr, 0));
+#endif
   const char* nw_env = getenv("MANNER_HIP_POOL_NW");
   if (sp <= 4 && !(nw_env && atoi(nw_env) == 8)) {
     const int bpw = 4 / sp;
     hipLaunchKernelGGL((pool_fused_kernel<24, 4, 3, 2>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(256), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
-                       (int)S, sp, out);
+                       (int)S, sp, out, diag);
   } else {
     const int bpw = 8 / sp;
     hipLaunchKernelGGL((pool_fused_kernel<24, 8, 6, 2>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(512), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
-                       (int)S, sp, out);
+                       (int)S, sp, out, diag);
   }
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
