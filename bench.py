@@ -810,7 +810,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
            "allgather_exchange": exchange_ran, "allgather_exchange_why": gathers[0].exchange_why,
            "allgather_what": ("no exchange (one rank)" if world == 1 else
                               "EXPOSED time of the table exchange, from the end of this rank's encoding to the complete table on every rank: " +
-                              ("ONE all_gather_into_tensor per module after the encoding (RCCL's own algorithm)" if exchange_ran == "collective" else
+                              (f"ONE all_gather_into_tensor per module after the encoding (backend {D.device_backend('cuda')!r}: its own algorithm)" if exchange_ran == "collective" else
                                f"direct full mesh of point-to-point transfers, {gathers[0].pieces} pieces per shard, each posted while the next is encoded")),
            "allgather_bytes_per_rank": recv_bytes if world > 1 else 0,
            "allgather_standalone": None if world == 1 else {
