@@ -54,7 +54,10 @@ int device_cus();   // compute units of the current device (gemm.hip)
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3, EPI_NORM_GELU = 4, EPI_NRES = 5,
                 EPI_BIAS_RES_F32 = 6 /* bf16 operands, f32 residual and output: the bf16x3 parity mode */,
                 EPI_BIAS_GELU_SPLIT3 = 7 /* x3 modes' FFN1: exact-erf gelu(acc + bias) written as the NEXT GEMM's split operand
-                                            [hi | hi | lo], row stride 3 N of the 16-bit type (the f32 intermediate never exists) */ };
+                                            [hi | hi | lo], row stride 3 N of the 16-bit type (the f32 intermediate never exists) */,
+                EPI_BIAS_GELU_DUAL = 8 /* training forward FFN1 (gemm_tn_gelu_dual): f32 pre-activation acc + bias AND its gelu in
+                                          the 16-bit operand type, one launch */,
+                EPI_GELU_GRAD = 9 /* training backward (gemm_tn_gelu_grad): 16-bit out = round16(acc) * gelu'(saved f32 pre-activation) */ };
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 static inline bool is_16bit(DType d) { return d != DT_F32; }
 

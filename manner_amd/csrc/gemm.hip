@@ -48,6 +48,19 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x|/sqrt2)
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
+// d gelu / dx = (1 + erf(x/sqrt2)) / 2 + x * phi(x) with the same erf (its exp(-x^2/2) is phi's): the training backward's
+// 16-bit epilogue (EPI_GELU_GRAD)
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float ex = __expf(-z * z);
+  const float e = 1.0f - p * t * ex;
+  return fmaf(x * 0.39894228040143268f, ex, 0.5f * (1.0f + copysignf(e, x)));
+}
 // GeLU for the 256x256 bf16 kernel's epilogue, transcendental-free so that the compiler packs it two lanes-elements
 // per instruction (v_pk_fma_f32):  gelu(x) = x/2 + |x| * P(min(|x|, 4.25)),  P ~ erf(t/sqrt2)/2 a degree-8 minimax
 // fit (LP on 3001 nodes, P(4.25) = 1/2 exactly so x > 4.25 gives x and x < -4.25 gives 0).  Max |error| 7.4e-5
@@ -771,6 +784,10 @@ struct DlnAux {
   // A/B (MANNER_HIP_GEMM_STAGGER=n): row panel p starts (p % 4) * n sleeps of ~2 us late, so that the workgroups of a launch do
   // not all reach their epilogue — a burst of 128 KB reads + 128 KB writes per CU — at the same moment
   int stagger;
+  // EPI_BIAS_GELU_DUAL: second output [m, N] of the operand type (gelu of the f32 rows written to Y);
+  // EPI_GELU_GRAD: saved f32 pre-activation [m, N] whose gelu' multiplies the output
+  void* aux16;
+  const float* aux32;
 };
 
 template <typename TE, typename TOut, int EPI, int ABL = 0>
@@ -1229,6 +1246,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
         }
       }
+      f32x4 pre[EPI == EPI_GELU_GRAD ? SQ : 1][2];
+      if constexpr (EPI == EPI_GELU_GRAD) {                                // TOut == TE: 8 outputs per chunk, their 8 saved f32 pre-activations
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+          const int row = q * ROWS_PER_INST + row0;
+          const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
+          const f32x4* ip = reinterpret_cast<const f32x4*>(dln.aux32 + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+          pre[q][0] = ip[0];
+          pre[q][1] = ip[1];
+        }
+      }
 #pragma unroll
       for (int q = 0; q < SQ; ++q) {
         const int row = q * ROWS_PER_INST + row0;
@@ -1236,6 +1264,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
         f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
         if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+        if constexpr (EPI == EPI_GELU_GRAD) {
+          e16x8 d = __builtin_bit_cast(e16x8, raw);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast(pre[q][e >> 2][e & 3]));
+          raw = __builtin_bit_cast(f32x4, d);
+        }
         if (EPI == EPI_BIAS_RES) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
@@ -1254,6 +1288,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           // that they do not push the weight tiles, re-read by every row panel, out of the XCD's 4 MB L2
           if (NORM && ABL != 5 && !dln.plain_stores) __builtin_nontemporal_store(raw, dst);
           else *dst = raw;
+          if constexpr (EPI == EPI_BIAS_GELU_DUAL) {                       // TOut == float: 4 pre-activations -> 4 gelu values, 8-byte store
+            e16x4 gv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = (TE)gelu_erf_fast(raw[e]);
+            *reinterpret_cast<e16x4*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1456,6 +1496,44 @@ int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, 
                        bias, reinterpret_cast<const bf16_t*>(residual), Y, N, K, m_total, n_tiles, aux);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
+}
+
+bool gemm_gelu_fusable(DType in, int64_t m_bound, int N, int K) {
+  return is_16bit(in) && m_bound > 0 && m_bound % G_BM == 0 && N % G_BN == 0 && K >= 128 && (K * 2) % ROW_BYTES == 0 && !small_problem(m_bound, N);
+}
+
+template <typename TE, typename TOut, int EPI>
+static int launch_gelu_fused(const void* X, const void* W, const float* bias, void* Y, int64_t m_bound, int N, int K, const int* m_total,
+                             const DlnAux& aux, hipStream_t stream) {
+  const int n_tiles = N / G_BN;
+  const int64_t tiles = (m_bound / G_BM) * n_tiles;
+  if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
+  const int n_cus = device_cus();
+  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
+  hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI>), g, b, 0, stream, static_cast<const TE*>(X), static_cast<const TE*>(W), bias,
+                     static_cast<const TE*>(nullptr), static_cast<TOut*>(Y), N, K, m_total, n_tiles, aux);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
+
+int gemm_tn_gelu_dual(DType in, const void* X, const void* W, const float* bias, float* Y, void* G16, int64_t m_bound, int N, int K,
+                      const int* m_total, hipStream_t stream) {
+  if (!gemm_gelu_fusable(in, m_bound, N, K) || !G16 || !Y)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_gelu_dual: m_bound=%lld N=%d K=%d", (long long)m_bound, N, K);
+  DlnAux aux{};
+  aux.aux16 = G16;
+  if (in == DT_F16) return launch_gelu_fused<f16_t, float, EPI_BIAS_GELU_DUAL>(X, W, bias, Y, m_bound, N, K, m_total, aux, stream);
+  return launch_gelu_fused<bf16_t, float, EPI_BIAS_GELU_DUAL>(X, W, bias, Y, m_bound, N, K, m_total, aux, stream);
+}
+
+int gemm_tn_gelu_grad(DType in, const void* X, const void* W, const float* zero_bias, const float* pre, void* Y16, int64_t m_bound, int N,
+                      int K, const int* m_total, hipStream_t stream) {
+  if (!gemm_gelu_fusable(in, m_bound, N, K) || !pre || !Y16)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_gelu_grad: m_bound=%lld N=%d K=%d", (long long)m_bound, N, K);
+  DlnAux aux{};
+  aux.aux32 = pre;
+  if (in == DT_F16) return launch_gelu_fused<f16_t, f16_t, EPI_GELU_GRAD>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
+  return launch_gelu_fused<bf16_t, bf16_t, EPI_GELU_GRAD>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
 }
 
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,

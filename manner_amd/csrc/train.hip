@@ -250,9 +250,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
   }
 }
 
+// Destination of a column sum: one vector, or (seg > 0) three vectors of seg columns each — the Q | K | V gradients of the packed
+// projection land in the three parameter gradients directly (a NULL part is not wanted and skipped)
+struct SumDst {
+  float* p[3];
+  int seg;
+  __device__ __forceinline__ void put(int c, float v) const {
+    if (seg <= 0) { p[0][c] = v; return; }
+    const int k = c / seg;
+    if (p[k]) p[k][c - k * seg] = v;
+  }
+};
+
 // out[c] = sum_b partial[b][c]   (fixed order)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int width,
-                                                              float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int width, SumDst out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= width) return;
   float s[4] = {0.f, 0.f, 0.f, 0.f};                  // four loads in flight per thread; the order of the sum stays fixed
@@ -262,15 +273,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     for (int u = 0; u < 4; ++u) s[u] += partial[(size_t)(b + u) * width + c];
   }
   for (; b < blocks; ++b) s[0] += partial[(size_t)b * width + c];
-  out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+  out.put(c, (s[0] + s[1]) + (s[2] + s[3]));
 }
 
 // The same sum for NARROW outputs (bias / LayerNorm gradients: width <= a few thousand, hundreds of partial rows): the kernel above
 // would run 3 - 12 workgroups, each thread walking all partial rows 4 at a time — ~40 us of dependent round trips per call, 100
 // calls per training step.  Here a workgroup owns 64 columns and splits the partial rows over 16 groups (8 loads in flight each);
 // the 16 group sums meet in LDS and are added in a fixed order.
-__global__ __launch_bounds__(1024) void reduce_partials_narrow_kernel(const float* __restrict__ partial, int blocks, int width,
-                                                                      float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void reduce_partials_narrow_kernel(const float* __restrict__ partial, int blocks, int width, SumDst out) {
   __shared__ float red[16][64];
   const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
@@ -289,14 +299,17 @@ __global__ __launch_bounds__(1024) void reduce_partials_narrow_kernel(const floa
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][col];
-    out[c] = t;
+    out.put(c, t);
   }
 }
-void reduce_partials(hipStream_t s, const float* partial, int blocks, int64_t width, float* out) {
+void reduce_partials(hipStream_t s, const float* partial, int blocks, int64_t width, const SumDst& out) {
   if (width <= 16384 && blocks >= 32)
     hipLaunchKernelGGL(reduce_partials_narrow_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, s, partial, blocks, (int)width, out);
   else
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, s, partial, blocks, (int)width, out);
+}
+void reduce_partials(hipStream_t s, const float* partial, int blocks, int64_t width, float* out) {
+  reduce_partials(s, partial, blocks, width, SumDst{{out, nullptr, nullptr}, 0});
 }
 
 // partial[b][c] = sum over the rows of block b of y[m][c]   (bias gradients, token-type embedding gradient)
@@ -1045,6 +1058,27 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, X16, w16, bias, nullptr, Y, t.Mb, Nout, K, t.sv.m_total, t.s);
 }
 
+// A/B switch (MANNER_HIP_TRAIN_GELU_FUSED=0): the GeLU of the FFN as separate elementwise kernels in the 16-bit modes too
+bool gelu_fused_enabled() {
+  const char* e = getenv("MANNER_HIP_TRAIN_GELU_FUSED");
+  return !e || atoi(e) != 0;
+}
+
+int gelu16(Ctx& t, const float* inter, void* z, int width, int mode);
+
+// FFN1 of the 16-bit modes: inter [Mb, I] f32 = h1 W1^T + b1 (saved for the backward's gelu') and g [Mb, I] = gelu(inter) in the
+// 16-bit type — one GEMM with both outputs where the shape allows, else GEMM + gelu16
+int ffn1_fwd16(Ctx& t, const void* h16, const float* W, const float* bias, float* inter, void* g, int I, int H) {
+  int rc;
+  if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), t.Mb, I, H)) {
+    const void* w16;
+    if ((rc = weight16(t, W, I, H, false, t.wk.b16, &w16))) return rc;
+    return gemm_tn_gelu_dual(t.dt(), h16, w16, bias, inter, g, t.Mb, I, H, t.sv.m_total, t.s);
+  }
+  if ((rc = linear_fwd(t, nullptr, W, bias, inter, I, H, h16))) return rc;
+  return gelu16(t, inter, g, I, 0);
+}
+
 // R = dropout(X W^T + bias) + residual (attention-output / FFN-output projection of the forward pass, modeling_bert.py:289-293,
 // 347-351): 16-bit modes on 256-tileable shapes run it as ONE GEMM (dropout and residual add in the epilogue); otherwise GEMM ->
 // wk.tmp, then the elementwise pass.  rowmap: compact [CLS] rows draw the bits of the token rows they stand for.
@@ -1102,8 +1136,12 @@ int linear_dgrad(Ctx& t, const float* dY, const float* W, void* dX, int Nout, in
 
 // dW [Nout, K] = dY [Mb, Nout]^T . X [Mb, K]   (the reduction runs over the token rows; rows >= *m_total contribute zeros)
 // dy_dt / x_dt: the operands' storage type (f32, or the mode's 16-bit type when the tensor exists in 16 bits only)
-int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt, float* dW, int Nout, int K, int dim_slot) {
+// split (optional; *split_done reports whether it was honoured): the reduction of the slice partials writes three row blocks of dW
+// [3 seg / K rows each] straight into three destinations instead of dW
+int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt, float* dW, int Nout, int K, int dim_slot,
+                 const SumDst* split = nullptr, bool* split_done = nullptr) {
   int rc;
+  if (split_done) *split_done = false;
   if (t.dt() != DT_F32 && Nout % 256 == 0 && K % 256 == 0) {
     // Few output tiles, one long reduction: split the token axis into `slices` independent GEMMs of one launch
     // (gridDim.y) so that every CU has a tile, then add the partial gradients in a fixed order.
@@ -1124,7 +1162,12 @@ int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt,
       if (x_dt == DT_F32) { if ((rc = convert_f32_to_16(t.dt(), static_cast<const float*>(X), t.wk.b16, t.Mb * K, t.s))) return rc; x16 = t.wk.b16; }
       if ((rc = wgrad_tr(t.dt(), dy16, x16, slices >= 2 ? t.wk.dwp : dW, Nout, K, slices, ks, t.sv.m_total, t.wk.zero, t.s))) return rc;
       if (slices >= 2) {
-        reduce_partials(t.s, t.wk.dwp, slices, (int64_t)Nout * K, dW);
+        if (split && (int64_t)Nout * K < 0x7fffffff) {
+          reduce_partials(t.s, t.wk.dwp, slices, (int64_t)Nout * K, *split);
+          if (split_done) *split_done = true;
+        } else {
+          reduce_partials(t.s, t.wk.dwp, slices, (int64_t)Nout * K, dW);
+        }
         MANNER_LAUNCH_CHECK();
       }
       return MANNER_HIP_OK;
@@ -1149,13 +1192,14 @@ int linear_wgrad(Ctx& t, const void* dY, DType dy_dt, const void* X, DType x_dt,
   return gemm_tn(t.dt(), DT_F32, EPI_BIAS, t.wk.a16, t.wk.b16, t.wk.zero, nullptr, dW, Nout, K, (int)t.Mb, t.wk.dims + dim_slot, t.s);
 }
 
-int bias_grad(Ctx& t, const void* dY, DType dy_dt, int width, float* db) {
+int bias_grad(Ctx& t, const void* dY, DType dy_dt, int width, float* db, const SumDst* split = nullptr) {
   const dim3 g((unsigned)((width + 255) / 256), COLSUM_BLOCKS), b(256);
   if (dy_dt == DT_F32) hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, t.s, static_cast<const float*>(dY), width, t.wk.part, t.sv.m_total);
   else if (dy_dt == DT_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, g, b, 0, t.s, static_cast<const f16_t*>(dY), width, t.wk.part, t.sv.m_total);
   else hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, t.s, static_cast<const bf16_t*>(dY), width, t.wk.part, t.sv.m_total);
   MANNER_LAUNCH_CHECK();
-  reduce_partials(t.s, t.wk.part, COLSUM_BLOCKS, width, db);
+  if (split) reduce_partials(t.s, t.wk.part, COLSUM_BLOCKS, width, *split);
+  else reduce_partials(t.s, t.wk.part, COLSUM_BLOCKS, width, db);
   MANNER_LAUNCH_CHECK();
   return MANNER_HIP_OK;
 }
@@ -1369,10 +1413,10 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     if ((rc = linear_fwd_drop_res(c, ctx_c, nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_c, L.r1, H, H,
                                   make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), cu))) return rc;
     if ((rc = ln_forward(c, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
-    if ((rc = linear_fwd(c, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
     if (mixed) {                                           // g exists in the 16-bit type only (the saved slot, half used)
-      if ((rc = gelu16(c, L.inter, L.g, I, 0))) return rc;
+      if ((rc = ffn1_fwd16(c, t.wk.h16b, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, L.g, I, H))) return rc;
     } else {
+      if ((rc = linear_fwd(c, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, nullptr))) return rc;
       hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, c.sv.m_total, 0, Out16{nullptr, 0});
       MANNER_LAUNCH_CHECK();
     }
@@ -1383,10 +1427,10 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
   if ((rc = linear_fwd_drop_res(t, L.ctx, mixed ? t.wk.h16b : nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_in, L.r1, H, H,
                                 make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr))) return rc;
   if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
-  if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, mixed ? t.wk.h16b : nullptr))) return rc;
   if (mixed) {
-    if ((rc = gelu16(t, L.inter, L.g, I, 0))) return rc;
+    if ((rc = ffn1_fwd16(t, t.wk.h16b, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, L.g, I, H))) return rc;
   } else {
+    if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, nullptr))) return rc;
     hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, Out16{nullptr, 0});
     MANNER_LAUNCH_CHECK();
   }
@@ -1663,8 +1707,14 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(c, dy2_any, g16, L.g, g16, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
     const void* dinter_any;
     if (mixed) {
-      if ((rc = linear_dgrad(c, nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), wk.big16, H, I, wk.h16b, t.dt()))) return rc;          // d g (16-bit)
-      if ((rc = gelu16(c, L.inter, wk.big16, I, 1))) return rc;                                                         // d inter, in place
+      if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), c.Mb, I, H)) {                       // d inter = (d y2 . W2) * gelu'(inter): one launch
+        const void* wt;
+        if ((rc = weight16(c, t.lw(l, MANNER_HIP_WL_FF2_W), H, I, true, wk.b16, &wt))) return rc;
+        if ((rc = gemm_tn_gelu_grad(t.dt(), wk.h16b, wt, wk.zero, L.inter, wk.big16, c.Mb, I, H, c.sv.m_total, s))) return rc;
+      } else {
+        if ((rc = linear_dgrad(c, nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), wk.big16, H, I, wk.h16b, t.dt()))) return rc;          // d g (16-bit)
+        if ((rc = gelu16(c, L.inter, wk.big16, I, 1))) return rc;                                                         // d inter, in place
+      }
       dinter_any = wk.big16;
     } else {
       if ((rc = linear_dgrad(c, dy2, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I))) return rc;                           // d g
@@ -1730,14 +1780,17 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     MANNER_LAUNCH_CHECK();
     }
     if (qkv_w) {
-      if ((rc = bias_grad(t, wk.dqkv, DT_F32, 3 * H, wk.dw))) return rc;
-      for (int k = 0; k < 3; ++k)
-        if (gl(l, MANNER_HIP_WL_Q_B + 2 * k))
-          MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_B + 2 * k), wk.dw + (size_t)k * H, H * sizeof(float), hipMemcpyDeviceToDevice, s));
-      if ((rc = linear_wgrad(t, mixed ? (const void*)wk.big16 : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3))) return rc;
-      for (int k = 0; k < 3; ++k)
-        if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
-          MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+      // the packed projection's gradients go to the three parameters' gradients in place: the fixed-order sums of the column /
+      // slice partials write three destinations (round 4: 6 device copies per layer before)
+      const SumDst db3{{gl(l, MANNER_HIP_WL_Q_B), gl(l, MANNER_HIP_WL_Q_B + 2), gl(l, MANNER_HIP_WL_Q_B + 4)}, H};
+      const SumDst dw3{{gl(l, MANNER_HIP_WL_Q_W), gl(l, MANNER_HIP_WL_Q_W + 2), gl(l, MANNER_HIP_WL_Q_W + 4)}, H * H};
+      if ((db3.p[0] || db3.p[1] || db3.p[2]) && (rc = bias_grad(t, wk.dqkv, DT_F32, 3 * H, nullptr, &db3))) return rc;
+      bool in_place = false;
+      if ((rc = linear_wgrad(t, mixed ? (const void*)wk.big16 : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3, &dw3, &in_place))) return rc;
+      if (!in_place)
+        for (int k = 0; k < 3; ++k)
+          if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
+            MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (!below) return MANNER_HIP_OK;
     // W^T of the packed Q | K | V weight: from the caller's cache for a frozen layer (then neither the pack nor the transpose runs)

@@ -39,6 +39,18 @@ __host__ __device__ inline uint32_t layer_site(int layer, int k) { return 8u * (
 int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, const float* residual, float* Y, int64_t m_bound, int N,
                      int K, const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream);
 
+// gemm.hip: the GeLU of the training FFN inside its neighbouring GEMMs (16-bit operands; round 4).
+//   gemm_gelu_fusable : the shapes the two entry points below take (256-tileable, K >= 128, not a small problem)
+//   gemm_tn_gelu_dual : Y [m, N] f32 = X W^T + bias (the saved pre-activation) and G16 [m, N] = gelu(Y) in the type `in`
+//   gemm_tn_gelu_grad : Y16 [m, N] (type `in`) = round16(X W^T) * gelu'(pre [m, N] f32)   — d inter from d y2 . W2 in one launch
+// GeLU and its derivative use the |error| <= 1.5e-7 erf of the inference engine's 16-bit epilogues (below the 16-bit rounding
+// step of the outputs); the separate kernels (fp32 mode, small problems, MANNER_HIP_TRAIN_GELU_FUSED=0) keep erff.
+bool gemm_gelu_fusable(DType in, int64_t m_bound, int N, int K);
+int gemm_tn_gelu_dual(DType in, const void* X, const void* W, const float* bias, float* Y, void* G16, int64_t m_bound, int N, int K,
+                      const int* m_total, hipStream_t stream);
+int gemm_tn_gelu_grad(DType in, const void* X, const void* W, const float* zero_bias, const float* pre, void* Y16, int64_t m_bound, int N,
+                      int K, const int* m_total, hipStream_t stream);
+
 // Training attention on the matrix pipe (train_attn.hip; 16-bit modes): S <= 128 keys per news, head_dim 64, one wave per
 // (news, head).  qkv16 [m, 3H] = [Q | K | V] of the 16-bit type `dt`.
 //   forward : ctx [m, H] f32 (+ its 16-bit copy ctx16, may be NULL) = dropout(softmax(q k^T / 8)) v;  ml[m, heads] = {row max of the
