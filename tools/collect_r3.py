@@ -139,7 +139,7 @@ def main():
         ab[tag] = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": v["WRITE_SIZE_KiB"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
                        "launches": v["launches"]} for k, v in tj.items() if isinstance(v, dict) and k.startswith(("gemm_", "attention"))}
     r3 = os.path.join(ROOT, "gpurun_out", "r3")
-    for path in sorted(glob.glob(os.path.join(r3, "ab_ct*_nt*.json"))):
+    for path in (sorted(glob.glob(os.path.join(r3, "ab_ct*_nt*.json"))) if ab else []):      # times only next to counters of the SAME session
         tag = os.path.basename(path)[3:-5]
         try:
             with open(path) as f:
