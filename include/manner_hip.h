@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 5
+#define MANNER_HIP_ABI_VERSION 6
 
 enum {
   MANNER_HIP_OK = 0,
@@ -529,6 +529,24 @@ size_t manner_hip_mha_axis0_workspace_bytes(int64_t L0, int64_t B1, int32_t E);
 int manner_hip_mha_axis0(const float* x, int64_t L0, int64_t B1, int32_t E, int32_t heads, const float* in_proj_w,
                          const float* in_proj_b, const float* out_proj_w, const float* out_proj_b, float* out, void* workspace,
                          size_t workspace_bytes, manner_hip_stream_t stream);
+
+/* ---- content-addressed news-embedding cache (ABI v6, round 4; csrc/cache.hip) ----------------------------------------------
+ * SURVEY.md §8(d) mode T ("each unique news encoded once per module") behind the unchanged drop-in call pattern: the reference
+ * re-encodes every occurrence — manner/models/cr_module.py:107,113 call manner/models/components/news_encoder.py:29-37 per batch —
+ * while in eval() the text encoder is a pure function of a row's real tokens and the weights.  The caller (MannerTextEncoder.forward,
+ * opt-in) keys every row, looks the keys up and encodes only the rows whose state is not 0.
+ * manner_hip_news_key128: keys uint64 [n_news, 2] of the tokens at mask != 0 (independent of padded_len; keys[n][0] != 0).
+ * manner_hip_news_cache_lookup: open-addressing table in CALLER-OWNED device memory — slot_keys uint64 [2, n_slots] (zero-filled =
+ *   empty; n_slots a power of two), slot_rows int32 [n_slots], row_count int32 [1] (rows handed out so far; may run past
+ *   capacity_rows once the table is full), scratch int32 [2 n_news].  Per input row: rows_out int32 (row of the embedding table, -1 if
+ *   none) and state_out int32: 0 = cached (or a duplicate of a key that is new in this call — its row is valid once the state-1
+ *   occurrence has been encoded and stored), 1 = new: encode and store at rows_out, 2 = encode without storing (table full).
+ *   Exactly one occurrence of a new key gets state 1.  One stream at a time per table. */
+int manner_hip_news_key128(const int64_t* ids, const int64_t* mask, int64_t n_news, int64_t padded_len, uint64_t* keys,
+                           manner_hip_stream_t stream);
+int manner_hip_news_cache_lookup(const uint64_t* keys, int64_t n_news, uint64_t* slot_keys, int32_t* slot_rows, int64_t n_slots,
+                                 int32_t* row_count, int32_t capacity_rows, int32_t* rows_out, int32_t* state_out, int32_t* scratch,
+                                 manner_hip_stream_t stream);
 
 #ifdef __cplusplus
 }

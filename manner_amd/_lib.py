@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
@@ -60,6 +60,8 @@ SIGNATURES = {
     "manner_hip_table_to_f16": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "manner_hip_score_user": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P]),
     "manner_hip_to_dense": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P]),
+    "manner_hip_news_key128": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "manner_hip_news_cache_lookup": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _I32, _P, _P, _P, _P]),
     "manner_hip_zscore_fuse": (C.c_int, [_P, _I64, _I32, C.POINTER(C.c_float), _P, _I64, _P, _P, _P]),
     "manner_hip_rank_ndcg": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "manner_hip_score_fuse_rank_workspace_bytes": (_SZ, [_I32, _I64]),

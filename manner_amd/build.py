@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libmanner_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "scoring.hip", "pool.hip", "entity.hip", "metrics.hip", "collate.hip", "encoder.hip", "train.hip", "train_attn.hip", "wgrad.hip", "train_small.hip"]
+SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "scoring.hip", "pool.hip", "entity.hip", "metrics.hip", "collate.hip", "cache.hip", "encoder.hip", "train.hip", "train_attn.hip", "wgrad.hip", "train_small.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

@@ -332,6 +332,59 @@ class HipEncoder:
             raise RuntimeError(f"manner_hip input error in an earlier encode call: {_status_message(flag)}")
 
 
+class NewsEmbeddingCache:
+    """Content-addressed table of text-encoder outputs (csrc/cache.hip; SURVEY.md §8d mode T behind the drop-in call pattern).
+
+    ``lookup(ids, mask)`` keys every row by its real tokens and returns (rows int32 [N], state int32 [N]): state 0 — the embedding is
+    (or, for a repeat of a key new in this call, will be) at ``table[rows]``; 1 — new, the caller encodes it and stores it at
+    ``table[rows]``; 2 — encode, do not store (table full).  Everything lives in HBM: ``capacity`` rows of ``dim`` f32 plus
+    2 x capacity hash slots of 20 bytes (161 013 news x 768 f32 = 495 MB — the whole MIND-large table fits 500 times over).
+    The owner clears it whenever the weights or the arithmetic mode change."""
+
+    def __init__(self, dim: int, capacity: int, device: torch.device):
+        if capacity < 1:
+            raise ValueError("NewsEmbeddingCache: capacity must be positive")
+        self.dim, self.capacity, self.device = int(dim), int(capacity), torch.device(device)
+        n_slots = 2
+        while n_slots < 2 * self.capacity:
+            n_slots *= 2
+        self.n_slots = n_slots
+        self.table = torch.empty((self.capacity, self.dim), dtype=torch.float32, device=self.device)
+        self.slot_keys = torch.zeros((2, n_slots), dtype=torch.int64, device=self.device)     # uint64 bit patterns
+        self.slot_rows = torch.full((n_slots,), -1, dtype=torch.int32, device=self.device)
+        self.row_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.lookups = 0          # host-side counters (rows asked for / rows encoded), for the hit rate
+        self.encoded = 0
+
+    def clear(self) -> None:
+        self.slot_keys.zero_()
+        self.slot_rows.fill_(-1)
+        self.row_count.zero_()
+        self.lookups = self.encoded = 0
+
+    def keys(self, ids: Tensor, mask: Tensor) -> Tensor:
+        ids = _dev(ids, torch.int64, "input_ids").contiguous()
+        mask = _dev(mask, torch.int64, "attention_mask").contiguous()
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError("NewsEmbeddingCache: input_ids / attention_mask must be [n_news, padded_len]")
+        out = torch.empty((ids.shape[0], 2), dtype=torch.int64, device=ids.device)
+        with torch.cuda.device(ids.device):
+            _lib.check(_lib.load().manner_hip_news_key128(_ptr(ids), _ptr(mask), ids.shape[0], ids.shape[1], _ptr(out), _stream()))
+        return out
+
+    def lookup(self, ids: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
+        keys = self.keys(ids, mask)
+        n = keys.shape[0]
+        rows = torch.empty(n, dtype=torch.int32, device=keys.device)
+        state = torch.empty(n, dtype=torch.int32, device=keys.device)
+        scratch = torch.empty(2 * max(n, 1), dtype=torch.int32, device=keys.device)
+        with torch.cuda.device(keys.device):
+            _lib.check(_lib.load().manner_hip_news_cache_lookup(_ptr(keys), n, _ptr(self.slot_keys), _ptr(self.slot_rows), self.n_slots,
+                                                                 _ptr(self.row_count), self.capacity, _ptr(rows), _ptr(state), _ptr(scratch),
+                                                                 _stream()))
+        return rows, state
+
+
 def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor, strict: bool = False) -> Tensor:
     """AdditiveAttention.forward (reference attention.py:21-27).  Default: the one-pass kernel (x read once, bf16x3 logits on the
     bf16 matrix pipe, within 1e-4 of the reference) where the shape allows it; ``strict=True`` (or MANNER_HIP_POOL_STRICT=1): the

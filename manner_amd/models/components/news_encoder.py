@@ -134,10 +134,18 @@ class MannerTextEncoder(nn.Module):
                     param.requires_grad = False
         self._hip: Optional[hip.HipEncoder] = None
         self._hip_key = None
+        self._cache: Optional[hip.NewsEmbeddingCache] = None
+
+    #: Opt-in memoisation of the eval() forward (SURVEY §8d "mode T" behind the unchanged call pattern): rows of an
+    #: `hip.NewsEmbeddingCache` in HBM, 0 = off (the default: every occurrence is encoded, as in the reference).  With it a row
+    #: whose real tokens were seen before under the same weights and precision is returned from the table — bit-identical to
+    #: encoding it again, because the inference engine computes a news from its own tokens only.  MIND-large has 161 013 news.
+    embedding_cache_rows: int = int(os.environ.get("MANNER_EMBED_CACHE_ROWS", "0"))
 
     def __getstate__(self):                      # the HIP handle is rebuilt lazily after copy/unpickle
         d = self.__dict__.copy()
         d["_hip"], d["_hip_key"] = None, None
+        d["_cache"] = None
         d["_hip_prefix"], d["_hip_prefix_key"] = None, None
         return d
 
@@ -151,6 +159,8 @@ class MannerTextEncoder(nn.Module):
                 finally:
                     self._hip.close()
                     self._hip = None
+            if getattr(self, "_cache", None) is not None:    # other weights / another precision: every cached embedding is stale
+                self._cache.clear()
             precisions = tuple(dict.fromkeys(("bf16", "fp32", self.precision)))
             self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
                                        precisions=precisions, device=device)
@@ -215,9 +225,39 @@ class MannerTextEncoder(nn.Module):
             return self._forward_train(ids, mask, dropout=self.training)
         enc = self._encoder(ids.device)
         enc.status_poll()
-        out = enc.encode_cls(ids, mask, precision=self.precision)
+        if self.embedding_cache_rows > 0:
+            out = self._forward_cached(enc, ids, mask)
+        else:
+            out = enc.encode_cls(ids, mask, precision=self.precision)
         enc.status_arm()
         return out
+
+    def _forward_cached(self, enc: hip.HipEncoder, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """eval() forward through the content-addressed cache: encode the rows not seen before, return every row from the table.
+        One host read per call (how many rows are new) — the unchanged callers synchronise anyway (`to_dense_batch`, the
+        per-row `torch.where` loop of cr_module.py:117-120)."""
+        cache = getattr(self, "_cache", None)
+        if cache is None or cache.capacity != self.embedding_cache_rows or cache.device != ids.device or cache.dim != self.plm_model.cfg.hidden:
+            cache = self._cache = hip.NewsEmbeddingCache(self.plm_model.cfg.hidden, self.embedding_cache_rows, ids.device)
+        try:
+            rows, state = cache.lookup(ids, mask)
+            todo = torch.nonzero(state != 0).squeeze(1)                          # the host read
+            cache.lookups += int(ids.shape[0])
+            cache.encoded += int(todo.numel())
+            out = None
+            if todo.numel():
+                fresh = enc.encode_cls(ids.index_select(0, todo), mask.index_select(0, todo), precision=self.precision)
+                keep = state.index_select(0, todo) == 1
+                cache.table.index_copy_(0, rows.index_select(0, todo)[keep].long(), fresh[keep])
+                if todo.numel() == ids.shape[0]:
+                    return fresh
+                out = cache.table.index_select(0, rows.clamp_min(0).long())
+                out.index_copy_(0, todo, fresh)                                  # state 2 rows have no table row
+                return out
+            return cache.table.index_select(0, rows.long())
+        except Exception:
+            cache.clear()                      # keys of this call may point at rows that were never written
+            raise
 
     def check_inputs(self) -> None:
         """Blocking: raise if any forward so far saw an invalid attention_mask / input id."""

@@ -1,0 +1,192 @@
+"""Content-addressed news-embedding cache (csrc/cache.hip, hip.NewsEmbeddingCache, MannerTextEncoder.embedding_cache_rows) —
+SURVEY.md §8(d) mode T behind the unchanged drop-in call pattern.  Run on the MI355X box: ``pytest -m gpu``.
+
+The reference encodes every occurrence of a news again (manner/models/cr_module.py:107,113 -> news_encoder.py:29-37); the cache
+must never change a number: its keys are compared with a Python dictionary of token tuples, its table bookkeeping with a Python
+model of the same rules, and the module's cached forward with the uncached forward, bit for bit.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from manner_amd import hip  # noqa: E402
+from manner_amd.config import PRESETS  # noqa: E402
+from manner_amd.models.components.news_encoder import MannerTextEncoder  # noqa: E402
+from manner_amd.synth import synth_news_tokens  # noqa: E402
+from manner_amd.weights import make_plm_weights  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rows(n, seed, max_len=40, vocab=50, width=None):
+    """n token rows from a SMALL vocabulary and few lengths (so that equal rows and equal prefixes occur), right-padded."""
+    g = np.random.default_rng(seed)
+    lens = g.integers(1, max_len + 1, n)
+    width = width or max_len
+    ids = np.zeros((n, width), np.int64)
+    mask = np.zeros((n, width), np.int64)
+    for i, ln in enumerate(lens):
+        ids[i, :ln] = g.integers(1, vocab, ln) if g.random() < 0.7 else np.arange(1, ln + 1)       # the second kind repeats often
+        mask[i, :ln] = 1
+    return ids, mask
+
+
+def _tuples(ids, mask):
+    return [tuple(int(t) for t, m in zip(r, mr) if m) for r, mr in zip(ids, mask)]
+
+
+def test_keys_depend_on_the_real_tokens_only():
+    """manner_hip_news_key128: equal keys <=> equal real-token sequences — whatever the padded width, whatever sits in the padded
+    positions, whatever the row's place in the call; a permutation of the tokens, a prefix, an extra token all change the key."""
+    cache = hip.NewsEmbeddingCache(8, 16, DEV)
+    ids, mask = _rows(6000, seed=1)
+    keys = cache.keys(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)).cpu().numpy()
+    assert (keys[:, 0] != 0).all()
+    by_tokens = {}
+    for t, k in zip(_tuples(ids, mask), map(tuple, keys)):
+        assert by_tokens.setdefault(t, k) == k                     # equal tokens -> equal key
+    assert len(set(by_tokens.values())) == len(by_tokens)          # different tokens -> different key
+    assert len(by_tokens) < 6000                                   # the draw does contain repeats
+    # the same rows at another padded width, with garbage under the zero mask, in another order
+    wide_ids = np.full((6000, 57), 12345, np.int64)
+    wide_mask = np.zeros((6000, 57), np.int64)
+    wide_ids[:, :40][mask == 1] = ids[mask == 1]
+    wide_mask[:, :40] = mask
+    perm = np.random.default_rng(2).permutation(6000)
+    keys2 = cache.keys(torch.from_numpy(wide_ids[perm]).to(DEV), torch.from_numpy(wide_mask[perm]).to(DEV)).cpu().numpy()
+    assert np.array_equal(keys2, keys[perm])
+    # order matters, length matters
+    a = np.array([[5, 6, 7, 0], [7, 6, 5, 0], [5, 6, 0, 0], [5, 6, 7, 7]], np.int64)
+    m = (a != 0).astype(np.int64)
+    k = cache.keys(torch.from_numpy(a).to(DEV), torch.from_numpy(m).to(DEV)).cpu().numpy()
+    assert len({tuple(r) for r in k}) == 4
+    # an empty call and an all-padding row are legal
+    assert cache.keys(torch.zeros((0, 4), dtype=torch.int64, device=DEV), torch.zeros((0, 4), dtype=torch.int64, device=DEV)).shape == (0, 2)
+    z = cache.keys(torch.zeros((2, 4), dtype=torch.int64, device=DEV), torch.zeros((2, 4), dtype=torch.int64, device=DEV)).cpu().numpy()
+    assert np.array_equal(z[0], z[1]) and z[0, 0] != 0
+
+
+def test_lookup_follows_the_table_rules():
+    """manner_hip_news_cache_lookup against a Python model: a key seen before -> state 0 and its row; a new key -> state 1 for
+    exactly ONE of its occurrences in the call (the others: state 0, same row), rows handed out densely; once `capacity` rows are out a
+    new key gets state 2 / row -1 on every occurrence and stays that way; clear() forgets everything."""
+    cap = 300
+    cache = hip.NewsEmbeddingCache(4, cap, DEV)
+    assert cache.n_slots == 1024
+    known = {}                   # tokens -> row (None: seen after the table was full)
+    handed = 0
+    for call in range(12):
+        ids, mask = _rows(257, seed=100 + call, max_len=12, vocab=6)
+        rows, state = cache.lookup(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV))
+        rows, state = rows.cpu().numpy(), state.cpu().numpy()
+        new_in_call = {}
+        for t, r, s in zip(_tuples(ids, mask), rows, state):
+            if t in known:
+                if known[t] is None:
+                    assert (s, r) == (2, -1), (call, t, s, r)
+                else:
+                    assert s == 0 and r == known[t], (call, t, s, r)
+            else:
+                new_in_call.setdefault(t, []).append((int(s), int(r)))
+        for t, occ in new_in_call.items():
+            states = sorted(s for s, _ in occ)
+            if states[0] == 2:                                      # the table filled up
+                assert all(o == (2, -1) for o in occ)
+                known[t] = None
+            else:
+                assert states.count(1) == 1 and states.count(0) == len(occ) - 1, (call, t, occ)
+                assert len({r for _, r in occ}) == 1
+                known[t] = occ[0][1]
+                handed += 1
+        got = sorted(r for r in known.values() if r is not None)
+        assert got == list(range(len(got))) and len(got) == min(handed, cap)      # dense, unique rows
+    assert sum(r is None for r in known.values()) > 0 and len([r for r in known.values() if r is not None]) == cap
+    cache.clear()
+    ids, mask = _rows(64, seed=100, max_len=12, vocab=6)
+    rows, state = cache.lookup(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV))
+    assert int((state == 1).sum()) == len(set(_tuples(ids, mask))) and int(rows.max()) == len(set(_tuples(ids, mask))) - 1
+
+
+def _text_encoder(seed=5):
+    cfg = PRESETS["tiny-bert"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = MannerTextEncoder("tiny-bert", frozen_layers=[0], dropout_probability=0.2)
+    w = make_plm_weights(cfg, seed=seed, std=0.05, with_pooler=True)
+    enc.plm_model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    return cfg, enc.to(DEV).eval()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_cached_forward_is_bit_identical_to_encoding_every_occurrence(precision):
+    """MannerTextEncoder.forward (eval, no_grad) with embedding_cache_rows > 0 against the same module without: batches that
+    share news with earlier batches, list a news several times, arrive at different padded widths — every output row equal to
+    the bit; only unseen rows reach the encoder (the cache's counters); a capacity smaller than the number of distinct news
+    changes nothing but the hit rate; a weight update or another precision empties the cache."""
+    cfg, enc = _text_encoder()
+    enc.precision = precision
+    pool_ids, pool_mask = synth_news_tokens(400, cfg, seed=9, max_len=48)
+    g = np.random.default_rng(3)
+
+    def batch(n, width):
+        pick = g.integers(0, 400, n)
+        pick[::7] = pick[0]                                        # one news many times in the batch
+        lp = max(int(pool_mask[pick].sum(1).max()), width)
+        return pick, {"input_ids": torch.from_numpy(pool_ids[pick][:, :lp].copy()).to(DEV),
+                      "attention_mask": torch.from_numpy(pool_mask[pick][:, :lp].copy()).to(DEV)}
+
+    batches = [batch(n, w) for n, w in ((90, 0), (150, 48), (33, 40), (260, 0), (90, 48))]
+    with torch.no_grad():
+        enc.embedding_cache_rows = 0
+        plain = [enc(b) for _, b in batches]
+        for cap in (1024, 120):                                    # 120 < distinct news of the run: part of the rows is never stored
+            enc.embedding_cache_rows = cap
+            seen = set()
+            for (pick, b), ref in zip(batches, plain):
+                before = enc._cache.encoded if enc._cache is not None and enc._cache.capacity == cap else 0
+                out = enc(b)
+                assert torch.equal(out, ref)
+                new = set(pick.tolist()) - seen
+                if cap == 1024:
+                    assert enc._cache.encoded - before == len(new)          # only the unseen news were encoded, each once
+                else:
+                    assert enc._cache.encoded - before >= len(new)
+                seen |= set(pick.tolist())
+            if cap == 1024:
+                assert enc._cache.lookups == sum(len(p) for p, _ in batches) and enc._cache.encoded == len(seen)
+        # a weight update: the next call must not serve the old embeddings
+        enc.embedding_cache_rows = 1024
+        first = enc(batches[0][1])
+        with torch.no_grad():
+            enc.plm_model.get_parameter("encoder.layer.1.output.dense.weight").mul_(1.5)
+        enc.embedding_cache_rows = 0
+        fresh = enc(batches[0][1])
+        enc.embedding_cache_rows = 1024
+        again = enc(batches[0][1])
+        assert not torch.equal(fresh, first) and torch.equal(again, fresh)
+        other = "f16" if precision == "fp32" else "fp32"
+        enc.precision = other
+        enc.embedding_cache_rows = 0
+        ref_other = enc(batches[1][1])
+        enc.embedding_cache_rows = 1024
+        assert torch.equal(enc(batches[1][1]), ref_other) and not torch.equal(ref_other, plain[1])
+    enc.check_inputs()
+
+
+def test_cache_is_bypassed_when_a_graph_is_recorded():
+    """train() mode and eval() with grad mode on run the differentiable engine (dropout, autograd): nothing is cached there."""
+    cfg, enc = _text_encoder()
+    enc.embedding_cache_rows = 256
+    ids, mask = synth_news_tokens(12, cfg, seed=4, max_len=20)
+    b = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    enc.train()
+    out = enc(b)
+    assert out.requires_grad and enc._cache is None
+    enc.eval()
+    with torch.no_grad():
+        enc(b)
+    assert enc._cache is not None and enc._cache.encoded == 12

@@ -20,4 +20,4 @@ dev = torch.device("cuda", 0)
 w = make_plm_weights(cfg, seed=42, std=0.02)
 ids, mask = synth_news_tokens(65238, cfg, seed=42, max_len=96, profile="title_abstract")
 pool = (torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), mask.sum(1))
-print(json.dumps(bench.dropin_leg(cfg, model, w, pool, dev, "f16", only=case), indent=0)[-1200:])
+print(json.dumps(bench.dropin_leg(cfg, model, w, pool, dev, "f16", only=case), indent=0)[-2600:])
