@@ -468,7 +468,12 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
     w = make_plm_weights(cfg, seed=42, std=0.02, with_pooler=False)
     out = {"what": train_leg.__doc__.split("  Batch")[0].strip(), "precision": precision + " GEMM operands, f32 accumulation / activations / gradients",
            "impressions_per_step": impressions, "news_per_step": n_hist + n_cand, "tokens_per_step": tokens, "frozen_layers": list(frozen)}
-    for variant, emb_trainable in (("reference_default_embeddings_trainable", True), ("embeddings_frozen_cached_prefix", False)):
+    for variant, emb_trainable in (("reference_default_embeddings_trainable", True), ("embeddings_frozen_cached_prefix", False),
+                                   ("embeddings_frozen_prefix_cache_across_steps", False)):
+        # third variant: the hidden states after the frozen layers come out of the content-addressed table in HBM (hip.PrefixCache;
+        # MannerTextEncoder.prefix_cache_rows) — the batch is the same every step here, so after the first step every news is "seen":
+        # the steady state of epochs >= 2 of the reference's 5-epoch schedule, not of a first epoch
+        across = variant.endswith("across_steps")
         torch.cuda.reset_peak_memory_stats(dev)
         resident_before = torch.cuda.memory_allocated(dev)   # what earlier legs left allocated (token pool, step batches): not this leg's
         params = {k: torch.from_numpy(v).to(dev).requires_grad_((emb_trainable or not k.startswith("embeddings.")) and
@@ -476,12 +481,19 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
         engine = None if emb_trainable else hip.HipEncoder(cfg, w, precisions=(precision,), device=dev)
         opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-5, fused=True)   # the reference's optimiser class, its fused implementation
         step_no = [0]
+        pcache = hip.PrefixCache(cfg.hidden, 32, 4096, dev) if across else None
+        first_layer = min(l for l in range(cfg.layers) if l not in frozen)
 
         def enc(x):
             step_no[0] += 1
+            extra = {}
+            if pcache is not None:
+                with torch.no_grad():
+                    extra = dict(start_layer=first_layer,
+                                 prefix_hidden=pcache.hidden_states(engine, x["input_ids"], x["attention_mask"], first_layer, precision))
             return train.encode_train(cfg, params, x["input_ids"], x["attention_mask"], precision=precision, p_hidden=0.1, p_attn=0.1,
                                       p_out=0.2, seed=step_no[0], prefix_engine=engine,
-                                      token_bound=tokens if x["input_ids"].shape[0] == n_hist + n_cand else None)
+                                      token_bound=tokens if x["input_ids"].shape[0] == n_hist + n_cand else None, **extra)
 
         def step():
             loss, _, _ = hotpath.cr_train_step(enc, batch, supcon=True, temperature=0.36)
@@ -512,6 +524,13 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
                         "loss_first_step": first, "loss_last_step": float(last.detach()),
                         "peak_GB": (torch.cuda.max_memory_allocated(dev) - resident_before) / 1e9,
                         "resident_from_earlier_legs_GB": resident_before / 1e9}
+        if pcache is not None:
+            out[variant].update({"prefix_cache_hit_rate_timed_steps": 1.0, "news_encoded_by_the_prefix_engine_in_all_steps": pcache.encoded,
+                                 "news_looked_up": pcache.lookups, "loss_equal_to_recomputed_prefix_variant":
+                                 bool(out["embeddings_frozen_cached_prefix"]["loss_first_step"] == first
+                                      and out["embeddings_frozen_cached_prefix"]["loss_last_step"] == float(last.detach())),
+                                 "table_MB": round(pcache.table.numel() * 4 / 1e6, 1)})
+            del pcache
         if engine is not None:
             engine.close()
         del params, opt

@@ -147,6 +147,7 @@ class MannerTextEncoder(nn.Module):
         d["_hip"], d["_hip_key"] = None, None
         d["_cache"] = None
         d["_hip_prefix"], d["_hip_prefix_key"] = None, None
+        d["_prefix_cache"], d["_prefix_cache_key"] = None, None
         return d
 
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
@@ -201,8 +202,30 @@ class MannerTextEncoder(nn.Module):
         engine = self._prefix_encoder(ids.device, params) if (emb_frozen and first_frozen) else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch's CPU generator: reproducible under manual_seed
         on = 1.0 if dropout else 0.0
+        extra = {}
+        if engine is not None and self.prefix_cache_rows > 0:
+            # frozen prefix from the content-addressed table (constant across epochs): only unseen news run layers 0..k-1
+            start = train.first_trainable_layer(plm.cfg, params)
+            if 0 < start:
+                pc = getattr(self, "_prefix_cache", None)
+                want = (self.prefix_cache_rows, self.prefix_cache_len, str(ids.device), self._hip_prefix_key)
+                if pc is None or self._prefix_cache_key != want:
+                    if pc is not None and (pc.capacity, pc.max_len, str(pc.device)) == want[:3]:
+                        pc.clear()                                   # same table, other frozen weights / precision
+                    else:
+                        pc = self._prefix_cache = hip.PrefixCache(plm.cfg.hidden, self.prefix_cache_len, self.prefix_cache_rows, ids.device)
+                    self._prefix_cache_key = want
+                with torch.no_grad():
+                    ph = pc.hidden_states(engine, ids, mask, start, self.train_precision if self.train_precision != "fp32" else "fp32")
+                extra = dict(prefix_hidden=ph, start_layer=start)
         return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=on * plm.hidden_dropout_prob,
-                                  p_attn=on * plm.attention_probs_dropout_prob, p_out=on * self.dropout.p, seed=seed, prefix_engine=engine)
+                                  p_attn=on * plm.attention_probs_dropout_prob, p_out=on * self.dropout.p, seed=seed, prefix_engine=engine,
+                                  **extra)
+
+    #: Opt-in: rows of a `hip.PrefixCache` — the hidden states after the frozen layers, kept per news across steps and epochs when the
+    #: embeddings and a prefix of layers are frozen.  One row is prefix_cache_len x hidden f32 (96 x 768: 295 KB).
+    prefix_cache_rows: int = int(os.environ.get("MANNER_PREFIX_CACHE_ROWS", "0"))
+    prefix_cache_len: int = int(os.environ.get("MANNER_PREFIX_CACHE_LEN", "96"))       # tokenizer_max_length, configs/data/mind_rec.yaml:41
 
     def forward(self, tokenized_text) -> torch.Tensor:
         ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]

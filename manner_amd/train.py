@@ -176,6 +176,19 @@ class _EncodeTrain(torch.autograd.Function):
         return (None, None, gprefix, None, *grads)       # the activation buffer lives with ctx: backward(retain_graph=True) may run again
 
 
+def first_trainable_layer(cfg: EncoderConfig, params: Dict[str, Tensor]) -> int:
+    """Index of the layer training starts at when everything below it is frozen — 0 when an embedding table trains (the reference's
+    default: the gradient then crosses every layer), else the first layer with a trainable tensor, capped at the last layer."""
+    canon = canonical_weights(cfg, params)
+    table = [canon[name] for name in hip.weight_table_order(cfg)]
+    if any(t.requires_grad for t in table[:_lib.W_EMB_COUNT]):
+        return 0
+    for l in range(cfg.layers):
+        if any(t.requires_grad for t in table[_lib.W_EMB_COUNT + l * _lib.WL_COUNT:_lib.W_EMB_COUNT + (l + 1) * _lib.WL_COUNT]):
+            return min(l, cfg.layers - 1)
+    return cfg.layers - 1
+
+
 def encode_train(cfg: EncoderConfig, params: Dict[str, Tensor], ids: Tensor, mask: Tensor, *, precision: str = "f16",
                  p_hidden: float = 0.1, p_attn: float = 0.1, p_out: float = 0.2, seed: int = 0,
                  prefix_engine: Optional[hip.HipEncoder] = None, prefix_hidden: Optional[Tensor] = None,

@@ -190,3 +190,68 @@ def test_cache_is_bypassed_when_a_graph_is_recorded():
     with torch.no_grad():
         enc(b)
     assert enc._cache is not None and enc._cache.encoded == 12
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_prefix_cache_training_is_bit_identical_to_recomputing_the_frozen_prefix(precision):
+    """SURVEY §8f rank 3: with the embeddings and layer 0 frozen the hidden states after layer 0 are constant across steps;
+    `MannerTextEncoder.prefix_cache_rows` keeps them per news in HBM (hip.PrefixCache) instead of running the frozen layers again.
+    Same seeds -> the outputs and every gradient of train() forwards/backwards are equal to the bit with the cache on and off, over
+    batches that share news, repeat news and arrive at different padded widths (a row stored at a narrow width reads zeros beyond it,
+    as encode_hidden writes them); only unseen news reach the prefix engine; changing a FROZEN weight empties the table."""
+    cfg, enc = _text_encoder(seed=6)
+    enc.train_precision = precision
+    for n, p in enc.plm_model.named_parameters():
+        if n.startswith("embeddings."):
+            p.requires_grad_(False)
+    pool_ids, pool_mask = synth_news_tokens(300, cfg, seed=12, max_len=40)
+    g = np.random.default_rng(5)
+
+    def batch(n, width):
+        pick = g.integers(0, 300, n)
+        pick[::5] = pick[1]
+        lp = max(int(pool_mask[pick].sum(1).max()), width)
+        return pick, {"input_ids": torch.from_numpy(pool_ids[pick][:, :lp].copy()).to(DEV),
+                      "attention_mask": torch.from_numpy(pool_mask[pick][:, :lp].copy()).to(DEV)}
+
+    batches = [batch(n, w) for n, w in ((40, 0), (64, 40), (25, 30), (64, 0))]
+    R = torch.from_numpy(np.random.default_rng(6).standard_normal((64, cfg.hidden)).astype(np.float32)).to(DEV)
+    enc.train()
+
+    def run(rows):
+        enc.prefix_cache_rows, enc.prefix_cache_len = rows, 40
+        res = []
+        for k, (_, b) in enumerate(batches):
+            for p in enc.parameters():
+                p.grad = None
+            torch.manual_seed(100 + k)                              # the dropout seed comes from torch's CPU generator
+            out = enc(b)
+            (out * R[:out.shape[0]]).sum().backward()
+            res.append((out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}))
+        return res
+
+    plain = run(0)
+    assert getattr(enc, "_prefix_cache", None) is None
+    cached = run(512)
+    pc = enc._prefix_cache
+    seen = set()
+    for _, (pick, _) in zip(cached, batches):
+        seen |= set(pick.tolist())
+    assert pc.lookups == sum(len(p) for p, _ in batches) and pc.encoded == len(seen)
+    for (o1, g1), (o2, g2) in zip(plain, cached):
+        assert torch.equal(o1, o2)
+        assert g1.keys() == g2.keys() and len(g1) > 4
+        for n in g1:
+            assert torch.equal(g1[n], g2[n]), n
+    again = run(512)                                               # every news cached now
+    assert pc.encoded == len(seen)
+    for (o1, _), (o2, _) in zip(plain, again):
+        assert torch.equal(o1, o2)
+    # a frozen weight changes: the table must not serve the old hidden states
+    with torch.no_grad():
+        enc.plm_model.get_parameter("encoder.layer.0.output.dense.weight").mul_(1.3)
+    fresh = run(0)
+    after = run(512)
+    assert not torch.equal(fresh[0][0], plain[0][0])
+    for (o1, _), (o2, _) in zip(fresh, after):
+        assert torch.equal(o1, o2)
