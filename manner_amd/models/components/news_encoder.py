@@ -282,6 +282,26 @@ class MannerTextEncoder(nn.Module):
             cache.clear()                      # keys of this call may point at rows that were never written
             raise
 
+    def warm_embedding_cache(self, tokenized_text, chunk: int = 8192) -> int:
+        """Encode a whole news pool into the embedding cache in large calls (mode T's table build: the engine's full rate instead
+        of the latency floor of the small calls that misses inside a batch cost) — e.g. from a Lightning ``on_test_start`` hook with
+        the tokenised news of the dev set; every later eval() forward then finds its rows.  Needs ``embedding_cache_rows`` > 0 and
+        eval() mode; returns the number of news that were encoded."""
+        if self.embedding_cache_rows <= 0:
+            raise RuntimeError("warm_embedding_cache: set embedding_cache_rows first")
+        if self.training:
+            raise RuntimeError("warm_embedding_cache: eval() mode only (train() draws dropout masks and records a graph)")
+        ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
+        encoded = 0
+        with torch.no_grad():
+            for a in range(0, ids.shape[0], chunk):
+                cache = getattr(self, "_cache", None)
+                e0 = cache.encoded if cache is not None else 0
+                self.forward({"input_ids": ids[a:a + chunk], "attention_mask": mask[a:a + chunk]})
+                e1 = self._cache.encoded
+                encoded += e1 - e0 if (self._cache is cache and e1 >= e0) else e1      # the first call may create or empty the table
+        return encoded
+
     def check_inputs(self) -> None:
         """Blocking: raise if any forward so far saw an invalid attention_mask / input id."""
         if self._hip is not None:

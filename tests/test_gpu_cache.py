@@ -255,3 +255,26 @@ def test_prefix_cache_training_is_bit_identical_to_recomputing_the_frozen_prefix
     assert not torch.equal(fresh[0][0], plain[0][0])
     for (o1, _), (o2, _) in zip(fresh, after):
         assert torch.equal(o1, o2)
+
+
+def test_warming_the_cache_with_the_news_pool_makes_every_batch_a_hit():
+    """`warm_embedding_cache(pool)` — the table build of mode T in large calls — then batches drawn from the pool reach the encoder
+    with nothing to encode, and their outputs are the uncached forward's to the bit."""
+    cfg, enc = _text_encoder(seed=8)
+    pool_ids, pool_mask = synth_news_tokens(500, cfg, seed=21, max_len=32)
+    pool = {"input_ids": torch.from_numpy(pool_ids).to(DEV), "attention_mask": torch.from_numpy(pool_mask).to(DEV)}
+    pick = np.random.default_rng(2).integers(0, 500, 96)
+    lp = int(pool_mask[pick].sum(1).max())
+    b = {"input_ids": pool["input_ids"][pick][:, :lp].contiguous(), "attention_mask": pool["attention_mask"][pick][:, :lp].contiguous()}
+    with torch.no_grad():
+        ref = enc(b)
+    with pytest.raises(RuntimeError):
+        enc.warm_embedding_cache(pool)                             # the cache is off
+    enc.embedding_cache_rows = 600
+    n_unique = len({tuple(r[m == 1]) for r, m in zip(pool_ids, pool_mask)})
+    assert enc.warm_embedding_cache(pool, chunk=128) == n_unique
+    assert enc.warm_embedding_cache(pool, chunk=128) == 0          # idempotent
+    with torch.no_grad():
+        before = enc._cache.encoded
+        out = enc(b)
+    assert enc._cache.encoded == before and torch.equal(out, ref)
