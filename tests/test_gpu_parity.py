@@ -1223,3 +1223,32 @@ def test_baseline_encoders_match_reference(golden_dir):
     with torch.no_grad():
         out = ue.to(DEV).eval()(_cuda(x)).cpu().numpy()
     assert np.abs(out - O.nrms_user_encoder(x, mha, pool, 16).numpy()).max() < 2e-4
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("arch,n_news,max_len", [("bert-base-uncased", 7, 40), ("bert-base-uncased", 70, 96), ("mini-roberta-large", 33, 48),
+                                                  ("bert-base-uncased", 300, 30)])
+def test_small_inference_calls_take_128x128_tiles_and_give_the_same_bits(precision, arch, n_news, max_len, monkeypatch):
+    """Round 4: a call with few 256x256 tiles (a handful of unseen news behind the embedding cache, an A-Module batch of 60, the
+    reference's batch of 8) runs the deferred-LayerNorm GEMMs (EPI_NORM / EPI_NORM_GELU / EPI_NRES) on `gemm_tn_small_kernel` —
+    128x128 tiles, the persistent kernel's matrix instruction in the same K order, the same epilogue expressions and the same
+    per-64-column row statistics.  MANNER_HIP_GEMM_SMALL_TILES=0 sends the same call through the persistent 256x256 kernel:
+    [CLS] embeddings and layer-k hidden states are equal to the BIT (what the embedding / prefix caches rest on: a row encoded in a
+    small call must be the row a large call would have produced), for token counts that end inside a 128-row tile and below one."""
+    import dataclasses
+    cfg = PRESETS[arch] if arch.startswith("mini") else dataclasses.replace(PRESETS[arch], layers=3)
+    w = make_plm_weights(cfg, seed=91, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=91, max_len=max_len)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")
+    ref_cls = enc.encode_cls(ids, mask, precision=precision)
+    ref_hid = enc.encode_hidden(ids, mask, 2, precision=precision)
+    monkeypatch.delenv("MANNER_HIP_GEMM_SMALL_TILES")
+    cls = enc.encode_cls(ids, mask, precision=precision)
+    hid = enc.encode_hidden(ids, mask, 2, precision=precision)
+    enc.status()
+    assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1
+    assert torch.equal(cls, ref_cls)
+    assert torch.equal(hid, ref_hid)
+    enc.close()

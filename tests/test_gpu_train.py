@@ -159,7 +159,10 @@ def test_small_problem_gemm_equals_the_persistent_kernel(precision, monkeypatch)
         res[tiles] = (out.detach().cpu().numpy(), _grads(params))
     monkeypatch.delenv("MANNER_HIP_GEMM_SMALL_TILES", raising=False)
     a, b = res[None], res["0"]
-    assert np.isfinite(a[0]).all() and np.abs(a[0] - b[0]).max() < 2e-3 * max(1.0, np.abs(b[0]).max())
+    # round 4: the 128x128 kernel runs the persistent kernel's matrix instruction (16x16x32) in the same K order with the same
+    # epilogue expressions — the forward is equal to the BIT; the gradients pass through the weight-gradient slices, whose count
+    # follows the tile count, so they keep the summation-order tolerance
+    assert np.isfinite(a[0]).all() and np.array_equal(a[0], b[0])
     for k, g in b[1].items():
         if g is None:
             assert a[1][k] is None
