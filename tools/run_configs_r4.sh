@@ -12,7 +12,7 @@ for c in (1, 2, 3, 4):
     try:
         d = json.loads(open(f"gpurun_out/r4/bench_config{c}.json").read().strip().splitlines()[-1])
         print(c, round(d["value"]), d["dtype"], round(d["encoder_mfma_frac"], 3), "bf16", round(d["bf16_mode"]["value"]), round(d["bf16_mode"]["encoder_mfma_frac"], 3),
-              "cpu", round(d["cpu_baseline"]["value"], 1), "parity", {k: v["top10_identical"] for k, v in d["config"]["parity_vs_oracle"].items() if isinstance(v, dict)})
+              "cpu", round(d["cpu_baseline"]["value"], 1), "parity", {k: v["top10_identical"] for k, v in d["config"]["parity_vs_oracle"].items() if isinstance(v, dict) and "top10_identical" in v})
     except Exception as e:
         print(c, "unreadable:", e)
 PY
