@@ -96,8 +96,9 @@ int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias,
 //                              vec = c1 (column sums of W'), bias = c2 (see fold_layernorm)
 //   EPI_NRES (in place on Y) : Y = X W^T + bias + ((Y - mean) * rstd) * vec,  vec = gamma, bias = b + beta;
 //                              also writes part[N/64][m_bound] = per-wave {sum, sum of squares} of the new rows.
+// m_exact >= 0: the host knows *m_total (a launch whose rows fill whole rounds then skips the tail launch of the round-aware split)
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
-                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream);
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact = -1);
 
 // K11 logits[r] = sum_j tanh(x[r] . W[j] + b[j]) q[j] on the f32 MFMA (D % 32 == 0, Q <= 256); x [R, D], W [Q, D]
 int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,

@@ -231,11 +231,11 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
       }
       PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, w.wqkv_f, p.cq2, w.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
       PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
       if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(dt, EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, w.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
     }
     if (hidden_layers >= 0) {   // the residual stream is still un-normalised: apply the LayerNorm that closes layer hidden_layers-1

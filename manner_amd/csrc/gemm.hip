@@ -297,7 +297,22 @@ struct SmallAux {
   const float2* mr;       // {mean, rstd} per row (EPI_NORM*: of X;  EPI_NRES: of the residual rows in Y)
   float2* part;           // EPI_NRES: [N/64][part_stride] partial {sum, sum of squares} of the rows written
   int64_t part_stride;
+  int tail_cus;           // > 0: TAIL mode — this launch takes the row panels the persistent kernel leaves (split_panels)
 };
+
+// Round-aware split of a launch (round 4; opt-in, MANNER_HIP_GEMM_TAIL_SPLIT=1 — a measured near-zero, see gemm_tn_dln).  A persistent launch of `tiles` 256x256 tiles on `cus` workgroups lasts ceil(tiles / cus)
+// whole tile times, so 282 tiles (94 row panels x N = 768: the history call of a batch of 8 impressions) take two rounds with 26
+// tiles in the second.  Because the 128x128 kernel gives the same bits, the launch can be cut at a row panel: the persistent kernel
+// takes the panels that fill r whole rounds, the 128x128 kernel the rest — if that rest is at most ONE round of small tiles (else
+// the persistent kernel keeps everything).  Both kernels evaluate this function on the device token count, so they always agree.
+__host__ __device__ inline int split_panels(int m_tiles, int n_tiles256, int cus) {
+  const int tiles = m_tiles * n_tiles256;
+  const int r = tiles / cus;
+  if (cus <= 0 || r < 1 || tiles == r * cus) return m_tiles;
+  const int p0 = (r * cus) / n_tiles256;
+  if ((m_tiles - p0) * 4 * n_tiles256 > cus) return m_tiles;
+  return p0;
+}
 
 template <typename TE, typename TOut, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_tn_small_kernel(
@@ -313,8 +328,15 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_small_kernel(
   const int nwg = gridDim.x, b = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
   const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  int mt = t / n_tiles;
+  const int nt = t - mt * n_tiles;
   const int M = *m_total;
+  if (aux.tail_cus > 0) {                                // the panels behind the persistent kernel's whole rounds
+    const int m256 = (M + 255) / 256;
+    const int p0 = split_panels(m256, n_tiles / 2, aux.tail_cus);
+    if (p0 >= m256) return;
+    mt += 2 * p0;
+  }
   if (mt * BM >= M) return;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -462,7 +484,8 @@ template <typename TIn, typename TOut, int EPI>
 int launch_small(const void* X, const void* W, const float* bias, const float* R, void* Y, int64_t m_bound, int N, int K,
                  const int* m_total, const Drop& drop, const int32_t* rowmap, hipStream_t stream, const SmallAux& aux = SmallAux{}) {
   const int n_tiles = N / BN;
-  const int64_t grid = (m_bound / BM) * n_tiles;
+  int64_t grid = (m_bound / BM) * n_tiles;
+  if (aux.tail_cus > 0 && grid > aux.tail_cus) grid = aux.tail_cus;          // a tail is at most one round of small tiles
   if (grid <= 0 || grid > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)grid);
   hipLaunchKernelGGL((gemm_tn_small_kernel<TIn, TOut, EPI>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const TIn*>(X),
                      static_cast<const TIn*>(W), bias, R, static_cast<TOut*>(Y), N, K, m_total, n_tiles, drop, rowmap, aux);
@@ -842,6 +865,8 @@ struct DlnAux {
   // EPI_GELU_GRAD: saved f32 pre-activation [m, N] whose gelu' multiplies the output
   void* aux16;
   const float* aux32;
+  // > 0 (and col_group == 0): this launch covers only the row panels of split_panels(); a tail launch of the 128x128 kernel follows
+  int split_cus;
 };
 
 template <typename TE, typename TOut, int EPI, int ABL = 0>
@@ -867,7 +892,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
   const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   const int M = *m_total;
-  const int m_tiles = (M + G_BM - 1) / G_BM;
+  const int m_tiles = dln.split_cus > 0 ? split_panels((M + G_BM - 1) / G_BM, n_tiles, dln.split_cus) : (M + G_BM - 1) / G_BM;
   const int valid_tiles = m_tiles * n_tiles;
   // Tile order: column tiles are walked in groups of `gsz`; within a group the order is row-panel-major.  One pass
   // over the rows then touches only gsz weight tiles (gsz * 256 * K * 2 bytes), which stay resident in the XCD's 4 MB
@@ -1485,7 +1510,7 @@ static int launch_dln(Epilogue epi, const void* X, const void* W, const float* b
 }
 
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
-                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact) {
   static const int col_group_env = getenv("MANNER_HIP_COL_GROUP") ? atoi(getenv("MANNER_HIP_COL_GROUP")) : -1;   // A/B switch
   const int col_group = col_group_env >= 0 ? col_group_env : 0;
   if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
@@ -1494,7 +1519,7 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   if (!is_16bit(dt)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: 16-bit element types only");
   if (small_problem(m_bound, N) && K % 64 == 0) {          // few tiles: 128x128 tiles of the same arithmetic (bit-identical results)
     const Drop none{0, 0, 0, 1.f};
-    const SmallAux sa{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound};
+    const SmallAux sa{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, 0};
 #define MANNER_SMALL_DLN(TE_)                                                                                                                    \
   switch (epi) {                                                                                                                                 \
     case EPI_NORM: return launch_small<TE_, TE_, EPI_NORM>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream, sa);            \
@@ -1514,8 +1539,34 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
   static const int stagger = getenv("MANNER_HIP_GEMM_STAGGER") ? atoi(getenv("MANNER_HIP_GEMM_STAGGER")) : 0;   // A/B switch
   aux.stagger = stagger;
-  if (dt == DT_F16) return launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
-  return launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+  // Round-aware split (see split_panels): only where a tail can exist by the host's bound (more tiles than workgroups), for the narrow
+  // outputs whose rounds are long and few (N <= 1024: out-projection / FFN2, 3 - 4 column tiles), with the default tile order.
+  const char* ts_env = getenv("MANNER_HIP_GEMM_TAIL_SPLIT");                 // A/B switch, read per launch (the tests flip it)
+  // OFF by default — measured (drop-in eval, f16, bert-base): B = 64 batches 62.4 -> 61.7 ms, B = 8 batches 8.76 -> 8.99 ms: at the
+  // reference's batch size most calls have FEWER tiles than CUs (one under-filled round, which no cut can fix) and the calls that do
+  // overflow rarely land in the one-round window, so the extra launch (3 - 8 us, 22 per call) costs more than the cut saves.
+  bool split = ts_env && atoi(ts_env) != 0 && col_group == 0 && n_tiles <= 4 && tiles > cus && K % 64 == 0 && stagger == 0;
+  if (split && m_exact >= 0) {                       // the caller knows the token count: no tail launch that would find nothing to do
+    const int mp = (int)((m_exact + G_BM - 1) / G_BM);
+    split = split_panels(mp, n_tiles, (int)cus) < mp;
+  }
+  if (split) aux.split_cus = (int)cus;
+  int rc;
+  if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+  else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+  if (rc || !split) return rc;
+  const Drop none{0, 0, 0, 1.f};
+  const SmallAux sa{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, (int)cus};
+#define MANNER_TAIL_DLN(TE_)                                                                                                                     \
+  switch (epi) {                                                                                                                                 \
+    case EPI_NORM: return launch_small<TE_, TE_, EPI_NORM>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream, sa);            \
+    case EPI_NORM_GELU: return launch_small<TE_, TE_, EPI_NORM_GELU>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream, sa);  \
+    case EPI_NRES: return launch_small<TE_, TE_, EPI_NRES>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream, sa);            \
+    default: return fail(MANNER_HIP_E_INVALID, "gemm_dln: epilogue %d", (int)epi);                                                                \
+  }
+  if (dt == DT_F16) { MANNER_TAIL_DLN(f16_t) }
+  MANNER_TAIL_DLN(bf16_t)
+#undef MANNER_TAIL_DLN
 }
 
 // `batch` independent Y_b [rows, N] (f32) = X_b [rows, K] . W_b [N, K]^T + bias on 16-bit operands, problem b at element

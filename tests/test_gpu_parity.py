@@ -1252,3 +1252,33 @@ def test_small_inference_calls_take_128x128_tiles_and_give_the_same_bits(precisi
     assert torch.equal(cls, ref_cls)
     assert torch.equal(hid, ref_hid)
     enc.close()
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("n_news,with_lengths", [(300, False), (300, True), (330, False), (256, True), (256, False)])
+def test_round_aware_split_of_a_launch_gives_the_same_bits(precision, n_news, with_lengths, monkeypatch):
+    """Round 4: a deferred-LayerNorm GEMM with N <= 1024 whose row panels overflow whole rounds of 256x256 tiles by at most one
+    round of 128x128 tiles is cut at a row panel — the persistent kernel takes the panels of the whole rounds, `gemm_tn_small_kernel`
+    (tail mode) the rest; both read the cut from the DEVICE token count (`split_panels`).  ~24 k tokens: 94 - 103 row panels, 282 - 309
+    tiles for the out-projection / FFN2 on 256 CUs.  Opt-in (MANNER_HIP_GEMM_TAIL_SPLIT=1; measured at -1 % / +2.6 % of a drop-in batch, DESIGN
+    section 4); without it the launch stays whole: [CLS] embeddings and hidden
+    states equal to the bit, with the loose bound of a call without host lengths and with the exact count of a call with them."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS["bert-base-uncased"], layers=3)
+    w = make_plm_weights(cfg, seed=93, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=93, max_len=96, profile="title_abstract")
+    lens = mask_np.sum(1) if with_lengths else None
+    assert 85 * 256 < int(mask_np.sum()) < 107 * 256 or n_news == 256
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_TAIL_SPLIT", "0")
+    ref_cls = enc.encode_cls(ids, mask, precision=precision, host_lengths=lens)
+    ref_hid = enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens)
+    monkeypatch.setenv("MANNER_HIP_GEMM_TAIL_SPLIT", "1")
+    cls = enc.encode_cls(ids, mask, precision=precision, host_lengths=lens)
+    hid = enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens)
+    enc.status()
+    assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1
+    assert torch.equal(cls, ref_cls)
+    assert torch.equal(hid, ref_hid)
+    enc.close()
