@@ -428,20 +428,21 @@ int pool_fused(const float* x, const float* W, const float* bias, const float* q
   MANNER_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_pack_w_kernel, dim3(128), dim3(256), 0, stream, W, bias, query, Q, D, ks, n_pass, wmax, kw, Wp, bq);
   MANNER_LAUNCH_CHECK();
-  // S <= 64: 4-wave workgroups, two per CU (one's loads and epilogue run under the other's matrix work); 64 < S <= 128: 8 waves.
-  // MANNER_HIP_POOL_NW=8 forces the 8-wave form for every S (A/B: 0.436 vs 0.432 ms at B = 4096, S = 50).
+  // 8-wave workgroups (one per CU) with ring stages of FOUR k-steps (one barrier and one counted wait per 4 x 15 matrix instructions
+  // per wave; 3 stages = 120 KiB): 0.418 ms at B = 4096, S = 50 against 0.454 for the 4-wave form (two workgroups per CU, stages of
+  // two k-steps) and 0.436 for 8 waves with stages of two.  MANNER_HIP_POOL_NW=4 selects the 4-wave form (S <= 64 only).
   unsigned long long* diag = nullptr;
 #ifdef MANNER_POOL_DIAG
   if (const char* de = getenv("MANNER_HIP_POOL_DIAG")) diag = reinterpret_cast<unsigned long long*>(strtoull(de, nullptr, 0));
 #endif
   const char* nw_env = getenv("MANNER_HIP_POOL_NW");
-  if (sp <= 4 && !(nw_env && atoi(nw_env) == 8)) {
+  if (sp <= 4 && nw_env && atoi(nw_env) == 4) {
     const int bpw = 4 / sp;
     hipLaunchKernelGGL((pool_fused_kernel<24, 4, 3, 2>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(256), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
                        (int)S, sp, out, diag);
   } else {
     const int bpw = 8 / sp;
-    hipLaunchKernelGGL((pool_fused_kernel<24, 8, 6, 2>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(512), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
+    hipLaunchKernelGGL((pool_fused_kernel<24, 8, 3, 4>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(512), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
                        (int)S, sp, out, diag);
   }
   MANNER_LAUNCH_CHECK();
