@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void cache_claim_kernel(const uint64_t* __rest
   const uint64_t maskb = (uint64_t)n_slots - 1;
   uint64_t i = mix64(k0) & maskb;
   int32_t slot = -1, won = 0;
-  for (int64_t probe = 0; probe < n_slots; ++probe, i = (i + 1) & maskb) {
+  // bounded probing: insertion and search give up at the same distance, so a key is either within it or not in the table; a table
+  // that has seen far more distinct keys than it has slots degrades to "encode, do not store" instead of to a long walk
+  const int64_t max_probe = n_slots < 1024 ? n_slots : 1024;
+  for (int64_t probe = 0; probe < max_probe; ++probe, i = (i + 1) & maskb) {
     unsigned long long cur = __hip_atomic_load(&slot_k0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == 0) {
       cur = atomicCAS(&slot_k0[i], 0ull, k0);
