@@ -278,3 +278,4 @@ def test_warming_the_cache_with_the_news_pool_makes_every_batch_a_hit():
         before = enc._cache.encoded
         out = enc(b)
     assert enc._cache.encoded == before and torch.equal(out, ref)
+
