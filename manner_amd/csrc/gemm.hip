@@ -456,9 +456,14 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_small_kernel(
         if constexpr (EPI == EPI_NORM || EPI == EPI_NORM_GELU) v[e] = fmaf(ms.y, fmaf(-ms.x, cv[a][e], acc[a][bb][e]), bv[a][e]);
         else v[e] = acc[a][bb][e] + bv[a][e];
       }
-      if constexpr (EPI == EPI_NORM_GELU) {
+      if constexpr (EPI == EPI_NORM_GELU || EPI == EPI_BIAS_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);
+      }
+      if constexpr (EPI == EPI_BIAS_RES) {               // the [CLS] tail's projections: residual of the operand type, f32 out
+        const e16x4 rv = *reinterpret_cast<const e16x4*>(reinterpret_cast<const TE*>(R) + (size_t)m * N + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
       }
       if constexpr (EPI == EPI_BIAS_RES_F32) {
         const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (size_t)m * N + n0);
@@ -1669,9 +1674,17 @@ int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, con
   if (out != DT_F32 && out != in) return fail(MANNER_HIP_E_INVALID, "gemm dtype combination unsupported");
   static const bool use_v1 = getenv("MANNER_HIP_GEMM_V1") != nullptr;   // A/B switch for development
   if (!use_v1 && is_16bit(in) && m_bound % G_BM == 0 && N % G_BN == 0 && K % 64 == 0 && small_problem(m_bound, N) &&
-      (epi == EPI_BIAS || epi == EPI_BIAS_RES_F32)) {
+      (epi == EPI_BIAS || epi == EPI_BIAS_RES_F32 || (epi == EPI_BIAS_RES && out == DT_F32) || (epi == EPI_BIAS_GELU && out == in))) {
     const Drop none{0, 0, 0, 1.f};
     const float* rf = static_cast<const float*>(residual);
+    if (epi == EPI_BIAS_RES) {                              // the inference engine's [CLS] tail (same bits as the persistent kernel)
+      if (in == DT_F16) return launch_small<f16_t, float, EPI_BIAS_RES>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
+      return launch_small<bf16_t, float, EPI_BIAS_RES>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    }
+    if (epi == EPI_BIAS_GELU) {
+      if (in == DT_F16) return launch_small<f16_t, f16_t, EPI_BIAS_GELU>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+      return launch_small<bf16_t, bf16_t, EPI_BIAS_GELU>(X, W, bias, nullptr, Y, m_bound, N, K, m_total, none, nullptr, stream);
+    }
     if (epi == EPI_BIAS_RES_F32) {
       if (in == DT_F16) return launch_small<f16_t, float, EPI_BIAS_RES_F32>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
       return launch_small<bf16_t, float, EPI_BIAS_RES_F32>(X, W, bias, rf, Y, m_bound, N, K, m_total, none, nullptr, stream);
