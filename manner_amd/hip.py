@@ -349,10 +349,13 @@ class NewsEmbeddingCache:
         while n_slots < 2 * self.capacity:
             n_slots *= 2
         self.n_slots = n_slots
-        self.table = (torch.zeros if zero else torch.empty)((self.capacity, self.dim), dtype=torch.float32, device=self.device)
-        self.slot_keys = torch.zeros((2, n_slots), dtype=torch.int64, device=self.device)     # uint64 bit patterns
-        self.slot_rows = torch.full((n_slots,), -1, dtype=torch.int32, device=self.device)
-        self.row_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # ordinary tensors even when the first forward runs under torch.inference_mode() (Lightning's test loop): an inference
+        # tensor could not be updated in place by a later call under no_grad
+        with torch.inference_mode(False):
+            self.table = (torch.zeros if zero else torch.empty)((self.capacity, self.dim), dtype=torch.float32, device=self.device)
+            self.slot_keys = torch.zeros((2, n_slots), dtype=torch.int64, device=self.device)     # uint64 bit patterns
+            self.slot_rows = torch.full((n_slots,), -1, dtype=torch.int32, device=self.device)
+            self.row_count = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.lookups = 0          # host-side counters (rows asked for / rows encoded), for the hit rate
         self.encoded = 0
 

@@ -279,3 +279,20 @@ def test_warming_the_cache_with_the_news_pool_makes_every_batch_a_hit():
         out = enc(b)
     assert enc._cache.encoded == before and torch.equal(out, ref)
 
+
+def test_cache_created_under_inference_mode_serves_no_grad_calls_too():
+    """Lightning's test loop runs under torch.inference_mode(); a later torch.no_grad() call (e.g. `warm_embedding_cache`) must be
+    able to update the same table in place — the cache's tensors are ordinary tensors whatever mode created them."""
+    cfg, enc = _text_encoder(seed=9)
+    enc.embedding_cache_rows = 128
+    ids, mask = synth_news_tokens(40, cfg, seed=31, max_len=24)
+    b1 = {"input_ids": torch.from_numpy(ids[:20]).to(DEV), "attention_mask": torch.from_numpy(mask[:20]).to(DEV)}
+    b2 = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    with torch.inference_mode():
+        first = enc(b1).clone()
+    with torch.no_grad():
+        second = enc(b2)
+    with torch.inference_mode():
+        third = enc(b2)
+    assert torch.equal(second[:20], first) and torch.equal(third, second) and enc._cache.encoded == 40
+
