@@ -1047,6 +1047,30 @@ struct Ctx {
 
 int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t cols, void* out, int64_t rows_out, const int* rv_dev,
                  int64_t rv_host, int64_t ks = 0);
+
+// Weight-gradient work on a SECOND stream (round 4).  The parameter gradients of a layer (4 weight-gradient GEMMs with their slice
+// reductions, 4 bias column sums, the operand conversions) are needed by nobody before the optimiser step, while the activation-
+// gradient chain runs launches that leave CUs idle (the N = H data-gradient GEMMs fill 183 of 256, the attention backward is
+// latency-bound).  Per device: one non-blocking stream, one "inputs are ready" event and one "done" event per group of a layer
+// (FFN2, FFN1, out-projection, Q|K|V); the main stream waits for a group's "done" right before it overwrites that group's input.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = false, tried = false;
+};
+SideStream& side_stream() {
+  static SideStream per_device[MAX_DEVICES];
+  SideStream& sd = per_device[current_device_slot()];
+  if (!sd.tried) {
+    sd.tried = true;
+    bool ok = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&sd.ready, hipEventDisableTiming) == hipSuccess;
+    for (int g = 0; ok && g < 4; ++g) ok = hipEventCreateWithFlags(&sd.done[g], hipEventDisableTiming) == hipSuccess;
+    sd.ok = ok;
+  }
+  return sd;
+}
+
 // The mode's 16-bit copy of weight matrix W [rows, cols] f32 (tr: of its transpose [cols, rows]) — from the caller's cache slot when
 // one was registered for it (filled here on first use), else converted into `scratch`.  wi: W's index in the weight table (-1: look it up).
 int weight16(Ctx& t, const float* W, int rows, int cols, bool tr, void* scratch, const void** out, int wi = -1) {
@@ -1704,10 +1728,67 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
   Ctx cc = t;
   cc.Mb = round_up(n_news, 256);
   cc.sv.m_total = sv.m_total + 1;
+  // the side context: same buffers, its own stream and its own scratch — operand conversions go to wk.a16 (nothing on the main
+  // stream touches it in a 16-bit backward), column-sum partials behind the LayerNorm backward's share of wk.part
+  const char* ws_env = getenv("MANNER_HIP_TRAIN_WGRAD_STREAM");          // A/B switch, read per call
+  const char* tr_env0 = getenv("MANNER_HIP_WGRAD_TR");
+  SideStream* sd = nullptr;
+  if (t.dt() != DT_F32 && !full && (!ws_env || atoi(ws_env) != 0) && (!tr_env0 || atoi(tr_env0) != 0) && cfg->hidden % 256 == 0 &&
+      cfg->intermediate % 256 == 0 && (size_t)LN_BWD_BLOCKS * H * 2 + (size_t)COLSUM_BLOCKS * (I > 3 * H ? I : 3 * H) <= (size_t)2 * LN_BWD_BLOCKS * (I > 3 * H ? I : 3 * H)) {
+    SideStream& cand = side_stream();
+    if (cand.ok) sd = &cand;
+  }
+  Ctx cs = t;
+  bool pending[4] = {false, false, false, false};
+  // on EVERY way out of this function the main stream is ordered behind whatever the side stream still has to do: the caller's
+  // stream-ordered allocator and the optimiser see the parameter gradients (and may reuse the buffers) only after that
+  struct SideJoin {
+    SideStream*& sd; bool (&pending)[4]; hipStream_t main;
+    ~SideJoin() {
+      if (!sd) return;
+      for (int g = 0; g < 4; ++g)
+        if (pending[g]) { (void)hipStreamWaitEvent(main, sd->done[g], 0); pending[g] = false; }
+    }
+  } side_join{sd, pending, s};
+  if (sd) {
+    cs.s = sd->s;
+    cs.wk.b16 = t.wk.a16;
+    cs.wk.a16 = nullptr;
+    cs.wk.part = t.wk.part + (size_t)2 * LN_BWD_BLOCKS * H;
+  }
+  // side_begin: the side stream continues behind everything enqueued on the main stream so far; side_end(g): group g is complete on
+  // the side stream; main_wait(g): the main stream does not overwrite group g's input before the group has read it
+  auto side_begin = [&]() -> int {
+    MANNER_HIP_TRY(hipEventRecord(sd->ready, s));
+    MANNER_HIP_TRY(hipStreamWaitEvent(sd->s, sd->ready, 0));
+    return MANNER_HIP_OK;
+  };
+  auto side_end = [&](int g) -> int {
+    MANNER_HIP_TRY(hipEventRecord(sd->done[g], sd->s));
+    pending[g] = true;
+    return MANNER_HIP_OK;
+  };
+  auto main_wait = [&](int g) -> int {
+    if (sd && pending[g]) {
+      MANNER_HIP_TRY(hipStreamWaitEvent(s, sd->done[g], 0));
+      pending[g] = false;
+    }
+    return MANNER_HIP_OK;
+  };
   auto layer_backward = [&](int l, bool compact) -> int {
     Ctx& c = compact ? cc : t;
+    const bool aside = sd != nullptr && !compact;              // this layer's parameter gradients go to the side stream
+    Ctx& w = aside ? cs : c;
     const int32_t* rowmap = compact ? sv.cu : nullptr;
     LayerSaved& L = sv.l[l];
+    // With the side stream every 16-bit gradient tensor a weight-gradient group reads has a buffer of its own (the second pair
+    // is carved from wk.tmp, which a 16-bit backward does not use), so that a group has a whole layer of main-stream work before
+    // its input is written again — by the SAME producer of the next layer, which is where the main stream waits for it:
+    //   d y2 -> h_dy2 (LN2 backward)   d proj -> h_dproj (LN1 backward)   d inter -> b_dinter (FFN2 data gradient)   d qkv -> b_dqkv (attention)
+    void* const h_dy2 = wk.h16b;
+    void* const h_dproj = sd ? static_cast<void*>(wk.tmp) : wk.h16b;
+    void* const b_dinter = wk.big16;
+    void* const b_dqkv = sd ? static_cast<void*>(reinterpret_cast<uint16_t*>(wk.tmp) + (size_t)m_bound * H) : wk.big16;
     const bool below = l > stop || emb_grads || grad_prefix;       // is d x_in needed?
     const bool mixed = t.dt() != DT_F32;
     // 16-bit modes: every GEMM-output gradient that is consumed only by GEMMs / column sums exists in the 16-bit type only —
@@ -1718,51 +1799,62 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     const float* dy2 = wk.tmp;                               // fp32 mode: d y2 / d proj in f32
     // LN2: dx -> d r2 (wk.dr); r2 = dropout(y2) + h1: d y2 = dropout(d r2), d h1 starts as d r2
     if (mixed) {
+      if ((rc = main_wait(0))) return rc;                      // h_dy2 still holds d y2 of the layer above for its FFN2 group
       if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B),
-                            make_drop(seed, layer_site(l, SITE_FFN), p_hidden), wk.h16b, rowmap))) return rc;
+                            make_drop(seed, layer_site(l, SITE_FFN), p_hidden), h_dy2, rowmap))) return rc;
     } else {
       if ((rc = ln_backward(c, wk.dx, L.r2, L.st2, t.lw(l, MANNER_HIP_WL_OLN_G), wk.dr, gl(l, MANNER_HIP_WL_OLN_G), gl(l, MANNER_HIP_WL_OLN_B)))) return rc;
       if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_FFN), p_hidden), nullptr, rowmap))) return rc;
     }
-    const void* dy2_any = mixed ? (const void*)wk.h16b : (const void*)dy2;
-    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(c, dy2_any, g16, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(c, dy2_any, g16, L.g, g16, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
+    const void* dy2_any = mixed ? (const void*)h_dy2 : (const void*)dy2;
+    const bool ff2_grads = gl(l, MANNER_HIP_WL_FF2_B) || gl(l, MANNER_HIP_WL_FF2_W);
+    if (aside && ff2_grads && (rc = side_begin())) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_B) && (rc = bias_grad(w, dy2_any, g16, H, gl(l, MANNER_HIP_WL_FF2_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF2_W) && (rc = linear_wgrad(w, dy2_any, g16, L.g, g16, gl(l, MANNER_HIP_WL_FF2_W), H, I, 0))) return rc;
+    if (aside && ff2_grads && (rc = side_end(0))) return rc;
     const void* dinter_any;
+    if ((rc = main_wait(1))) return rc;                        // b_dinter still holds d inter of the layer above for its FFN1 group
     if (mixed) {
       if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), c.Mb, I, H)) {                       // d inter = (d y2 . W2) * gelu'(inter): one launch
         const void* wt;
         if ((rc = weight16(c, t.lw(l, MANNER_HIP_WL_FF2_W), H, I, true, wk.b16, &wt))) return rc;
-        if ((rc = gemm_tn_gelu_grad(t.dt(), wk.h16b, wt, wk.zero, L.inter, wk.big16, c.Mb, I, H, c.sv.m_total, s))) return rc;
+        if ((rc = gemm_tn_gelu_grad(t.dt(), h_dy2, wt, wk.zero, L.inter, b_dinter, c.Mb, I, H, c.sv.m_total, s))) return rc;
       } else {
-        if ((rc = linear_dgrad(c, nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), wk.big16, H, I, wk.h16b, t.dt()))) return rc;          // d g (16-bit)
-        if ((rc = gelu16(c, L.inter, wk.big16, I, 1))) return rc;                                                         // d inter, in place
+        if ((rc = linear_dgrad(c, nullptr, t.lw(l, MANNER_HIP_WL_FF2_W), b_dinter, H, I, h_dy2, t.dt()))) return rc;          // d g (16-bit)
+        if ((rc = gelu16(c, L.inter, b_dinter, I, 1))) return rc;                                                         // d inter, in place
       }
-      dinter_any = wk.big16;
+      dinter_any = b_dinter;
     } else {
       if ((rc = linear_dgrad(c, dy2, t.lw(l, MANNER_HIP_WL_FF2_W), wk.dbig, H, I))) return rc;                           // d g
       hipLaunchKernelGGL(gelu_kernel, dim3(c.ew_grid(I)), dim3(256), 0, s, L.inter, wk.dbig, wk.dbig, I, c.sv.m_total, 1, Out16{nullptr, 0});   // d inter
       MANNER_LAUNCH_CHECK();
       dinter_any = wk.dbig;
     }
-    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(c, dinter_any, g16, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
-    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(c, dinter_any, g16, L.h1, DT_F32, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
+    const bool ff1_grads = gl(l, MANNER_HIP_WL_FF1_B) || gl(l, MANNER_HIP_WL_FF1_W);
+    if (aside && ff1_grads && (rc = side_begin())) return rc;
+    if (gl(l, MANNER_HIP_WL_FF1_B) && (rc = bias_grad(w, dinter_any, g16, I, gl(l, MANNER_HIP_WL_FF1_B)))) return rc;
+    if (gl(l, MANNER_HIP_WL_FF1_W) && (rc = linear_wgrad(w, dinter_any, g16, L.h1, DT_F32, gl(l, MANNER_HIP_WL_FF1_W), I, H, 1))) return rc;
+    if (aside && ff1_grads && (rc = side_end(1))) return rc;
     {
       bool fused = false;                                    // d h1 = d inter . W1 + d r2
-      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), mixed ? wk.dx : wk.tmp, I, H, mixed ? wk.big16 : nullptr,
+      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.dbig, t.lw(l, MANNER_HIP_WL_FF1_W), mixed ? wk.dx : wk.tmp, I, H, mixed ? b_dinter : nullptr,
                              DT_F32, mixed ? wk.dr : nullptr, &fused)))
         return rc;
       if (!fused && (rc = add_rows(c, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H))) return rc;
     }
     // LN1: d h1 -> d r1 (wk.dr); r1 = dropout(proj) + x_in
     if (mixed) {
+      if ((rc = main_wait(2))) return rc;                      // h_dproj still holds d proj of the layer above for its out-projection group
       if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B),
-                            make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), wk.h16b, rowmap))) return rc;
+                            make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), h_dproj, rowmap))) return rc;
     } else {
       if ((rc = ln_backward(c, wk.dx, L.r1, L.st1, t.lw(l, MANNER_HIP_WL_ALN_G), wk.dr, gl(l, MANNER_HIP_WL_ALN_G), gl(l, MANNER_HIP_WL_ALN_B)))) return rc;
       if ((rc = dropout_add(c, wk.dr, nullptr, wk.tmp, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr, rowmap))) return rc;    // d proj
     }
-    const void* dproj_any = mixed ? (const void*)wk.h16b : (const void*)wk.tmp;
-    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(c, dproj_any, g16, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
+    const void* dproj_any = mixed ? (const void*)h_dproj : (const void*)wk.tmp;
+    const bool ao_grads = gl(l, MANNER_HIP_WL_AO_B) || gl(l, MANNER_HIP_WL_AO_W);
+    if (aside && ao_grads && (rc = side_begin())) return rc;
+    if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(w, dproj_any, g16, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_AO_W)) {
       const float* ctx_rows = L.ctx;
       if (compact) {                                     // the [CLS] rows of ctx, gathered as in the forward
@@ -1770,32 +1862,34 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
         MANNER_LAUNCH_CHECK();
         ctx_rows = wk.dbig;
       }
-      if ((rc = linear_wgrad(c, dproj_any, g16, ctx_rows, DT_F32, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+      if ((rc = linear_wgrad(w, dproj_any, g16, ctx_rows, DT_F32, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
     }
+    if (aside && ao_grads && (rc = side_end(2))) return rc;
     const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
                        gl(l, MANNER_HIP_WL_K_B) || gl(l, MANNER_HIP_WL_V_B);
     if (!below && !qkv_w) return MANNER_HIP_OK;
     if (compact) {
       // d ctx of the [CLS] rows -> token rows (every other row of d ctx is zero)
-      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dqkv, H, H, mixed ? wk.h16b : nullptr))) return rc;
+      if ((rc = linear_dgrad(c, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dqkv, H, H, mixed ? h_dproj : nullptr))) return rc;
       MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
       hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dqkv, sv.cu, H, wk.dx, make_drop(0, 0, 0.f));
       MANNER_LAUNCH_CHECK();
-    } else if ((rc = linear_dgrad(t, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? wk.h16b : nullptr))) {   // d ctx
+    } else if ((rc = linear_dgrad(t, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? h_dproj : nullptr))) {   // d ctx
       return rc;
     }
     const Drop da = make_drop(seed, layer_site(l, SITE_ATTN), p_attn);
+    if ((rc = main_wait(3))) return rc;                        // b_dqkv / wk.dqkv still hold d qkv of the layer above for its Q|K|V group
     if (t.mfma_attn()) {
       // matrix-pipe backward: D = dctx . ctx and the 16-bit copy of dctx (wk.h16a is free in the backward), then d q and d k / d v
-      if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.big16, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
+      if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, b_dqkv, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
                                          (int)padded_len, da, m_bound, sv.m_total, s)))
         return rc;
     } else {
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
   do {                                                                                                                            \
     const dim3 ag((unsigned)(cfg->heads / HPB_), (unsigned)n_news);                                                               \
-    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da, t.o16(wk.big16), full ? sv.lens : nullptr);  \
-    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da, t.o16(wk.big16), full ? sv.lens : nullptr); \
+    hipLaunchKernelGGL((attn_train_bwd_q_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, wk.dsum, sv.cu, cfg->heads, H, da, t.o16(b_dqkv), full ? sv.lens : nullptr);  \
+    hipLaunchKernelGGL((attn_train_bwd_kv_kernel<AT_, HPB_>), ag, dim3(AT_), 0, s, L.qkv, wk.dx, L.ml, wk.dsum, wk.dqkv, sv.cu, cfg->heads, H, da, t.o16(b_dqkv), full ? sv.lens : nullptr); \
   } while (0)
     MANNER_ATTN_DISPATCH(padded_len, cfg->heads, MANNER_ATTN_BWD);
 #undef MANNER_ATTN_BWD
@@ -1806,13 +1900,16 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
       // slice partials write three destinations (round 4: 6 device copies per layer before)
       const SumDst db3{{gl(l, MANNER_HIP_WL_Q_B), gl(l, MANNER_HIP_WL_Q_B + 2), gl(l, MANNER_HIP_WL_Q_B + 4)}, H};
       const SumDst dw3{{gl(l, MANNER_HIP_WL_Q_W), gl(l, MANNER_HIP_WL_Q_W + 2), gl(l, MANNER_HIP_WL_Q_W + 4)}, H * H};
-      if ((db3.p[0] || db3.p[1] || db3.p[2]) && (rc = bias_grad(t, wk.dqkv, DT_F32, 3 * H, nullptr, &db3))) return rc;
+      Ctx& wq = sd ? cs : t;                                  // (the compact last layer's attention half runs on the token rows too)
+      if (sd && (rc = side_begin())) return rc;
+      if ((db3.p[0] || db3.p[1] || db3.p[2]) && (rc = bias_grad(wq, wk.dqkv, DT_F32, 3 * H, nullptr, &db3))) return rc;
       bool in_place = false;
-      if ((rc = linear_wgrad(t, mixed ? (const void*)wk.big16 : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3, &dw3, &in_place))) return rc;
+      if ((rc = linear_wgrad(wq, mixed ? (const void*)b_dqkv : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3, &dw3, &in_place))) return rc;
       if (!in_place)
         for (int k = 0; k < 3; ++k)
           if (gl(l, MANNER_HIP_WL_Q_W + 2 * k))
-            MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            MANNER_HIP_TRY(hipMemcpyAsync(gl(l, MANNER_HIP_WL_Q_W + 2 * k), wk.dw + (size_t)k * H * H, (size_t)H * H * sizeof(float), hipMemcpyDeviceToDevice, wq.s));
+      if (sd && (rc = side_end(3))) return rc;
     }
     if (!below) return MANNER_HIP_OK;
     // W^T of the packed Q | K | V weight: from the caller's cache for a frozen layer (then neither the pack nor the transpose runs)
@@ -1820,13 +1917,13 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     const bool qkv_t_cached = mixed && t.slot(2 * wiq + 1) && t.wc_valid[2 * wiq + 1];
     if (!qkv_t_cached && (rc = pack_qkv_weights(t, l))) return rc;
     if (compact) {                                       // d x_in = d qkv . W on every row, + d r1 on the [CLS] rows
-      if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.dx, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, nullptr, nullptr, wiq))) return rc;
+      if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, wk.dx, 3 * H, H, mixed ? b_dqkv : nullptr, DT_F32, nullptr, nullptr, wiq))) return rc;
       hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dr, sv.cu, H, wk.dx);
       MANNER_LAUNCH_CHECK();
       return MANNER_HIP_OK;
     }
     bool fused = false;                                  // d x_in = d qkv . W + d r1
-    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, mixed ? wk.dx : wk.tmp, 3 * H, H, mixed ? wk.big16 : nullptr, DT_F32, mixed ? wk.dr : nullptr, &fused, wiq)))
+    if ((rc = linear_dgrad(t, wk.dqkv, wk.wcat, mixed ? wk.dx : wk.tmp, 3 * H, H, mixed ? b_dqkv : nullptr, DT_F32, mixed ? wk.dr : nullptr, &fused, wiq)))
       return rc;
     return fused ? MANNER_HIP_OK : add_rows(t, mixed ? wk.dx : wk.tmp, wk.dr, wk.dx, H);
   };

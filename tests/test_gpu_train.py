@@ -368,6 +368,49 @@ def test_gelu_inside_the_ffn_gemms_tracks_the_separate_kernels(precision, monkey
     print(f"{precision}: outputs rel {e_out:.2e}; worst gradient tensor {worst[2]}: rel-to-max {worst[0]:.3e}, cosine {worst[1]:.7f}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("arch,n_news,max_len", [("mini-roberta-large", 40, 48), ("bert-base-uncased", 260, 64)])
+def test_weight_gradients_on_the_side_stream_are_bit_identical(precision, arch, n_news, max_len, monkeypatch):
+    """Round 4: in the 16-bit modes the parameter gradients of a layer (weight-gradient GEMMs, slice reductions, bias column sums,
+    operand conversions) run on a second HIP stream while the activation-gradient chain goes on; events order every reuse of a
+    buffer.  Same kernels, same summation orders: every gradient is equal to the BIT with MANNER_HIP_TRAIN_WGRAD_STREAM=0 (one
+    stream) — three overlapped runs, so that a missing wait would have to lose its race three times to hide; trainable embeddings
+    (the chain runs through all layers) and frozen ones; the embedding tables' own gradients are atomically scatter-added and keep
+    their rounding tolerance."""
+    import dataclasses
+    cfg = PRESETS[arch] if arch.startswith("mini") else dataclasses.replace(PRESETS[arch], layers=3)
+    w = make_plm_weights(cfg, seed=85, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=85, max_len=max_len)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(10).standard_normal((n_news, cfg.hidden)).astype(np.float32)).to(DEV)
+
+    def run(freeze_emb):
+        params = {k: torch.from_numpy(v).to(DEV).requires_grad_(not (freeze_emb and k.startswith("embeddings."))) for k, v in w.items()}
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=7)
+        (out * R).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().cpu().numpy(), _grads(params)
+
+    for freeze_emb in (False, True):
+        monkeypatch.setenv("MANNER_HIP_TRAIN_WGRAD_STREAM", "0")
+        ref_out, ref_g = run(freeze_emb)
+        monkeypatch.delenv("MANNER_HIP_TRAIN_WGRAD_STREAM")
+        for attempt in range(3):
+            out, g = run(freeze_emb)
+            assert np.array_equal(out, ref_out)
+            n_checked = 0
+            for k in ref_g:
+                assert (g[k] is None) == (ref_g[k] is None), k
+                if g[k] is None:
+                    continue
+                if k.startswith("embeddings.") and "LayerNorm" not in k:
+                    assert np.abs(g[k] - ref_g[k]).max() <= 1e-5 * max(np.abs(ref_g[k]).max(), 1e-6), (attempt, k)
+                else:
+                    assert np.array_equal(g[k], ref_g[k]), (attempt, freeze_emb, k)
+                    n_checked += 1
+            assert n_checked >= 30
+
+
 def test_train_from_cached_frozen_prefix():
     """Embeddings and layer 0 frozen: the frozen prefix comes from the inference engine (encode_hidden) and training
     starts at layer 1 — same outputs and layer-1 gradients as the full path, and grad_prefix matches the oracle's."""
