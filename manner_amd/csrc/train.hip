@@ -1063,7 +1063,11 @@ SideStream& side_stream() {
   SideStream& sd = per_device[current_device_slot()];
   if (!sd.tried) {
     sd.tried = true;
-    bool ok = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+    // LOWEST priority: the side stream should take the CUs the chain leaves idle, not compete for them (measured, default step of
+    // bench.py's training leg: lowest 14.10 ms, default priority 14.38, highest 14.54; one stream 14.79)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    bool ok = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, least) == hipSuccess &&
               hipEventCreateWithFlags(&sd.ready, hipEventDisableTiming) == hipSuccess;
     for (int g = 0; ok && g < 4; ++g) ok = hipEventCreateWithFlags(&sd.done[g], hipEventDisableTiming) == hipSuccess;
     sd.ok = ok;
