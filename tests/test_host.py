@@ -600,3 +600,90 @@ def test_impression_blocks_are_balanced_by_occurrences():
     for w in (2, 3, 4):
         sh = balanced_impression_shards(np.array([0, 1, 2, 3, 4]), np.array([0, 300, 302, 304, 306]), w)
         assert all(b > a for a, b in sh) and sh[0][0] == 0 and sh[-1][1] == 4 and all(x[1] == y[0] for x, y in zip(sh, sh[1:])), (w, sh)
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("manner_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_final_line_is_compact_strict_json(tmp_path, capsys):
+    """The driver parses bench.py's LAST stdout line (round 4's 26 KB line left its record with `parsed: null`): with EVERY leg present
+    and bloated — long prose, whole sweeps, NaN / Infinity — the line stays below 8 KB, is strict JSON, carries the contract keys and
+    the three objects, and the complete record goes to the side file instead."""
+    bench = _load_bench()
+    prose = "a very long explanation of what this figure means and how it was obtained; " * 12
+    sweep = [{"impression": i, "hip_top11": [[j, 1000 + j, 700.0 + j / 7, 700.0 + j / 9, 700.0 + j / 11] for j in range(11)],
+              "oracle_top11": [[j, 1000 + j, 700.0 + j / 7, 700.0 + j / 9, 700.0 + j / 11] for j in range(11)]} for i in range(3)]
+    modes = {m: {"score_max_abs_err": 1e-4 / 3, "top10_identical": 63, "top10_identical_frac": 63 / 64, "top10_valid_order_of_oracle_scores_frac": 1.0,
+                 "ndcg10_delta": float("nan") if m == "bf16" else 6.4e-9, "differing_impressions": sweep} for m in ("fp32", "f16x3", "f16", "bf16")}
+    agree = {"impressions": 73152, "top10_identical_frac": 0.7456, "ndcg10_delta": 6.5e-5, "score_max_abs_err": 0.0318, "what": prose}
+    result = {
+        "metric": "candidate news encoded+scored/sec", "value": 43848.81234567, "unit": "candidates/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+        "ms_per_step": 209.6031234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": prose, "baseline_config": 1, "modules": 1, "ensemble_weights": [], "impressions_per_step_per_gpu": 256,
+                   "length_profile": "title_abstract", "seeded_weights_std": 0.02, "parallelism": "dp1 (impressions sharded, no collective)"},
+        "news_encoded_per_s": 75341.2, "tokens_per_s": 5.6e6, "encoder_tflops": 912.2, "encoder_mfma_frac": 0.3649, "ndcg10_last_step": 0.26,
+        "world_size_seen": 1, "dist_backend": None, "launcher": None,
+        "bf16_mode": {"what": prose, "value": 45157.3, "ms_per_step": 203.5, "news_encoded_per_s": 77589.5, "encoder_mfma_frac": 0.3758},
+        "parity_grade_mode": {"dtype": "f16x3", "value": 14391.0, "unit": "candidates/s", "ms_per_step": 638.7, "news_encoded_per_s": 24732.9, "steps": 20, "tag": prose},
+        "pcie_inclusive_rank0": {"what": prose, "candidates_per_s": 43392.4, "ms_per_step": 211.8, "h2d_MB_per_step": 12.0},
+        "kernels": {f"kernel_{i}": {"ms_total": 1.0 + i, "launches": 100, "avg_us": 10.0 + i, "flops_per_launch": 3e11, "tflops": 900.0} for i in range(12)},
+        "roofline": {"kernel": "gemm_ffn1 (gemm_tn_x16_kernel)", "bound": "mfma", "achieved": 915.854, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.366342,
+                     "traffic": 986080000.0, "traffic_source": prose, "mfma_only_ceiling_tflops": 2040.0, "avg_launch_us": 328.149, "flops_per_launch": 3.00536e11},
+        "collate": {"ms_per_batch": 0.21, "note": prose, "large_batch": {"ms": 1.0}},
+        "table_mode": {"what": prose, "candidates_per_s": 3.0e6, "news_encoded_per_s": 75813.7, "scorer_pairs_per_s": 2.2e9, "scorer_kernel_ms_rank0": 0.71,
+                       "allgather_ms": 0.03, "allgather_exchange": "collective", "allgather_what": prose, "scorer_note": prose, "encode_ms": 860.5, "score_ms": 1.18,
+                       "ndcg10": 0.2744, "allgather_GBps_per_rank": float("inf"), "allgather_frac_of_xgmi": 0.31, "scorer_f16_table": {"what": prose, "plain": agree, "centred": agree},
+                       "mesh_exchange": {"exchange": "mesh", "tables_identical": True, "standalone_ms": 1.1, "standalone_frac_of_xgmi": 0.4, "what": prose}},
+        "parity_at_scale": {"what": prose, "hf_init_weights_std0.02": {"f16": agree, "bf16": agree, "f16x3": agree}, "spread_weights_std0.05": {"f16": agree, "bf16": agree}},
+        "parity_mode": {"dtype": "fp32", "news_encoded_per_s": 9898.9, "what": prose, "f16x3_news_encoded_per_s": 24732.9},
+        "small_ops": {k: {"ms": 0.4, "GB/s": 1500.0, "frac_of_8TBps": 0.19, "bound": prose, "shape": {"B": 4096}} for k in ("additive_pool", "dot", "zscore_fuse", "to_dense")},
+        "cpu_baseline": {"value": 28.51, "unit": "candidates/s", "cores": 16, "kind": "port", "cpu_model": "AMD EPYC 9575F 64-Core Processor",
+                         "cores_how": prose, "runs_s": [7.75, 8.16, 8.58], "sample": prose},
+        "parity": {**modes, "against_float64_oracle": {"impressions": 4, "oracle_f32_max_abs_err": 2.3e-4, "hip_fp32_max_abs_err": 1.3e-4, "hip_f16x3_max_abs_err": 1.2e-4, "what": prose},
+                   "score_abs_scale": 776.8, "impressions": 64, "candidates": 2088, "repeated_candidates_in_sample": 0, "oracle_s": 63.6, "what": prose},
+        "train_mode": {"what": prose, **{v: {"ms_per_step": 14.6, "peak_GB": 23.1, "frac_of_mfma_peak": 0.168, "step_ms_each": [14.6] * 5}
+                                         for v in ("reference_default_embeddings_trainable", "embeddings_frozen_cached_prefix", "embeddings_frozen_prefix_cache_across_steps")}},
+        "dropin": {"what": prose, **{f"B{b}_{m}": {"ms_per_step": 8.65, "enqueue_ms": 3.0} for b in (8, 64) for m in ("eval", "train")},
+                   "B8_eval_embedding_cache": {"what": prose, "note": prose, "cold_whole_sweep": {"ms_per_step": 14.2, "hit_rate": 0.81}}},
+    }
+
+    class Args:
+        precision = "f16"
+        full_json = str(tmp_path / "bench_full.json")
+
+    bench.emit(result, Args)
+    out = capsys.readouterr().out.splitlines()
+    line = out[-1]
+    assert len(out) == 1 and len(line.encode()) < 8192, len(line)
+
+    def reject(name):
+        raise ValueError(name)
+
+    j = json.loads(line, parse_constant=reject)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["value"] == pytest.approx(43848.8, rel=1e-5) and j["vs_baseline"] is None and j["config"]["baseline_config"] == 1
+    assert set(j["roofline"]) >= {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "flops_per_launch", "encoder_mfma_frac"}
+    assert j["roofline"]["frac"] == pytest.approx(0.366342) and j["roofline"]["encoder_mfma_frac"] == {"f16": 0.3649, "bf16": 0.3758}
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "cpu_model", "runs_s", "sample"} and j["cpu_baseline"]["kind"] == "port"
+    pg = j["config"]["parity_grade"]
+    assert pg["dtype"] == "f16x3" and pg["candidates_per_s"] == 14391.0 and pg["top10_identical"] == 63 and pg["of_impressions"] == 64 and pg["timed_steps"] == 20
+    assert j["config"]["parity_vs_oracle"]["bf16"].get("ndcg10_delta") is None            # NaN never reaches the line
+    assert all(len(v) <= 120 for v in (j["config"]["workload"], j["cpu_baseline"]["sample"], j["roofline"]["traffic_source"]))
+    assert j["legs"]["dropin_ms_per_step"]["B8_eval"] == 8.65 and j["legs"]["train_ms_per_step"]["reference_default_embeddings_trainable"] == 14.6
+    # the complete record is in the side file, prose and sweeps included
+    full = json.loads((tmp_path / "bench_full.json").read_text())
+    assert full["parity"]["fp32"]["differing_impressions"][0]["hip_top11"][0][1] == 1000 and full["dropin"]["what"] == prose
+    assert j["full_record"].endswith("bench_full.json")
+    # a result that is far too large for the optional parts still yields a line below the limit with the three objects
+    result["kernels"] = {f"kernel_with_a_long_name_{i:04d}": {"avg_us": float(i)} for i in range(600)}
+    line2 = bench.compact_line(result)
+    j2 = json.loads(line2, parse_constant=reject)
+    assert len(line2.encode()) < 8192 and {"config", "roofline", "cpu_baseline"} <= set(j2) and "kernel_avg_us" not in j2.get("legs", {})
