@@ -872,32 +872,47 @@ struct DlnAux {
   const float* aux32;
   // > 0 (and col_group == 0): this launch covers only the row panels of split_panels(); a tail launch of the 128x128 kernel follows
   int split_cus;
+  // Row-panel height (round 5): 0 = the kernel picks 256 or 192 rows per tile from the DEVICE token count (panel_rows()), 1 = always
+  // 256, 2 = always 192 (A/B: MANNER_HIP_GEMM_PANEL=256|192).  x_rows = rows the X buffer holds (a multiple of 8): a 192-row tile's
+  // last panel may reach past it, so its 8-row DMA pieces are clamped to the buffer (rows >= *m_total are computed and never stored).
+  int panel_mode;
+  int64_t x_rows;
 };
 
-template <typename TE, typename TOut, int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
-    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
-    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
-    int n_tiles, DlnAux dln) {
+// Wave quantisation of a persistent launch (round 5).  tiles = ceil(M / rows) * n_tiles on `cus` workgroups last ceil(tiles / cus)
+// whole tile times, so 61 row panels x N = 768 (183 tiles of 256 rows) are ONE round with 73 of 256 CUs idle — while the same rows
+// as 82 panels of 192 rows are 246 tiles: one round of three-quarter tiles.  A row's result does not depend on the panel height (per
+// output element the same sequence of matrix instructions over K), so the choice is free of numerical consequences: both bodies give
+// the same BITS (tests/test_gpu_parity.py holds them to torch.equal).  A 192-row tile costs ~0.8 of a 256-row tile (the weight half
+// of its DMA and LDS traffic does not shrink); 192 wins when its rounds x 0.8 undercut the 256-row rounds by at least 3 %.
+__host__ __device__ inline int panel_rows(int M, int n_tiles, int cus, int mode) {
+  if (mode == 1) return 256;
+  if (mode == 2) return 192;
+  const int t256 = ((M + 255) / 256) * n_tiles, t192 = ((M + 191) / 192) * n_tiles;
+  const int r256 = (t256 + cus - 1) / cus, r192 = (t192 + cus - 1) / cus;
+  return r192 * 80 < r256 * 97 ? 192 : 256;
+}
+
+// MBT = 16-row MFMA token blocks per wave: 8 (256-row tile, wave tile 128 x 64) or 6 (192-row tile, wave tile 96 x 64).  The weight
+// half of a tile (256 columns: 4 waves x 64) is the same for both; the activation stage keeps its 32 KiB stride and holds 24 KiB.
+template <typename TE, typename TOut, int EPI, int ABL, int MBT>
+__device__ __forceinline__ void gemm_tn_x16_body(
+    char* lds, const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, int M, int n_tiles, const DlnAux& dln) {
   typedef TE TIn;                               // bf16_t or f16_t (E16<TE>: vector types and the MFMA of the type)
   typedef typename E16<TE>::v8 e16x8;
   typedef typename E16<TE>::v4 e16x4;
   constexpr int EPC = 8, BK = 64;
-  // 2 weight stages [0, 64 KiB) + 3 activation stages [64, 160 KiB): the activation tile's first touch
-  // comes from HBM (~2 us), so it is prefetched TWO K-steps ahead; weights are L2-resident (one ahead)
-  __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
+  constexpr int TM = 32 * MBT;                  // rows of a tile
+  constexpr int HB = MBT / 2;                   // token blocks per m-half of a K-step chunk (and DMA piece pairs of an activation wave)
+  constexpr int WROWS = TM / 2;                 // rows of a wave's tile
+  static_assert(MBT == 8 || MBT == 6, "row panels of 256 or 192 rows");
   constexpr int XB = 2 * G_OP_BYTES;                                        // base of the activation ring
 
-  if constexpr (EPI == EPI_BIAS) {
-    X += (size_t)blockIdx.y * dln.batch_x;
-    W += (size_t)blockIdx.y * dln.batch_w;
-    Y += (size_t)blockIdx.y * dln.batch_y;
-  }
   const int G = gridDim.x, b = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
   const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int M = *m_total;
-  const int m_tiles = dln.split_cus > 0 ? split_panels((M + G_BM - 1) / G_BM, n_tiles, dln.split_cus) : (M + G_BM - 1) / G_BM;
+  const int m_tiles = (MBT == 8 && dln.split_cus > 0) ? split_panels((M + TM - 1) / TM, n_tiles, dln.split_cus) : (M + TM - 1) / TM;
   const int valid_tiles = m_tiles * n_tiles;
   // Tile order: column tiles are walked in groups of `gsz`; within a group the order is row-panel-major.  One pass
   // over the rows then touches only gsz weight tiles (gsz * 256 * K * 2 bytes), which stay resident in the XCD's 4 MB
@@ -922,58 +937,69 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   const int kl15 = lane & 15, klq = lane >> 4;        // K-loop copies (the epilogue recomputes its own)
   const int kwn = wave & 3, kwm = wave >> 2;
 
-  // DMA: waves 0-3 bring the weight tile, 4-7 the activation tile, 8 pieces (64 rows) each
+  // DMA: waves 0-3 bring the weight tile (8 pieces = 64 rows each), 4-7 the activation tile (MBT pieces = TM / 4 rows each)
   const bool is_w = wave < 4;
-  const int prow0 = 64 * (wave & 3);
+  const int prow0 = is_w ? 64 * (wave & 3) : (TM / 4) * (wave & 3);
   const int ldst0 = (is_w ? 0 : XB) + prow0 * ROW_BYTES;
   const int lrow = lane >> 3;
   int voff[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par)
     voff[par] = lrow * K + (((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * EPC);
-  auto tile_src = [&](int tile) -> const TIn* {
+  // a tile operand as this wave sees it: first row of its pieces and — 192-row tiles only — the largest row offset at which an
+  // 8-row piece still lies inside the X buffer (the last panel may reach past x_rows; W tiles and 256-row panels never do)
+  struct Src { const TIn* p; int lim; };
+  auto tile_src = [&](int tile) -> Src {
     int mt_, nt_;
     decode(tile, mt_, nt_);
-    return is_w ? W + (size_t)(nt_ * G_BN + prow0) * K : X + (size_t)(mt_ * G_BM + prow0) * K;
+    if (is_w) return Src{W + (size_t)(nt_ * G_BN + prow0) * K, 64};
+    if constexpr (MBT == 8) {
+      return Src{X + (size_t)(mt_ * TM + prow0) * K, 64};
+    } else {
+      const int last = (int)dln.x_rows - 8;
+      const int r0 = min(mt_ * TM + prow0, last);
+      return Src{X + (size_t)r0 * K, min(last - r0, 64)};
+    }
   };
-  auto issue2 = [&](int buf, const TIn* gsrc, int k0, int pair) {
+  auto issue2 = [&](int buf, const Src& gsrc, int k0, int pair) {
     char* base = lds + buf * G_OP_BYTES + ldst0;          // buf: weight stage 0..1 / activation stage 0..2
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int i = 2 * pair + par;
+      const int ro = MBT == 8 ? 8 * i : min(8 * i, gsrc.lim);
       if (ABL == 6 && !is_w)
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]), LDS_PTR(base + i * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc.p + (size_t)ro * K + k0 + voff[par]), LDS_PTR(base + i * 1024), 16, 0, 2);
       else
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + (size_t)(8 * i) * K + k0 + voff[par]),
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc.p + (size_t)ro * K + k0 + voff[par]),
                                          LDS_PTR(base + i * 1024), 16, 0, 0);
     }
   };
 
   const int swz = (kl15 >> 1) & 7;
   const int woff = (kwn * 64 + kl15) * ROW_BYTES;
-  const int xoff = (kwm * 128 + kl15) * ROW_BYTES;
+  const int xoff = (kwm * WROWS + kl15) * ROW_BYTES;
   auto read_w = [&](const char* base, int s2, e16x8 (&wf)[4]) {
     const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const e16x8*>(base + woff + a * 16 * ROW_BYTES + coff);
   };
-  auto read_x = [&](const char* base, int s2, int half, e16x8 (&xf)[4]) {
+  auto read_x = [&](const char* base, int s2, int half, e16x8 (&xf)[HB]) {
     const int coff = ((4 * s2 + klq) ^ swz) << 4;
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
-      xf[bb] = *reinterpret_cast<const e16x8*>(base + xoff + (4 * half + bb) * 16 * ROW_BYTES + coff);
+    for (int bb = 0; bb < HB; ++bb)
+      xf[bb] = *reinterpret_cast<const e16x8*>(base + xoff + (HB * half + bb) * 16 * ROW_BYTES + coff);
   };
 
-  f32x4 acc[4][8];
-  auto mma16 = [&](const e16x8 (&wf)[4], const e16x8 (&xf)[4], int half) {
+  f32x4 acc[4][MBT];
+  auto mma16 = [&](const e16x8 (&wf)[4], const e16x8 (&xf)[HB], int half) {
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
+    for (int bb = 0; bb < HB; ++bb)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
-        acc[a][4 * half + bb] = E16<TE>::mfma16(wf[a], xf[bb], acc[a][4 * half + bb]);
+        acc[a][HB * half + bb] = E16<TE>::mfma16(wf[a], xf[bb], acc[a][HB * half + bb]);
   };
 
-  e16x8 w0[4], w1[4], xa[4], xb[4];
+  e16x8 w0[4], w1[4], xa[HB], xb[HB];
   // DMA issue is STAGGERED between the two waves of a SIMD (waves w and w+4): an LDS-DMA piece costs the
   // issuing wave ~60-100 cycles, 8 pieces per K-step; if both partners issued in the same chunk neither
   // could feed the matrix pipe meanwhile.  Waves 0-3 (weight tile) issue all 8 pieces of step k+2 in
@@ -981,14 +1007,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   // of step k+1 in chunk 0; each half has >= 2.5 chunks to land before the vmcnt(0) of the sync.
   // MODE 0: steady state; 1: second-to-last step (chunk 3 prefetches K-step 0 of the NEXT tile instead of
   // step k+2); 2: last step (chunk 0 prefetches the activation half of the next tile's step 0).
-  auto issue_all = [&](int buf, const TIn* src, int k0) {
+  auto issue_all = [&](int buf, const Src& src, int k0) {
 #pragma unroll
-    for (int pair = 0; pair < 4; ++pair) issue2(buf, src, k0, pair);
+    for (int pair = 0; pair < 4; ++pair)
+      if (MBT == 8 || pair < HB || is_w) issue2(buf, src, k0, pair);
   };
   // xs = activation stage of this K-step (ring of 3, continuous across tiles); its successor holds the
   // next step (already requested), the one after receives, in chunk 0, the step TWO ahead:
   // MODE 0: step k+2 of this tile; MODE 1 (k = nk-2): step 0 of the next tile; MODE 2 (k = nk-1): its step 1.
-  auto kstep = [&](int cur, int xs, const TIn* gsrc, int k1, int k2, const TIn* gnext, bool has_next, auto mode_tag) {
+  auto kstep = [&](int cur, int xs, const Src& gsrc, int k1, int k2, const Src& gnext, bool has_next, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     const char* wbase = lds + cur * G_OP_BYTES;
     const char* wnxt = lds + (cur ^ 1) * G_OP_BYTES;
@@ -1023,7 +1050,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     if (MODE <= 1) {
       // (the last tile's second-to-last step has no younger DMA behind the pieces the last step reads: wait for all)
       if (is_w || (MODE == 1 && !has_next)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if constexpr (MBT == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // an activation wave's pieces per K-step
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1049,7 +1077,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   constexpr int ROWS_PER_INST = 64 / CHUNKS;
   const int nk = K / BK;
 
-  const TIn* gsrc = tile_src(t);
+  Src gsrc = tile_src(t);
   issue_all(0, gsrc, 0);             // K-step 0: weight stage 0 / activation stage 0
   if (!is_w) issue_all(1, gsrc, BK); // activations of K-step 1 (nk >= 2)
   int buf = 0;                       // weight stage that holds K-step 0 of the current tile
@@ -1060,19 +1088,21 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     decode(t, mt, nt);
     const int tn = t + G;
     const bool has_next = tn < valid_tiles;
-    const TIn* gnext = tile_src(has_next ? tn : t);
+    const Src gnext = tile_src(has_next ? tn : t);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int bb = 0; bb < 8; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int bb = 0; bb < MBT; ++bb) acc[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // tile prologue: K-step 0 has landed (issued one epilogue ago; the previous tile's stores may fly on)
     if (first) {
       if (is_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step 1's activations may still fly
+      else if constexpr (MBT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step 1's activations may still fly
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else if (ABL == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (sizeof(TOut) == 2) {                       // every bf16 epilogue ends with its 16 row stores
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (sizeof(TOut) == 2) {                       // every 16-bit epilogue ends with its 2 * MBT row stores
+      if constexpr (MBT == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // residual variant: the last half slab's 4 stores
     }
@@ -1105,12 +1135,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
       char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;       // 32 rows x 64 bf16, XOR-swizzled chunks
       const int nbase = nt * G_BN + wn * 64;
-      const int mrow0 = mt * G_BM + wm * 128;
+      const int mrow0 = mt * TM + wm * WROWS;
       if (ABL == 1) {                                  // lab: main loop only
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int bb = 0; bb < 8; ++bb) asm volatile("" ::"v"(acc[a][bb]));
+          for (int bb = 0; bb < MBT; ++bb) asm volatile("" ::"v"(acc[a][bb]));
       } else {
         f32x4 bv[4], g4[4];
 #pragma unroll
@@ -1125,11 +1155,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         char* rslab1 = lds + last * G_OP_BYTES + ew * 4096;           // the weight stage of the last K-step is free too
         const int rrow0 = el >> 3, rsl = el & 7;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {                 // two halves of 4 token blocks (64 rows = two slabs); keeping
-          f32x4 rawres[2][4];                            // more loads in flight (all 16, or half 1 under half 0's
-          float2 ms[4];                                  // arithmetic) measured 15 % slower per tile
+        for (int hb = 0; hb < (MBT + 3) / 4; ++hb) {     // halves of 4 token blocks (64 rows = two slabs; a 192-row tile's
+          const int nsb = MBT / 2 - 2 * hb >= 2 ? 2 : 1; // second half has one: 32 rows); keeping more loads in flight (all 16,
+          const int nb4 = 2 * nsb;                       // or half 1 under half 0's arithmetic) measured 15 % slower per tile
+          f32x4 rawres[2][4];
+          float2 ms[4];
 #pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
+          for (int sb = 0; sb < nsb; ++sb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int row = 8 * q + rrow0;
@@ -1137,9 +1169,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
               rawres[sb][q] = ABL == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R + (size_t)m * N + nbase + 8 * (rsl ^ (row & 7)));
             }
 #pragma unroll
-          for (int b4 = 0; b4 < 4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
+          for (int b4 = 0; b4 < nb4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
 #pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
+          for (int sb = 0; sb < nsb; ++sb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int row = 8 * q + rrow0;
@@ -1148,7 +1180,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           __builtin_amdgcn_wave_barrier();
           e16x4 res[4][4];
 #pragma unroll
-          for (int b4 = 0; b4 < 4; ++b4) {
+          for (int b4 = 0; b4 < nb4; ++b4) {
             const int row = 16 * (b4 & 1) + l15;
             const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
 #pragma unroll
@@ -1159,7 +1191,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
           }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int b4 = 0; b4 < 4; ++b4) {
+          for (int b4 = 0; b4 < nb4; ++b4) {
             const int bb = 4 * hb + b4;
             const float rs = ms[b4].y, nm = -ms[b4].x * ms[b4].y;
             float p1 = 0.f, p2 = 0.f;
@@ -1184,7 +1216,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       if (ABL != 1) {
         const int row0 = el >> 3, sl = el & 7;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MBT / 2; ++j) {
 #pragma unroll
           for (int b2 = 0; b2 < 2; ++b2) {
             const int row = 16 * b2 + l15;
@@ -1232,18 +1264,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     constexpr bool SPLIT = EPI == EPI_BIAS_GELU_SPLIT3;              // 16-bit [hi | hi | lo] output rows of 3 N elements
     const size_t ldy = SPLIT ? (size_t)3 * N : (size_t)N;
     f32x4 cv[NORM ? 4 : 1];
-    float2 ms[NORM ? 8 : 1];
+    float2 ms[NORM ? MBT : 1];
+    const int mrow0 = mt * TM + wm * WROWS;            // first row of this wave's tile
     if constexpr (NORM) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) cv[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
 #pragma unroll
-      for (int bb = 0; bb < 8; ++bb) ms[bb] = dln.mr[min(mt * G_BM + wm * 128 + 16 * bb + l15, M - 1)];
+      for (int bb = 0; bb < MBT; ++bb) ms[bb] = dln.mr[min(mrow0 + 16 * bb + l15, M - 1)];
     }
     constexpr int SLAB_ROWS = 4096 / OUT_ROW;          // 32 tokens (bf16) / 16 tokens (f32) per slab
     constexpr int MB = SLAB_ROWS / 16;                 // MFMA token blocks per slab
     constexpr int SQ = SLAB_ROWS / ROWS_PER_INST;      // row-contiguous 16-byte instructions per slab (4)
 #pragma unroll
-    for (int j = 0; j < 128 / SLAB_ROWS; ++j) {
+    for (int j = 0; j < WROWS / SLAB_ROWS; ++j) {
 #pragma unroll
       for (int b2 = 0; b2 < MB; ++b2) {
         const int row = 16 * b2 + l15;
@@ -1286,7 +1319,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
           const int c = sl ^ (row & (CHUNKS - 1));
-          const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
+          const int m = mrow0 + SLAB_ROWS * j + row;
           const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
           if (m < M) {
             TOut* dst = Y + (size_t)m * ldy + nbase + c * OPC;
@@ -1311,7 +1344,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
         for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
           const int c = sl ^ (row & (CHUNKS - 1));
-          const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
+          const int m = mrow0 + SLAB_ROWS * j + row;
           const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
           if (m < M) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + 2 * (size_t)N + nbase + c * OPC));
         }
@@ -1324,7 +1357,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
+          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
           const size_t idx = (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC;
           if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const e16x4*>(R + idx);
           else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
@@ -1335,7 +1368,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
           const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mt * G_BM + wm * 128 + SLAB_ROWS * j + row, M - 1);
+          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
           const f32x4* ip = reinterpret_cast<const f32x4*>(dln.aux32 + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
           pre[q][0] = ip[0];
           pre[q][1] = ip[1];
@@ -1345,7 +1378,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
       for (int q = 0; q < SQ; ++q) {
         const int row = q * ROWS_PER_INST + row0;
         const int c = sl ^ (row & (CHUNKS - 1));
-        const int m = mt * G_BM + wm * 128 + SLAB_ROWS * j + row;
+        const int m = mrow0 + SLAB_ROWS * j + row;
         f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
         if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
         if constexpr (EPI == EPI_GELU_GRAD) {
@@ -1389,37 +1422,75 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
   }
 }
 
+// PANELS = true: the workgroup-uniform choice between the 256-row and the 192-row body (panel_rows() of the device token count);
+// false (lab builds, ABL != 0): the 256-row body only.
+template <typename TE, typename TOut, int EPI, int ABL = 0, bool PANELS = (ABL == 0)>
+__global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
+    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles, DlnAux dln) {
+  // 2 weight stages [0, 64 KiB) + 3 activation stages [64, 160 KiB): the activation tile's first touch
+  // comes from HBM (~2 us), so it is prefetched TWO K-steps ahead; weights are L2-resident (one ahead)
+  __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
+  if constexpr (EPI == EPI_BIAS) {
+    X += (size_t)blockIdx.y * dln.batch_x;
+    W += (size_t)blockIdx.y * dln.batch_w;
+    Y += (size_t)blockIdx.y * dln.batch_y;
+  }
+  const int M = *m_total;
+  if constexpr (PANELS) {
+    if (panel_rows(M, n_tiles, (int)gridDim.x, dln.panel_mode) == 192) {
+      gemm_tn_x16_body<TE, TOut, EPI, ABL, 6>(lds, X, W, bias, R, Y, N, K, M, n_tiles, dln);
+      return;
+    }
+  }
+  gemm_tn_x16_body<TE, TOut, EPI, ABL, 8>(lds, X, W, bias, R, Y, N, K, M, n_tiles, dln);
+}
+
+// Persistent grid of an x16 launch and the panel fields of its DlnAux: one workgroup per CU (160 KiB LDS each), fewer only when even
+// the finer (192-row) tiling of the host's row bound has fewer tiles.  MANNER_HIP_GEMM_PANEL=256|192 pins the panel height (A/B; read
+// per launch: the tests flip it).
+static int x16_grid(int64_t m_bound, int n_tiles, DlnAux& aux, dim3& g) {
+  const int64_t tiles = ((m_bound + 191) / 192) * n_tiles;
+  if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
+  const int n_cus = device_cus();
+  g = dim3((unsigned)(tiles < n_cus ? tiles : n_cus));
+  const char* e = getenv("MANNER_HIP_GEMM_PANEL");
+  aux.panel_mode = e ? (atoi(e) == 256 ? 1 : atoi(e) == 192 ? 2 : 0) : 0;
+  aux.x_rows = m_bound;
+  return MANNER_HIP_OK;
+}
+
 template <typename TE, typename TOut>
 int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
   const int n_tiles = N / G_BN;
-  const int64_t tiles = (m_bound / G_BM) * n_tiles;
-  if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
-  const int n_cus = device_cus();       // persistent grid: one workgroup per CU (160 KiB LDS each)
-  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
+  DlnAux aux0{};
+  dim3 g, b(512);
+  if (int rc = x16_grid(m_bound, n_tiles, aux0, g)) return rc;
   const TE* x = static_cast<const TE*>(X);
   const TE* w = static_cast<const TE*>(W);
   const TE* r = static_cast<const TE*>(R);
   TOut* y = static_cast<TOut*>(Y);
   switch (epi) {
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
       break;
     case EPI_BIAS_RES:
-      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+      hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
       break;
     case EPI_BIAS_GELU_SPLIT3:
       if constexpr (sizeof(TOut) == 2) {
-        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU_SPLIT3>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_GELU_SPLIT3>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
         break;
       }
       return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_GELU_SPLIT3 writes the 16-bit split operand");
     case EPI_BIAS_RES_F32:
       if constexpr (sizeof(TOut) == 4) {
-        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, DlnAux{});
+        hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
         break;
       }
       return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 writes f32");
@@ -1539,9 +1610,10 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   const int n_tiles = N / G_BN;
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
-  dim3 g((unsigned)(tiles < cus ? tiles : cus));
   static const bool plain_stores = getenv("MANNER_HIP_NT_STORES") && atoi(getenv("MANNER_HIP_NT_STORES")) == 0;   // A/B switch
   DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
+  dim3 g;
+  if (int rc0 = x16_grid(m_bound, n_tiles, aux, g)) return rc0;
   static const int stagger = getenv("MANNER_HIP_GEMM_STAGGER") ? atoi(getenv("MANNER_HIP_GEMM_STAGGER")) : 0;   // A/B switch
   aux.stagger = stagger;
   // Round-aware split (see split_panels): only where a tail can exist by the host's bound (more tiles than workgroups), for the narrow
@@ -1555,7 +1627,7 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
     const int mp = (int)((m_exact + G_BM - 1) / G_BM);
     split = split_panels(mp, n_tiles, (int)cus) < mp;
   }
-  if (split) aux.split_cus = (int)cus;
+  if (split) { aux.split_cus = (int)cus; aux.panel_mode = 1; }     // the round-aware split cuts at 256-row panels
   int rc;
   if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
   else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
@@ -1586,6 +1658,8 @@ int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias,
   dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus), (unsigned)batch), b(512);
   DlnAux aux{};
   aux.batch_x = xs; aux.batch_w = ws; aux.batch_y = ys;
+  aux.panel_mode = 1;            // gridDim.y problems share the CUs: rounds of ONE problem say nothing; 256-row panels
+  aux.x_rows = rows;
   if (in == DT_F16)
     hipLaunchKernelGGL((gemm_tn_x16_kernel<f16_t, float, EPI_BIAS>), g, b, 0, stream, static_cast<const f16_t*>(X),
                        static_cast<const f16_t*>(W), bias, static_cast<const f16_t*>(nullptr), Y, N, K, m_total, n_tiles, aux);
@@ -1607,10 +1681,9 @@ int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, 
     return launch_small<bf16_t, float, EPI_BIAS_RES_F32>(X, W, bias, residual, Y, m_bound, N, K, m_total, drop, rowmap, stream);
   }
   const int n_tiles = N / G_BN;
-  const int64_t tiles = (m_bound / G_BM) * n_tiles;
-  const int n_cus = device_cus();
-  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
   DlnAux aux{};
+  dim3 g, b(512);
+  if (int rc = x16_grid(m_bound, n_tiles, aux, g)) return rc;
   aux.drop_seed = drop.seed; aux.drop_site = drop.site; aux.drop_thr = drop.thr; aux.drop_scale = drop.scale; aux.drop_rowmap = rowmap;
   if (in == DT_F16)
     hipLaunchKernelGGL((gemm_tn_x16_kernel<f16_t, float, EPI_BIAS_RES_F32>), g, b, 0, stream, static_cast<const f16_t*>(X), static_cast<const f16_t*>(W),
@@ -1628,12 +1701,10 @@ bool gemm_gelu_fusable(DType in, int64_t m_bound, int N, int K) {
 
 template <typename TE, typename TOut, int EPI>
 static int launch_gelu_fused(const void* X, const void* W, const float* bias, void* Y, int64_t m_bound, int N, int K, const int* m_total,
-                             const DlnAux& aux, hipStream_t stream) {
+                             DlnAux aux, hipStream_t stream) {
   const int n_tiles = N / G_BN;
-  const int64_t tiles = (m_bound / G_BM) * n_tiles;
-  if (tiles <= 0 || tiles > 0x7fffffff) return fail(MANNER_HIP_E_INVALID, "gemm grid %lld out of range", (long long)tiles);
-  const int n_cus = device_cus();
-  dim3 g((unsigned)(tiles < n_cus ? tiles : n_cus)), b(512);
+  dim3 g, b(512);
+  if (int rc = x16_grid(m_bound, n_tiles, aux, g)) return rc;
   hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI>), g, b, 0, stream, static_cast<const TE*>(X), static_cast<const TE*>(W), bias,
                      static_cast<const TE*>(nullptr), static_cast<TOut*>(Y), N, K, m_total, n_tiles, aux);
   MANNER_LAUNCH_CHECK();

@@ -221,12 +221,14 @@ class HipEncoder:
         except Exception:
             pass
 
-    def _workspace(self, n_news: int, tokens: int, prec: int) -> Tensor:
+    def _workspace(self, n_news: int, tokens: int, prec: int) -> Tuple[Tensor, int]:
+        """(buffer, bytes to hand to the library).  The library sizes its chunks from the BYTES it is given, so a buffer that an
+        earlier call in a wider arithmetic left larger must not change this call's chunking (and with it the per-launch figures)."""
         need = int(_lib.load().manner_hip_encoder_workspace_bytes(self._handle, n_news, tokens, prec))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        return self._ws, need
 
     def encode_cls(self, ids: Tensor, mask: Tensor, precision: str = "bf16",
                    host_lengths: Optional[np.ndarray] = None, max_chunk_tokens: int = 65536,
@@ -254,10 +256,10 @@ class HipEncoder:
             tokens = min(n * lp, max_chunk_tokens)
         tokens = max(tokens, lp, 256)
         with torch.cuda.device(ids.device):
-            ws = self._workspace(min(n, tokens), tokens, prec)
+            ws, ws_bytes = self._workspace(min(n, tokens), tokens, prec)
             _lib.check(_lib.load().manner_hip_encode_cls(
                 self._handle, _ptr(ids), _ptr(mask), C.c_void_p(hl.ctypes.data if hl is not None else 0), n, lp, prec,
-                _ptr(out), _ptr(ws), ws.numel(), _stream()))
+                _ptr(out), _ptr(ws), ws_bytes, _stream()))
         return out
 
     def encode_hidden(self, ids: Tensor, mask: Tensor, n_layers: int, precision: str = "bf16",
@@ -285,10 +287,10 @@ class HipEncoder:
             tokens = min(n * lp, max_chunk_tokens)
         tokens = max(tokens, lp, 256)
         with torch.cuda.device(ids.device):
-            ws = self._workspace(min(n, tokens), tokens, prec)
+            ws, ws_bytes = self._workspace(min(n, tokens), tokens, prec)
             _lib.check(_lib.load().manner_hip_encode_hidden(
                 self._handle, _ptr(ids), _ptr(mask), C.c_void_p(hl.ctypes.data if hl is not None else 0), n, lp, prec,
-                int(n_layers), 0 if out_dtype == torch.float32 else 1, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+                int(n_layers), 0 if out_dtype == torch.float32 else 1, _ptr(out), _ptr(ws), ws_bytes, _stream()))
         return out
 
     def profile(self, enable: bool) -> None:

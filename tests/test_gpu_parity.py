@@ -1282,3 +1282,39 @@ def test_round_aware_split_of_a_launch_gives_the_same_bits(precision, n_news, wi
     assert torch.equal(cls, ref_cls)
     assert torch.equal(hid, ref_hid)
     enc.close()
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16", "f16x3"])
+@pytest.mark.parametrize("n_news,with_lengths", [(200, False), (200, True), (131, False), (262, True)])
+def test_row_panel_height_of_the_persistent_gemm_gives_the_same_bits(precision, n_news, with_lengths, monkeypatch):
+    """Round 5: the persistent MFMA GEMM picks 256- or 192-row panels per launch from the DEVICE token count (`panel_rows`: 61 panels
+    of 256 rows x N = 768 are 183 tiles — one round with 73 CUs idle; 82 panels of 192 rows are 246 three-quarter tiles).  A row's
+    result does not depend on the panel height: per output element the same sequence of matrix instructions over K and the same
+    epilogue expressions.  MANNER_HIP_GEMM_PANEL=256 / 192 pins the height; unset, the kernel chooses: [CLS] embeddings and layer-k
+    hidden states of all three are equal to the BIT, for token counts whose last 192-row panel reaches past the workspace rows
+    (clamped DMA pieces), with the loose row bound of a call without host lengths and the exact one with them."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS["bert-base-uncased"], layers=3)
+    w = make_plm_weights(cfg, seed=95, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=95, max_len=96, profile="title_abstract")
+    lens = mask_np.sum(1) if with_lengths else None
+    tokens = int(mask_np.sum())
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")          # the persistent kernel for every shape of this test
+    got = {}
+    for mode in ("256", "192", None):
+        if mode is None:
+            monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_GEMM_PANEL", mode)
+        got[mode] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens),
+                     enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens))
+    enc.status()
+    monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+    cls, hid = got["256"]
+    assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1, tokens
+    for mode in ("192", None):
+        assert torch.equal(got[mode][0], cls), (mode, tokens)
+        assert torch.equal(got[mode][1], hid), (mode, tokens)
+    enc.close()

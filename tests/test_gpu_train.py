@@ -1065,3 +1065,39 @@ def test_train_kernels_stay_inside_the_declared_buffers(preset, n, max_len, toke
         assert bool((buf[:G] == 0xA5).all()), f"{name}: bytes in FRONT of the buffer were written"
         assert bool((buf[-G:] == 0xA5).all()), f"{name}: bytes BEHIND the buffer were written"
     assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(g).all()) for g in grads if g is not None)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_row_panel_height_of_the_training_gemms_gives_the_same_bits(precision, monkeypatch):
+    """Round 5: the training path's forward / data-gradient GEMMs (EPI_BIAS, EPI_BIAS_RES_F32 with its dropout bits, the fused GeLU
+    epilogues EPI_BIAS_GELU_DUAL / EPI_GELU_GRAD) run on 256- or 192-row panels, chosen per launch from the device token count.
+    MANNER_HIP_GEMM_PANEL pins the height: the encoder output and EVERY gradient are equal to the bit (the weight-gradient slices do
+    not depend on the panel height of the other GEMMs)."""
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=73, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(141, cfg, seed=73, max_len=48)          # ~4 k tokens: the last 192-row panel is ragged
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(5).standard_normal((141, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for mode in ("256", "192", None):
+        if mode is None:
+            monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_GEMM_PANEL", mode)
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=precision, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=6,
+                                 token_bound=int(mask_np.sum()))
+        (out * R).sum().backward()
+        res[mode] = (out.detach().cpu().numpy(), _grads(params))
+    monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+    a = res["256"]
+    assert np.isfinite(a[0]).all() and np.abs(a[0]).max() > 0.1
+    for mode in ("192", None):
+        b = res[mode]
+        assert np.array_equal(a[0], b[0]), mode
+        for k, g in a[1].items():
+            if g is None:
+                assert b[1][k] is None
+            else:
+                assert np.array_equal(g, b[1][k]), (mode, k)
