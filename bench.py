@@ -447,7 +447,7 @@ def small_ops_leg(dev, B=4096, S=50, D=768, Q=200, C=37):
     return out
 
 
-def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4, 5, 6, 7), steps=5):
+def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4, 5, 6, 7), steps=5, only=None):
     """one CR-Module training step (cr_module.py:140-171) on the HIP engine — encoder in train() mode with its
     dropouts (0.1 / 0.1 / 0.2), fused late-fusion scorer, SupCon loss, backward into every trainable tensor, then
     torch.optim.AdamW (the optimiser stays the reference's).  Batch: `impressions` users with a history of <= 50 news and
@@ -474,6 +474,8 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
            "impressions_per_step": impressions, "news_per_step": n_hist + n_cand, "tokens_per_step": tokens, "frozen_layers": list(frozen)}
     for variant, emb_trainable in (("reference_default_embeddings_trainable", True), ("embeddings_frozen_cached_prefix", False),
                                    ("embeddings_frozen_prefix_cache_across_steps", False)):
+        if only and variant not in only:
+            continue
         # third variant: the hidden states after the frozen layers come out of the content-addressed table in HBM (hip.PrefixCache;
         # MannerTextEncoder.prefix_cache_rows) — the batch is the same every step here, so after the first step every news is "seen":
         # the steady state of epochs >= 2 of the reference's 5-epoch schedule, not of a first epoch
@@ -531,7 +533,7 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
         if pcache is not None:
             out[variant].update({"prefix_cache_hit_rate_timed_steps": 1.0, "news_encoded_by_the_prefix_engine_in_all_steps": pcache.encoded,
                                  "news_looked_up": pcache.lookups, "loss_equal_to_recomputed_prefix_variant":
-                                 bool(out["embeddings_frozen_cached_prefix"]["loss_first_step"] == first
+                                 bool("embeddings_frozen_cached_prefix" in out and out["embeddings_frozen_cached_prefix"]["loss_first_step"] == first
                                       and out["embeddings_frozen_cached_prefix"]["loss_last_step"] == float(last.detach())),
                                  "table_MB": round(pcache.table.numel() * 4 / 1e6, 1)})
             del pcache

@@ -1071,8 +1071,8 @@ def test_train_kernels_stay_inside_the_declared_buffers(preset, n, max_len, toke
 def test_row_panel_height_of_the_training_gemms_gives_the_same_bits(precision, monkeypatch):
     """Round 5: the training path's forward / data-gradient GEMMs (EPI_BIAS, EPI_BIAS_RES_F32 with its dropout bits, the fused GeLU
     epilogues EPI_BIAS_GELU_DUAL / EPI_GELU_GRAD) run on 256- or 192-row panels, chosen per launch from the device token count.
-    MANNER_HIP_GEMM_PANEL pins the height: the encoder output and EVERY gradient are equal to the bit (the weight-gradient slices do
-    not depend on the panel height of the other GEMMs)."""
+    MANNER_HIP_GEMM_PANEL pins the height: the encoder output and every gradient are equal to the bit (the weight-gradient slices do
+    not depend on the panel height of the other GEMMs) — but for the word / position tables, whose scatter-add uses f32 atomics."""
     monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")
     cfg = PRESETS["mini-roberta-large"]
     w = make_plm_weights(cfg, seed=73, std=0.03, with_pooler=False)
@@ -1099,5 +1099,8 @@ def test_row_panel_height_of_the_training_gemms_gives_the_same_bits(precision, m
         for k, g in a[1].items():
             if g is None:
                 assert b[1][k] is None
+            elif k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+                # the two scatter-adds of the embedding backward are f32 atomics (rows repeat across news): run-to-run order, not bits
+                assert np.allclose(g, b[1][k], rtol=1e-5, atol=1e-5 * np.abs(g).max()), (mode, k)
             else:
                 assert np.array_equal(g, b[1][k]), (mode, k)

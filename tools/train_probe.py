@@ -20,6 +20,8 @@ if os.environ.get("TRAIN_PROBE_NODROP"):            # what the counter-based dro
         k.update(p_hidden=0.0, p_attn=0.0, p_out=0.0)
         return _orig(*a, **k)
     _T.encode_train = _nodrop
-out = bench.train_leg(PRESETS["bert-base-uncased"], torch.device("cuda", 0), prec)
+only = os.environ.get("TRAIN_PROBE_VARIANT")          # e.g. reference_default_embeddings_trainable: one variant, for a profile of it alone
+out = bench.train_leg(PRESETS["bert-base-uncased"], torch.device("cuda", 0), prec, only=(only,) if only else None,
+                      steps=int(os.environ.get("TRAIN_PROBE_STEPS", "5")))
 print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "step_ms_each", "peak_GB")} if isinstance(v, dict) else v)
                   for k, v in out.items() if k != "what"}))
