@@ -799,7 +799,10 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             encode_all(args.precision, gs, post=True)
             torch.cuda.current_stream().synchronize()   # this rank's encoding is done; mesh transfers of the last pieces may still fly
             t1 = time.perf_counter()
+            torch.cuda.reset_peak_memory_stats(dev)
+            before = torch.cuda.memory_allocated(dev)
             tabs = [g.wait() for g in gs]
+            exchange_extra[0] = max(exchange_extra[0], torch.cuda.max_memory_allocated(dev) - before)   # bytes the exchange itself allocated
             sync(); t2 = time.perf_counter()
             if b > a:                                   # a rank may hold no impressions when there are fewer impressions than ranks
                 res_ = hotpath.score_impressions(tabs, dimp, weights=fuse_w, labels=labels, k=10)
@@ -807,6 +810,7 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
             out_t = {"encode_s": t1 - t0, "allgather_s": t2 - t1, "score_s": t3 - t2, "total_s": t3 - t0}
         return out_t, res_, tabs
 
+    exchange_extra = [0]
     times, res, tables = pipeline(gathers)
     if res is None:
         res = {"scores": torch.zeros(0, device=dev), "ndcg": torch.zeros(0, device=dev)}
@@ -814,14 +818,21 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
     # the collective alone, nothing to hide behind: ONE all_gather_into_tensor (RCCL's own algorithm choice) per module
     coll_s = None
     if world > 1:
+        # ... IN PLACE, as the pipeline runs it (round 5: the table is the head of the [W * mx, D] gather buffer; no clone, no copy back);
+        # then once more through fresh buffers (all_gather_table) as an independent check of the in-place form, not timed
+        coll_gathers = gathers if exchange_ran == "collective" else [D.MeshTableGather(n_news, cfg.hidden, dev, pieces=1, exchange="collective") for _ in range(K)]
+        if coll_gathers is not gathers:
+            for k in range(K):
+                coll_gathers[k].table[lo:hi].copy_(local[k])
+        sync(); t0 = time.perf_counter()
+        for g in coll_gathers:
+            g.wait()
+        sync(); coll_s = time.perf_counter() - t0
         blocks = [torch.zeros((mx_rows, cfg.hidden), dtype=torch.float32, device=dev) for _ in range(K)]
         for k in range(K):
             blocks[k][: hi - lo] = local[k]
-        D.all_gather_table(blocks[0], shards)
-        sync(); t0 = time.perf_counter()
         gathered = [D.all_gather_table(blocks[k], shards) for k in range(K)]
-        sync(); coll_s = time.perf_counter() - t0
-        same = all(bool(torch.equal(gathered[k], tables[k])) for k in range(K))
+        same = all(bool(torch.equal(gathered[k], tables[k])) and bool(torch.equal(coll_gathers[k].table, tables[k])) for k in range(K))
         del blocks, gathered
     else:
         same = True
@@ -894,10 +905,11 @@ def table_mode(args, conf, cfg, encs, fuse_w, pool, rank, world, dev, scale_pari
                               (f"ONE all_gather_into_tensor per module after the encoding (backend {D.device_backend('cuda')!r}: its own algorithm)" if exchange_ran == "collective" else
                                f"direct full mesh of point-to-point transfers, {gathers[0].pieces} pieces per shard, each posted while the next is encoded")),
            "allgather_bytes_per_rank": recv_bytes if world > 1 else 0,
+           "allgather_extra_alloc_MB_rank0": exchange_extra[0] / 1e6,        # 0: the in-place exchange allocates nothing (was 2 x table per module)
            "allgather_standalone": None if world == 1 else {
                "collective_ms": 1e3 * coll_s, "collective_GBps_per_rank": recv_bytes / coll_s / 1e9,
                "collective_frac_of_xgmi": recv_bytes / coll_s / 1e9 / (7 * 153.0), "equals_pipeline_table": same,
-               "what": "the exchange with nothing to overlap: ONE all_gather_into_tensor per module; bytes = what a rank receives; "
+               "what": "the exchange with nothing to overlap: ONE in-place all_gather_into_tensor per module; bytes = what a rank receives; "
                        "xGMI peak = 7 links x 153 GB/s; the mesh form is measured in `mesh_exchange`"},
            "allgather_GBps_per_rank": (recv_bytes / coll_s / 1e9) if world > 1 and coll_s > 0 else None,
            "allgather_frac_of_xgmi": (recv_bytes / coll_s / 1e9 / (7 * 153.0)) if world > 1 and coll_s > 0 else None,
@@ -1182,7 +1194,7 @@ def compact_line(result, limit=COMPACT_LIMIT):
     tm = result.get("table_mode") or {}
     if tm:
         legs["table_mode"] = _pick(tm, ("candidates_per_s", "news_encoded_per_s", "scorer_pairs_per_s", "scorer_kernel_ms_rank0", "allgather_ms",
-                                        "allgather_exchange", "allgather_GBps_per_rank", "allgather_frac_of_xgmi", "encode_ms", "score_ms", "ndcg10", "error"))
+                                        "allgather_exchange", "allgather_GBps_per_rank", "allgather_frac_of_xgmi", "allgather_extra_alloc_MB_rank0", "encode_ms", "score_ms", "ndcg10", "error"))
         me = tm.get("mesh_exchange")
         if isinstance(me, dict):
             legs["table_mode"]["mesh"] = _pick(me, ("exchange", "tables_identical", "standalone_ms", "standalone_frac_of_xgmi", "error", "skipped"))

@@ -183,10 +183,11 @@ int manner_hip_encoder_profile_read(manner_hip_encoder_t enc, manner_hip_stream_
 int manner_hip_additive_pool(const float* x, const float* lin_w, const float* lin_b, const float* query,
                              int64_t B, int64_t S, int32_t D, int32_t Q, float* out, float* scratch,
                              manner_hip_stream_t stream);
-/* ABI v5 — the same operator with ONE pass over x (csrc/pool.hip): the rows of x stay on the CU (registers, bf16 hi/lo pairs =
- * 16 significant bits) between the logits — bf16x3 products on the bf16 matrix pipe: W.hi x.hi + W.hi x.lo + W.lo x.hi, f32
- * accumulation — and the softmax-weighted sum; x is read from HBM once.  Pooled vectors within 1e-4 of the reference (measured
- * ~1e-5 on tests/golden/additive_attention.npz incl. the zero-padded Q2 case).  Runs when D = 768 (S <= 128) or D = 1024 (S <= 64),
+/* ABI v5 — the same operator with ONE pass over x (csrc/pool.hip): the rows of x stay on the CU (registers, IEEE-half hi/lo pairs
+ * under a power-of-two row scale = 22 significant bits) between the logits — split (x3) products on the f16 matrix pipe: W.hi x.hi +
+ * W.hi x.lo + W.lo x.hi, f32 accumulation; tanh by exp / rcp — and the softmax-weighted sum; x is read from HBM once.  Pooled vectors
+ * within 1e-4 of the reference (measured 2e-7 on tests/golden/additive_attention.npz incl. the zero-padded Q2 case, 1.1e-5 on a
+ * peaked-softmax stress input).  Runs when D = 768 (S <= 128) or D = 1024 (S <= 64),
  * Q <= 320 and x / out are 16-byte aligned; otherwise — or with strict != 0, or MANNER_HIP_POOL_STRICT=1 in the environment — the
  * exact-f32 two-pass path of manner_hip_additive_pool runs (logits on the f32 matrix pipe, x read twice).
  *   workspace: manner_hip_additive_pool_workspace_bytes(B, S, D, Q) bytes, 256-byte aligned (packed W fragments / the logits). */

@@ -104,7 +104,7 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
 int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,
                      float* logits, hipStream_t stream);
 
-// K11 in one pass over x (pool.hip): bf16x3 logits on the bf16 matrix pipe from register-resident rows, softmax, weighted sum
+// K11 in one pass over x (pool.hip): split (x3) logits on the f16 matrix pipe from register-resident scaled-half hi/lo rows, softmax, weighted sum
 bool pool_fused_supported(int64_t B, int64_t S, int D, int Q);
 size_t pool_fused_workspace_bytes(int D, int Q);
 int pool_fused(const float* x, const float* W, const float* bias, const float* query, int64_t B, int64_t S, int D, int Q, float* out,

@@ -1053,14 +1053,21 @@ int transpose_to(Ctx& t, const void* in, DType in_dt, int64_t rows_in, int64_t c
 // gradient chain runs launches that leave CUs idle (the N = H data-gradient GEMMs fill 183 of 256, the attention backward is
 // latency-bound).  Per device: one non-blocking stream, one "inputs are ready" event and one "done" event per group of a layer
 // (FFN2, FFN1, out-projection, Q|K|V); the main stream waits for a group's "done" right before it overwrites that group's input.
+// Host threads: the stream and its events are ONE set per device, and a backward's record / wait pairs on them must not
+// interleave with another backward's (B's record of `ready` between A's record and A's wait would order A's side work behind B's main
+// stream instead of its own).  `mu` guards the lazy creation and is held by a backward for as long as it enqueues with the side stream
+// — two host threads training on one device serialise their (1 - 2 ms) enqueue phases; their kernels still share the device in stream
+// order.
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ok = false, tried = false;
+  std::mutex mu;
 };
 SideStream& side_stream() {
   static SideStream per_device[MAX_DEVICES];
   SideStream& sd = per_device[current_device_slot()];
+  std::lock_guard<std::mutex> guard(sd.mu);
   if (!sd.tried) {
     sd.tried = true;
     // LOWEST priority: the side stream should take the CUs the chain leaves idle, not compete for them (measured, default step of
@@ -1366,9 +1373,17 @@ static bool recorded_attn_path(const void* saved, bool rule) {
 
 struct WCacheArg { void* const* slots = nullptr; int32_t* valid = nullptr; int n = 0; };
 static thread_local WCacheArg g_next_wcache;
+// The registration belongs to the NEXT train_* call of the thread and to that call only: every entry point takes it (and clears the
+// thread-local) before anything can fail, so a call that returns early never leaves pointers into the caller's dropped arrays behind
+// for a later call that registers nothing.
+static WCacheArg take_wcache() {
+  const WCacheArg a = g_next_wcache;
+  g_next_wcache = WCacheArg{};
+  return a;
+}
 
 int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, int64_t N, int64_t Lp, int64_t Mb,
-          int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s) {
+          int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s, const WCacheArg& wc) {
   int rc;
   if ((rc = check_cfg(cfg, N, Lp, Mb, precision, start))) return rc;
   if (!weights || n_weights != MANNER_HIP_W_EMB_COUNT + cfg->layers * MANNER_HIP_WL_COUNT)
@@ -1379,13 +1394,10 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
   if (!saved || !ws) return fail(MANNER_HIP_E_INVALID, "train: null buffer");
   t.c = cfg; t.w = weights; t.N = N; t.Lp = Lp; t.Mb = Mb; t.prec = precision; t.s = s;
   t.n_w = n_weights;
-  if (g_next_wcache.slots) {                           // registered for THIS call by manner_hip_train_weight_cache (same thread)
-    if (g_next_wcache.n == 2 * n_weights && precision != MANNER_HIP_PREC_F32) {
-      t.wc_slots = g_next_wcache.slots;
-      t.wc_valid = g_next_wcache.valid;
-      t.wc_n = g_next_wcache.n;
-    }
-    g_next_wcache = WCacheArg{};
+  if (wc.slots && wc.n == 2 * n_weights && precision != MANNER_HIP_PREC_F32) {    // registered for THIS call (same thread)
+    t.wc_slots = wc.slots;
+    t.wc_valid = wc.valid;
+    t.wc_n = wc.n;
   }
   Bump bs(saved), bw(ws);
   plan_saved(bs, t.sv, *cfg, N, Mb, start);
@@ -1626,11 +1638,12 @@ static int train_forward_impl(const manner_hip_encoder_config* cfg, const float*
                               int32_t precision, int32_t start_layer, const float* prefix_hidden, float p_hidden, float p_attn,
                               float p_out, uint64_t seed, float* cls_out, void* saved, size_t saved_bytes, void* workspace,
                               size_t workspace_bytes, int32_t* status, manner_hip_stream_t stream, bool full) {
+  const WCacheArg wc = take_wcache();                  // first thing: consumed whatever this call goes on to do
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
-                  workspace_bytes, s)))
+                  workspace_bytes, s, wc)))
     return rc;
   if (!ids || !mask || !cls_out) return fail(MANNER_HIP_E_INVALID, "train_forward: null pointer");
   t.attn_mfma = choose_attn_path(cfg, precision, full);
@@ -1692,11 +1705,12 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
                                int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed, const float* grad_cls,
                                void* saved, size_t saved_bytes, float* const* grads, float* grad_prefix, void* workspace,
                                size_t workspace_bytes, manner_hip_stream_t stream, bool full) {
+  const WCacheArg wc = take_wcache();                  // first thing: consumed whatever this call goes on to do
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
-                  workspace_bytes, s)))
+                  workspace_bytes, s, wc)))
     return rc;
   if (!ids || !grad_cls || !grads) return fail(MANNER_HIP_E_INVALID, "train_backward: null pointer");
   t.attn_mfma = recorded_attn_path(saved, choose_attn_path(cfg, precision, full));      // what the forward of this buffer chose
@@ -1737,10 +1751,19 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
   const char* ws_env = getenv("MANNER_HIP_TRAIN_WGRAD_STREAM");          // A/B switch, read per call
   const char* tr_env0 = getenv("MANNER_HIP_WGRAD_TR");
   SideStream* sd = nullptr;
+  std::unique_lock<std::mutex> side_lock;                // held while this call enqueues with the device's side stream
+  // the scratch the side stream carves out of buffers the main stream of a 16-bit backward does not use (plan_work): its column-sum
+  // partials behind the LayerNorm backward's share of wk.part, the second pair of 16-bit gradient buffers (4 x [Mb, H]) in wk.tmp
+  const size_t wide_ = (size_t)(I > 3 * H ? I : 3 * H);
+  const bool part_fits = (size_t)LN_BWD_BLOCKS * H * 2 + (size_t)COLSUM_BLOCKS * wide_ <= (size_t)2 * LN_BWD_BLOCKS * wide_;
+  const bool tmp_fits = (size_t)4 * t.Mb * H * 2 <= (size_t)t.Mb * wide_ * sizeof(float);
   if (t.dt() != DT_F32 && !full && (!ws_env || atoi(ws_env) != 0) && (!tr_env0 || atoi(tr_env0) != 0) && cfg->hidden % 256 == 0 &&
-      cfg->intermediate % 256 == 0 && (size_t)LN_BWD_BLOCKS * H * 2 + (size_t)COLSUM_BLOCKS * (I > 3 * H ? I : 3 * H) <= (size_t)2 * LN_BWD_BLOCKS * (I > 3 * H ? I : 3 * H)) {
+      cfg->intermediate % 256 == 0 && part_fits && tmp_fits) {
     SideStream& cand = side_stream();
-    if (cand.ok) sd = &cand;
+    if (cand.ok) {
+      sd = &cand;
+      side_lock = std::unique_lock<std::mutex>(cand.mu);
+    }
   }
   Ctx cs = t;
   bool pending[4] = {false, false, false, false};

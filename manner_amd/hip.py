@@ -428,15 +428,17 @@ class PrefixCache(NewsEmbeddingCache):
             if fresh is not None:
                 out.index_copy_(0, todo, fresh)                                  # rows that could not be stored
             return out
-        except Exception:
+        except BaseException:                  # also KeyboardInterrupt / SystemExit: the table is torch.empty, a claimed key must not survive
             self.clear()
             raise
 
 
 def additive_pool(x: Tensor, lin_w: Tensor, lin_b: Tensor, query: Tensor, strict: bool = False) -> Tensor:
-    """AdditiveAttention.forward (reference attention.py:21-27).  Default: the one-pass kernel (x read once, bf16x3 logits on the
-    bf16 matrix pipe, within 1e-4 of the reference) where the shape allows it; ``strict=True`` (or MANNER_HIP_POOL_STRICT=1): the
-    exact-f32 two-pass path."""
+    """AdditiveAttention.forward (reference attention.py:21-27).  Default: the one-pass kernel where the shape allows it (D = 768,
+    S <= 128, Q <= 320) — x read once and kept on the CU as power-of-two-scaled IEEE-half hi/lo pairs, logits as split (x3) products
+    on the f16 matrix pipe, tanh by exp/rcp: pooled vectors within 1e-4 of the reference (measured 2e-7 on the goldens, 1.1e-5 on a
+    peaked-softmax stress input; csrc/pool.hip).  ``strict=True`` (or MANNER_HIP_POOL_STRICT=1): the exact-f32 two-pass path (f32
+    matrix pipe logits + apply), which train() mode always uses."""
     x = _dev(x, torch.float32, "input_vector").contiguous()
     b, s, d = x.shape
     lin_w = _dev(lin_w, torch.float32, "linear.weight").contiguous()

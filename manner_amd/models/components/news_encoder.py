@@ -278,7 +278,7 @@ class MannerTextEncoder(nn.Module):
                 out.index_copy_(0, todo, fresh)                                  # state 2 rows have no table row
                 return out
             return cache.table.index_select(0, rows.long())
-        except Exception:
+        except BaseException:                  # KeyboardInterrupt / SystemExit too: a notebook or a resumed loop goes on using the module
             cache.clear()                      # keys of this call may point at rows that were never written
             raise
 

@@ -48,20 +48,30 @@ class _WeightCopyCache:
 
     The 16-bit training modes convert every weight matrix to the GEMM operand type — and transpose it for the data-gradient GEMMs —
     on every call; for the layers the reference freezes (``frozen_layers: [0..7]``, news_encoder.py:24-27) the result never changes:
-    8 layers x (3 conversions + the Q|K|V pack + 4 transposes) = 0.5 ms of a 15.5 ms step.  Entries are keyed by the parameters' storage
-    (address, size) and their torch version counters (an optimizer step, ``load_state_dict`` or any in-place write bumps them);
-    a parameter that requires grad is never cached.  The copies themselves are made by the library on first use — the same kernels as
-    without the cache, so the cached path is bit-identical — this class only owns the buffers and the validity flags."""
+    8 layers x (3 conversions + the Q|K|V pack + 4 transposes) = 0.5 ms of a 15.5 ms step.  An entry belongs to the parameter OBJECTS
+    it was made from (round 5): it holds weak references to them, is used only while every reference still yields the very
+    tensor passed in, and is dropped by a finalizer the moment one of them is collected — a new model whose fresh parameters land on
+    the same allocator addresses with the same version counters can never see a stale copy, and the copies of a model that is gone do
+    not stay pinned in HBM.  Within the owners' lifetime an entry is validated by storage (address, size) and the torch version
+    counters (an optimizer step, ``load_state_dict`` or any in-place write through the parameter bumps them); a write through
+    ``p.data`` bypasses the counter — call ``invalidate_weight_cache()`` after one.  A parameter that requires grad is never cached.
+    The copies themselves are made by the library on first use — the same kernels as without the cache, so the cached path is
+    bit-identical — this class only owns the buffers and the validity flags."""
 
-    # (offset of the matrix inside a layer's block of the weight table, dependencies, element count as a function of H, I, copies)
     def __init__(self):
         self._entries = {}
 
-    @staticmethod
-    def _key(dev, prec, layer, what):
-        return (str(dev), prec, layer, what)
+    def clear(self):
+        self._entries.clear()
+
+    def __len__(self):
+        return len(self._entries)
+
+    def _drop(self, key):
+        self._entries.pop(key, None)
 
     def arrays(self, cfg, params, needs_grad, prec, start, dev):
+        import weakref
         n = len(params)
         h, i_ = cfg.hidden, cfg.intermediate
         esz = 2
@@ -76,14 +86,19 @@ class _WeightCopyCache:
             for what, deps, at, nbytes, both in groups:
                 if any(needs_grad[b + d] for d in deps):
                     continue
-                key = self._key(dev, prec, l, what)
+                owners = [params[b + d] for d in deps]
+                key = (str(dev), prec, l, what) + tuple(id(o) for o in owners)
                 ent = self._entries.get(key)
-                vers = tuple(int(params[b + d]._version) for d in deps)
-                ptrs = tuple((params[b + d].data_ptr(), params[b + d].numel()) for d in deps)
+                vers = tuple(int(o._version) for o in owners)
+                ptrs = tuple((o.data_ptr(), o.numel()) for o in owners)
+                if ent is not None and not all(r() is o for r, o in zip(ent["owners"], owners)):
+                    ent = None                       # an id() re-used by another object: never this entry's tensors
                 if ent is None or ent["ptrs"] != ptrs:
-                    ent = {"ptrs": ptrs, "vers": None,
+                    ent = {"ptrs": ptrs, "vers": None, "owners": [weakref.ref(o) for o in owners],
                            "bufs": [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if both else 1)], "valid": [0, 0]}
                     self._entries[key] = ent
+                    for o in owners:                 # the entry dies with the first of its owners
+                        weakref.finalize(o, self._drop, key)
                 if ent["vers"] != vers:
                     ent["valid"] = [0, 0]
                     ent["vers"] = vers
@@ -101,6 +116,13 @@ class _WeightCopyCache:
 
 
 _WCACHE = _WeightCopyCache()
+
+
+def invalidate_weight_cache() -> None:
+    """Forget every cached 16-bit copy of frozen weights (they are rebuilt on the next training call).  Needed only after a write that
+    torch's version counter cannot see (``p.data.copy_(...)``, a raw pointer write); optimiser steps, ``load_state_dict`` and in-place
+    ops through the parameter are detected by themselves."""
+    _WCACHE.clear()
 
 
 def _register_weight_cache(lib, cfg, params, needs_grad, opts, start, dev):

@@ -28,3 +28,35 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_MEASURED = {}
+
+
+@pytest.fixture
+def measured(request):
+    """record(key=value, ...): keeps the MEASURED side of a kernel-vs-kernel tolerance next to its bound.  The values
+    of a session are written to gpurun_out/measured_tolerances.json (scratch that travels back from the GPU box; the copy that is
+    judged lives under profiles/)."""
+    def record(**values):
+        _MEASURED.setdefault(request.node.name, {}).update({k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()})
+    return record
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MEASURED:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "measured_tolerances.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_MEASURED)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -211,7 +211,7 @@ def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, 
 
 
 @pytest.mark.parametrize("precision,rel,cos_min", [("f16", 2e-2, 0.9999), ("bf16", 8e-2, 0.999)])
-def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, cos_min, monkeypatch):
+def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, cos_min, monkeypatch, measured):
     """the matrix-pipe training attention (train_attn.hip; 16-bit Q | K | V, probabilities rounded to 16 bits for the P.V
     and the gradient products) against the f32 VALU kernels it replaced, IN ONE PROCESS — MANNER_HIP_TRAIN_ATTN_VALU is read per
     call, the forward records its choice against the saved buffer and the backward follows the record.  Same weights, inputs and
@@ -259,6 +259,8 @@ def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, 
             worst = (e, c, k)
         assert e <= rel and c >= cos_min, (k, e, c)
     print(f"{precision}: worst gradient tensor {worst[2]}: rel-to-max {worst[0]:.3e}, cosine {worst[1]:.6f}")
+    measured(bound_rel=rel, bound_cos=cos_min, worst_rel_to_max=worst[0], cosine_of_that_tensor=worst[1], tensor=str(worst[2]),
+             output_max_abs_diff=float(np.abs(a - b).max()), output_scale=float(np.abs(b).max()))
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
@@ -323,10 +325,29 @@ def test_frozen_weight_copy_cache_is_bit_identical_and_follows_weight_updates(pr
             assert np.abs(g[k] - new_g[k]).max() <= 1e-5 * max(np.abs(new_g[k]).max(), 1e-6), k
         else:
             assert np.array_equal(g[k], new_g[k]), k
+    # Round 5: an entry belongs to the parameter OBJECTS it was made from.  When the model goes, its copies go (nothing
+    # stays pinned in HBM) — and a NEW model whose fresh tensors land on the freed addresses with the same version counters (the
+    # allocator hands the blocks straight back) gets its own copies, never the old model's.
+    import gc
+    ptrs = sorted(p.data_ptr() for k, p in params.items() if "layer.0." in k)
+    del params, fresh, g, new_g
+    gc.collect()
+    assert len(train._WCACHE) == 0
+    w3 = {k: (v * np.float32(0.5) if "layer.0." in k and v.ndim == 2 else v) for k, v in w.items()}
+    monkeypatch.setenv("MANNER_TRAIN_WEIGHT_CACHE", "0")
+    other_out, _ = run({k: torch.from_numpy(v).to(DEV).requires_grad_("layer.0." not in k) for k, v in w3.items()})
+    monkeypatch.delenv("MANNER_TRAIN_WEIGHT_CACHE")
+    gc.collect()
+    params3 = {k: torch.from_numpy(v).to(DEV).requires_grad_("layer.0." not in k) for k, v in w3.items()}
+    reused = len(set(ptrs) & {p.data_ptr() for k, p in params3.items() if "layer.0." in k})
+    out3, _ = run(params3)
+    assert not np.array_equal(other_out, ref_out) and np.array_equal(out3, other_out), reused
+    train.invalidate_weight_cache()
+    assert len(train._WCACHE) == 0
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-def test_gelu_inside_the_ffn_gemms_tracks_the_separate_kernels(precision, monkeypatch):
+def test_gelu_inside_the_ffn_gemms_tracks_the_separate_kernels(precision, monkeypatch, measured):
     """Round 4: in the 16-bit modes FFN1 writes the saved f32 pre-activation AND its 16-bit gelu from one GEMM
     (EPI_BIAS_GELU_DUAL), and the data-gradient GEMM through FFN2 multiplies by gelu'(pre-activation) in its epilogue
     (EPI_GELU_GRAD) — no gelu16_kernel pass over the I-wide tensors.  The fused epilogues use the |error| <= 1.5e-7 erf of the
@@ -366,6 +387,8 @@ def test_gelu_inside_the_ffn_gemms_tracks_the_separate_kernels(precision, monkey
             worst = (e, c, k)
         assert e <= (3e-2 if precision == "bf16" else 1e-2) and c >= (0.9999 if precision == "bf16" else 0.99999), (k, e, c)
     print(f"{precision}: outputs rel {e_out:.2e}; worst gradient tensor {worst[2]}: rel-to-max {worst[0]:.3e}, cosine {worst[1]:.7f}")
+    measured(bound_rel=3e-2 if precision == "bf16" else 1e-2, bound_cos=0.9999 if precision == "bf16" else 0.99999, output_rel=e_out,
+             worst_rel_to_max=worst[0], cosine_of_that_tensor=worst[1], tensor=str(worst[2]))
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
