@@ -57,7 +57,10 @@ enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_NORM = 3,
                                             [hi | hi | lo], row stride 3 N of the 16-bit type (the f32 intermediate never exists) */,
                 EPI_BIAS_GELU_DUAL = 8 /* training forward FFN1 (gemm_tn_gelu_dual): f32 pre-activation acc + bias AND its gelu in
                                           the 16-bit operand type, one launch */,
-                EPI_GELU_GRAD = 9 /* training backward (gemm_tn_gelu_grad): 16-bit out = round16(acc) * gelu'(saved f32 pre-activation) */ };
+                EPI_GELU_GRAD = 9 /* training backward (gemm_tn_gelu_grad): 16-bit out = round16(acc) * gelu'(saved f32 pre-activation) */,
+                EPI_BIAS_GELU_DUAL16 = 10 /* round 5, 16-bit saved activations: pre16 = round16(acc + bias) AND gelu(pre16), both in the
+                                             16-bit operand type (what the reference's 16-mixed autocast saves: the f16 Linear output) */,
+                EPI_GELU_GRAD16 = 11 /* ... and the backward: 16-bit out = round16(acc) * gelu'(pre16) */ };
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 static inline bool is_16bit(DType d) { return d != DT_F32; }
 

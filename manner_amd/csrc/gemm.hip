@@ -868,8 +868,10 @@ struct DlnAux {
   int stagger;
   // EPI_BIAS_GELU_DUAL: second output [m, N] of the operand type (gelu of the f32 rows written to Y);
   // EPI_GELU_GRAD: saved f32 pre-activation [m, N] whose gelu' multiplies the output
+  // EPI_BIAS_GELU_DUAL16: aux16 = gelu of the 16-bit rows written to Y;  EPI_GELU_GRAD16: pre16 = saved 16-bit pre-activation [m, N]
   void* aux16;
   const float* aux32;
+  const void* pre16;
   // > 0 (and col_group == 0): this launch covers only the row panels of split_panels(); a tail launch of the 128x128 kernel follows
   int split_cus;
   // Row-panel height (round 5): 0 = the kernel picks 256 or 192 rows per tile from the DEVICE token count (panel_rows()), 1 = always
@@ -1363,6 +1365,15 @@ __device__ __forceinline__ void gemm_tn_x16_body(
           else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
         }
       }
+      f32x4 pre16v[EPI == EPI_GELU_GRAD16 ? SQ : 1];
+      if constexpr (EPI == EPI_GELU_GRAD16) {                              // TOut == TE: 8 outputs per chunk, their 8 saved 16-bit pre-activations
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+          const int row = q * ROWS_PER_INST + row0;
+          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
+          pre16v[q] = *reinterpret_cast<const f32x4*>(static_cast<const TE*>(dln.pre16) + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+        }
+      }
       f32x4 pre[EPI == EPI_GELU_GRAD ? SQ : 1][2];
       if constexpr (EPI == EPI_GELU_GRAD) {                                // TOut == TE: 8 outputs per chunk, their 8 saved f32 pre-activations
 #pragma unroll
@@ -1385,6 +1396,13 @@ __device__ __forceinline__ void gemm_tn_x16_body(
           e16x8 d = __builtin_bit_cast(e16x8, raw);
 #pragma unroll
           for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast(pre[q][e >> 2][e & 3]));
+          raw = __builtin_bit_cast(f32x4, d);
+        }
+        if constexpr (EPI == EPI_GELU_GRAD16) {
+          e16x8 d = __builtin_bit_cast(e16x8, raw);
+          const e16x8 pv = __builtin_bit_cast(e16x8, pre16v[q]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast((float)pv[e]));
           raw = __builtin_bit_cast(f32x4, d);
         }
         if (EPI == EPI_BIAS_RES) {
@@ -1410,6 +1428,13 @@ __device__ __forceinline__ void gemm_tn_x16_body(
 #pragma unroll
             for (int e = 0; e < 4; ++e) gv[e] = (TE)gelu_erf_fast(raw[e]);
             *reinterpret_cast<e16x4*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
+          }
+          if constexpr (EPI == EPI_BIAS_GELU_DUAL16) {                     // TOut == TE: 8 rounded pre-activations -> their 8 gelu values
+            const e16x8 pv = __builtin_bit_cast(e16x8, raw);
+            e16x8 gv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = (TE)gelu_erf_fast((float)pv[e]);
+            *reinterpret_cast<e16x8*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
           }
         }
       }
@@ -1729,6 +1754,26 @@ int gemm_tn_gelu_grad(DType in, const void* X, const void* W, const float* zero_
   aux.aux32 = pre;
   if (in == DT_F16) return launch_gelu_fused<f16_t, f16_t, EPI_GELU_GRAD>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
   return launch_gelu_fused<bf16_t, bf16_t, EPI_GELU_GRAD>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
+}
+
+int gemm_tn_gelu_dual16(DType in, const void* X, const void* W, const float* bias, void* Pre16, void* G16, int64_t m_bound, int N, int K,
+                        const int* m_total, hipStream_t stream) {
+  if (!gemm_gelu_fusable(in, m_bound, N, K) || !G16 || !Pre16)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_gelu_dual16: m_bound=%lld N=%d K=%d", (long long)m_bound, N, K);
+  DlnAux aux{};
+  aux.aux16 = G16;
+  if (in == DT_F16) return launch_gelu_fused<f16_t, f16_t, EPI_BIAS_GELU_DUAL16>(X, W, bias, Pre16, m_bound, N, K, m_total, aux, stream);
+  return launch_gelu_fused<bf16_t, bf16_t, EPI_BIAS_GELU_DUAL16>(X, W, bias, Pre16, m_bound, N, K, m_total, aux, stream);
+}
+
+int gemm_tn_gelu_grad16(DType in, const void* X, const void* W, const float* zero_bias, const void* pre16, void* Y16, int64_t m_bound, int N,
+                        int K, const int* m_total, hipStream_t stream) {
+  if (!gemm_gelu_fusable(in, m_bound, N, K) || !pre16 || !Y16)
+    return fail(MANNER_HIP_E_INVALID, "gemm_tn_gelu_grad16: m_bound=%lld N=%d K=%d", (long long)m_bound, N, K);
+  DlnAux aux{};
+  aux.pre16 = pre16;
+  if (in == DT_F16) return launch_gelu_fused<f16_t, f16_t, EPI_GELU_GRAD16>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
+  return launch_gelu_fused<bf16_t, bf16_t, EPI_GELU_GRAD16>(X, W, zero_bias, Y16, m_bound, N, K, m_total, aux, stream);
 }
 
 int gemm_tn(DType in, DType out, Epilogue epi, const void* X, const void* W, const float* bias,

@@ -433,6 +433,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   const int64_t n = blockIdx.x;
   for (int c = threadIdx.x; c < H; c += 256) dst[(size_t)n * H + c] = src[(size_t)cu[n] * H + c];
 }
+// the same gather from a tensor that exists in the 16-bit type only (round 5: ctx with 16-bit saved activations); exact widening
+template <typename TE>
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const TE* __restrict__ src, const int32_t* __restrict__ cu, int H,
+                                                            float* __restrict__ dst) {
+  const int64_t n = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) dst[(size_t)n * H + c] = (float)src[(size_t)cu[n] * H + c];
+}
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ cu, int H,
                                                                float* __restrict__ dst) {
   const int64_t n = blockIdx.x;
@@ -1029,6 +1036,17 @@ struct Ctx {
   // of L.qkv (16-bit or f32) follows from it.
   bool attn_mfma = false;
   bool mfma_attn() const { return attn_mfma; }
+  // Round 5 — 16-bit saved activations (`lean`; MANNER_HIP_TRAIN_SAVE16=0 switches it off for A/B): with the matrix-pipe attention
+  // and the fused GeLU epilogues available for the token-row shapes, the tensors that only GEMMs / the attention consume exist in the
+  // 16-bit type ONLY — what the reference's `precision: 16-mixed` autocast saves (the f16 outputs of its Linear layers and matmuls):
+  //   ctx    : the attention writes the 16-bit rows alone (its f32 rows had no reader but a conversion)
+  //   inter  : FFN1 saves round16(h1 W1^T + b1) and gelu of THAT value (EPI_BIAS_GELU_DUAL16); gelu' in the backward reads it
+  //   d ctx  : leaves its data-gradient GEMM in the 16-bit type, straight into the attention backward's operand buffer
+  //   d qkv  : the attention backward writes the 16-bit rows alone; the Q|K|V bias gradient is their column sum
+  // The f32 residual stream (r1, h1, r2, x: LayerNorm inputs / outputs, f32 under autocast too) is untouched.  Decided once per
+  // forward (setup of train_forward_impl), recorded with the attention path against the saved buffer, read back by the backward.
+  // The compact [CLS] tail of the last layer keeps the f32 pre-activation (its n_news rows are a small problem: separate GeLU kernels).
+  bool lean = false;
   // Optional cache of 16-bit weight copies across calls (manner_hip_train_weight_cache; round 4): slot 2 i = the mode's 16-bit copy of
   // weight i of the table in its own layout, slot 2 i + 1 = its transpose (what the data-gradient GEMMs read); at a layer's Q weight:
   // the packed [3H, H] Q | K | V copy and its transpose, at its Q bias (slot 2 i): the f32 [3H] bias concatenation.  A slot the caller
@@ -1114,7 +1132,7 @@ int linear_fwd(Ctx& t, const float* X, const float* W, const float* bias, float*
 }
 
 // A/B switch (MANNER_HIP_TRAIN_GELU_FUSED=0): the GeLU of the FFN as separate elementwise kernels in the 16-bit modes too
-bool gelu_fused_enabled() {
+static bool gelu_fused_enabled() {
   const char* e = getenv("MANNER_HIP_TRAIN_GELU_FUSED");
   return !e || atoi(e) != 0;
 }
@@ -1123,8 +1141,14 @@ int gelu16(Ctx& t, const float* inter, void* z, int width, int mode);
 
 // FFN1 of the 16-bit modes: inter [Mb, I] f32 = h1 W1^T + b1 (saved for the backward's gelu') and g [Mb, I] = gelu(inter) in the
 // 16-bit type — one GEMM with both outputs where the shape allows, else GEMM + gelu16
-int ffn1_fwd16(Ctx& t, const void* h16, const float* W, const float* bias, float* inter, void* g, int I, int H) {
+// pre16 (round 5, Ctx::lean): the saved pre-activation is round16(h1 W1^T + b1) in the 16-bit type (the f32 slot, half used)
+int ffn1_fwd16(Ctx& t, const void* h16, const float* W, const float* bias, float* inter, void* g, int I, int H, bool pre16 = false) {
   int rc;
+  if (pre16) {                                              // lean was chosen only where this shape is fusable
+    const void* w16;
+    if ((rc = weight16(t, W, I, H, false, t.wk.b16, &w16))) return rc;
+    return gemm_tn_gelu_dual16(t.dt(), h16, w16, bias, inter, g, t.Mb, I, H, t.sv.m_total, t.s);
+  }
   if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), t.Mb, I, H)) {
     const void* w16;
     if ((rc = weight16(t, W, I, H, false, t.wk.b16, &w16))) return rc;
@@ -1361,14 +1385,22 @@ static bool choose_attn_path(const manner_hip_encoder_config* c, int32_t precisi
   const bool valu = v && *v && *v != '0';
   return precision != MANNER_HIP_PREC_F32 && !valu && !full && c->hidden == c->heads * 64;   // the MFMA kernels are written for head_dim 64
 }
-static void record_attn_path(const void* saved, bool mfma) {
-  std::lock_guard<std::mutex> g(g_attn_mu);
-  g_attn_path[saved] = mfma ? 1 : 0;
+static bool gelu_fused_enabled();
+static bool choose_lean(const manner_hip_encoder_config* c, int32_t precision, int64_t Mb, bool mfma) {
+  const char* v = getenv("MANNER_HIP_TRAIN_SAVE16");                       // read per call: the tests compare both layouts in one process
+  const bool off = v && *v == '0';
+  const DType dt = precision == MANNER_HIP_PREC_F16 ? DT_F16 : DT_BF16;
+  return mfma && !off && gelu_fused_enabled() && gemm_gelu_fusable(dt, Mb, c->intermediate, c->hidden) && gemm_gelu_fusable(dt, Mb, c->hidden, c->hidden);
 }
-static bool recorded_attn_path(const void* saved, bool rule) {
+static void record_attn_path(const void* saved, bool mfma, bool lean) {
+  std::lock_guard<std::mutex> g(g_attn_mu);
+  g_attn_path[saved] = (mfma ? 1 : 0) | (lean ? 2 : 0);
+}
+static bool recorded_attn_path(const void* saved, bool rule, bool lean_rule, bool* lean) {
   std::lock_guard<std::mutex> g(g_attn_mu);
   auto it = g_attn_path.find(saved);
-  return it == g_attn_path.end() ? rule : it->second != 0;
+  *lean = it == g_attn_path.end() ? lean_rule : (it->second & 2) != 0;
+  return it == g_attn_path.end() ? rule : (it->second & 1) != 0;
 }
 
 struct WCacheArg { void* const* slots = nullptr; int32_t* valid = nullptr; int n = 0; };
@@ -1452,7 +1484,9 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
       x16 = t.wk.a16;
     }
     if ((rc = gemm_tn(t.dt(), t.dt(), EPI_BIAS, x16, qkv_w16, qkv_b, nullptr, L.qkv, t.Mb, 3 * H, H, t.sv.m_total, s))) return rc;
-    if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, L.ctx, t.wk.h16b, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc;
+    // lean: the 16-bit rows alone, into the saved slot (half used) — the out-projection GEMM reads them there
+    if (t.lean) { if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, nullptr, L.ctx, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc; }
+    else if ((rc = attn_train_mfma_forward(t.dt(), L.qkv, L.ctx, t.wk.h16b, L.ml, cu, t.N, cfg->heads, H, (int)t.Lp, da_m, s))) return rc;
   } else {
     if ((rc = linear_fwd(t, x_in, t.wk.wcat, t.wk.bcat, L.qkv, 3 * H, H, mixed && x_in_has_16 ? t.wk.h16a : nullptr))) return rc;
     const Drop da = da_m;
@@ -1469,7 +1503,9 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
     c.sv.m_total = t.sv.m_total + 1;                         // {tokens, news}: the second entry bounds the compact rows
     float* ctx_c = t.wk.dr;                                  // [n_news, H] gathers (the backward gathers ctx again)
     float* x_c = t.wk.dbig;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, L.ctx, cu, H, ctx_c);
+    if (!t.lean) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, L.ctx, cu, H, ctx_c);
+    else if (t.dt() == DT_F16) hipLaunchKernelGGL(gather_rows16_kernel<f16_t>, dim3((unsigned)t.N), dim3(256), 0, s, reinterpret_cast<const f16_t*>(L.ctx), cu, H, ctx_c);
+    else hipLaunchKernelGGL(gather_rows16_kernel<bf16_t>, dim3((unsigned)t.N), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(L.ctx), cu, H, ctx_c);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)t.N), dim3(256), 0, s, x_in, cu, H, x_c);
     MANNER_LAUNCH_CHECK();
     if ((rc = linear_fwd_drop_res(c, ctx_c, nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_c, L.r1, H, H,
@@ -1486,11 +1522,11 @@ int layer_forward(Ctx& t, int l, LayerSaved& L, const float* x_in, float* x_out,
                                   make_drop(seed, layer_site(l, SITE_FFN), p_hidden), cu))) return rc;
     return ln_forward(c, L.r2, t.lw(l, MANNER_HIP_WL_OLN_G), t.lw(l, MANNER_HIP_WL_OLN_B), x_out, L.st2, make_drop(0, 0, 0.f));
   }
-  if ((rc = linear_fwd_drop_res(t, L.ctx, mixed ? t.wk.h16b : nullptr, t.lw(l, MANNER_HIP_WL_AO_W), t.lw(l, MANNER_HIP_WL_AO_B), x_in, L.r1, H, H,
-                                make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr))) return rc;
+  if ((rc = linear_fwd_drop_res(t, t.lean ? nullptr : L.ctx, t.lean ? (const void*)L.ctx : (mixed ? (const void*)t.wk.h16b : nullptr), t.lw(l, MANNER_HIP_WL_AO_W),
+                                t.lw(l, MANNER_HIP_WL_AO_B), x_in, L.r1, H, H, make_drop(seed, layer_site(l, SITE_PROJ), p_hidden), nullptr))) return rc;
   if ((rc = ln_forward(t, L.r1, t.lw(l, MANNER_HIP_WL_ALN_G), t.lw(l, MANNER_HIP_WL_ALN_B), L.h1, L.st1, make_drop(0, 0, 0.f), t.wk.h16b))) return rc;
   if (mixed) {
-    if ((rc = ffn1_fwd16(t, t.wk.h16b, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, L.g, I, H))) return rc;
+    if ((rc = ffn1_fwd16(t, t.wk.h16b, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, L.g, I, H, t.lean))) return rc;
   } else {
     if ((rc = linear_fwd(t, L.h1, t.lw(l, MANNER_HIP_WL_FF1_W), t.lw(l, MANNER_HIP_WL_FF1_B), L.inter, I, H, nullptr))) return rc;
     hipLaunchKernelGGL(gelu_kernel, dim3(t.ew_grid(I)), dim3(256), 0, s, L.inter, nullptr, L.g, I, t.sv.m_total, 0, Out16{nullptr, 0});
@@ -1647,7 +1683,8 @@ static int train_forward_impl(const manner_hip_encoder_config* cfg, const float*
     return rc;
   if (!ids || !mask || !cls_out) return fail(MANNER_HIP_E_INVALID, "train_forward: null pointer");
   t.attn_mfma = choose_attn_path(cfg, precision, full);
-  record_attn_path(saved, t.attn_mfma);
+  t.lean = choose_lean(cfg, precision, m_bound, t.attn_mfma);
+  record_attn_path(saved, t.attn_mfma, t.lean);
   if ((start_layer > 0) != (prefix_hidden != nullptr))
     return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
   for (float p : {p_hidden, p_attn, p_out})
@@ -1713,7 +1750,10 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
                   workspace_bytes, s, wc)))
     return rc;
   if (!ids || !grad_cls || !grads) return fail(MANNER_HIP_E_INVALID, "train_backward: null pointer");
-  t.attn_mfma = recorded_attn_path(saved, choose_attn_path(cfg, precision, full));      // what the forward of this buffer chose
+  {                                                      // what the forward of this buffer chose
+    const bool rule = choose_attn_path(cfg, precision, full);
+    t.attn_mfma = recorded_attn_path(saved, rule, choose_lean(cfg, precision, m_bound, rule), &t.lean);
+  }
   if (t.attn_mfma && (precision == MANNER_HIP_PREC_F32 || full)) return fail(MANNER_HIP_E_INVALID, "train_backward: the forward of this saved buffer ran another precision / row layout");
   if (grad_prefix && start_layer == 0) return fail(MANNER_HIP_E_INVALID, "train_backward: grad_prefix goes with start_layer > 0");
   const int H = cfg->hidden, I = cfg->intermediate;
@@ -1842,7 +1882,11 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     const void* dinter_any;
     if ((rc = main_wait(1))) return rc;                        // b_dinter still holds d inter of the layer above for its FFN1 group
     if (mixed) {
-      if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), c.Mb, I, H)) {                       // d inter = (d y2 . W2) * gelu'(inter): one launch
+      if (t.lean && !compact) {                                                               // ... with the 16-bit saved pre-activation
+        const void* wt;
+        if ((rc = weight16(c, t.lw(l, MANNER_HIP_WL_FF2_W), H, I, true, wk.b16, &wt))) return rc;
+        if ((rc = gemm_tn_gelu_grad16(t.dt(), h_dy2, wt, wk.zero, L.inter, b_dinter, c.Mb, I, H, c.sv.m_total, s))) return rc;
+      } else if (gelu_fused_enabled() && gemm_gelu_fusable(t.dt(), c.Mb, I, H)) {                // d inter = (d y2 . W2) * gelu'(inter): one launch
         const void* wt;
         if ((rc = weight16(c, t.lw(l, MANNER_HIP_WL_FF2_W), H, I, true, wk.b16, &wt))) return rc;
         if ((rc = gemm_tn_gelu_grad(t.dt(), h_dy2, wt, wk.zero, L.inter, b_dinter, c.Mb, I, H, c.sv.m_total, s))) return rc;
@@ -1883,13 +1927,17 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     if (aside && ao_grads && (rc = side_begin())) return rc;
     if (gl(l, MANNER_HIP_WL_AO_B) && (rc = bias_grad(w, dproj_any, g16, H, gl(l, MANNER_HIP_WL_AO_B)))) return rc;
     if (gl(l, MANNER_HIP_WL_AO_W)) {
-      const float* ctx_rows = L.ctx;
+      const void* ctx_rows = L.ctx;
+      DType ctx_dt = t.lean ? g16 : DT_F32;              // lean: ctx exists in the 16-bit type only — the operand as it lies, no conversion
       if (compact) {                                     // the [CLS] rows of ctx, gathered as in the forward
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, L.ctx, sv.cu, H, wk.dbig);
+        if (!t.lean) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, s, L.ctx, sv.cu, H, wk.dbig);
+        else if (t.dt() == DT_F16) hipLaunchKernelGGL(gather_rows16_kernel<f16_t>, dim3((unsigned)n_news), dim3(256), 0, s, reinterpret_cast<const f16_t*>(L.ctx), sv.cu, H, wk.dbig);
+        else hipLaunchKernelGGL(gather_rows16_kernel<bf16_t>, dim3((unsigned)n_news), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(L.ctx), sv.cu, H, wk.dbig);
         MANNER_LAUNCH_CHECK();
         ctx_rows = wk.dbig;
+        ctx_dt = DT_F32;
       }
-      if ((rc = linear_wgrad(w, dproj_any, g16, ctx_rows, DT_F32, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
+      if ((rc = linear_wgrad(w, dproj_any, g16, ctx_rows, ctx_dt, gl(l, MANNER_HIP_WL_AO_W), H, H, 2))) return rc;
     }
     if (aside && ao_grads && (rc = side_end(2))) return rc;
     const bool qkv_w = gl(l, MANNER_HIP_WL_Q_W) || gl(l, MANNER_HIP_WL_K_W) || gl(l, MANNER_HIP_WL_V_W) || gl(l, MANNER_HIP_WL_Q_B) ||
@@ -1901,6 +1949,8 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
       MANNER_HIP_TRY(hipMemsetAsync(wk.dx, 0, (size_t)m_bound * H * sizeof(float), s));
       hipLaunchKernelGGL(cls_bwd_kernel, dim3((unsigned)n_news), dim3(256), 0, s, wk.dqkv, sv.cu, H, wk.dx, make_drop(0, 0, 0.f));
       MANNER_LAUNCH_CHECK();
+    } else if (t.lean) {                                 // d ctx in the 16-bit type, straight into the attention backward's operand buffer
+      if ((rc = linear_dgrad(t, nullptr, t.lw(l, MANNER_HIP_WL_AO_W), wk.h16a, H, H, h_dproj, t.dt()))) return rc;
     } else if ((rc = linear_dgrad(t, mixed ? nullptr : wk.tmp, t.lw(l, MANNER_HIP_WL_AO_W), wk.dx, H, H, mixed ? h_dproj : nullptr))) {   // d ctx
       return rc;
     }
@@ -1908,8 +1958,13 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
     if ((rc = main_wait(3))) return rc;                        // b_dqkv / wk.dqkv still hold d qkv of the layer above for its Q|K|V group
     if (t.mfma_attn()) {
       // matrix-pipe backward: D = dctx . ctx and the 16-bit copy of dctx (wk.h16a is free in the backward), then d q and d k / d v
-      if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, L.ctx, L.ml, wk.dqkv, b_dqkv, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
-                                         (int)padded_len, da, m_bound, sv.m_total, s)))
+      // lean: ctx (and, but for the compact last layer, d ctx) in the 16-bit type; d qkv as 16-bit rows only
+      if (t.lean) {
+        if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, compact ? (const void*)wk.dx : (const void*)wk.h16a, !compact, L.ctx, true, L.ml, nullptr, b_dqkv,
+                                           wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H, (int)padded_len, da, m_bound, sv.m_total, s)))
+          return rc;
+      } else if ((rc = attn_train_mfma_backward(t.dt(), L.qkv, wk.dx, false, L.ctx, false, L.ml, wk.dqkv, b_dqkv, wk.h16a, wk.dsum, sv.cu, n_news, cfg->heads, H,
+                                                (int)padded_len, da, m_bound, sv.m_total, s)))
         return rc;
     } else {
 #define MANNER_ATTN_BWD(AT_, HPB_)                                                                                              \
@@ -1929,7 +1984,8 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
       const SumDst dw3{{gl(l, MANNER_HIP_WL_Q_W), gl(l, MANNER_HIP_WL_Q_W + 2), gl(l, MANNER_HIP_WL_Q_W + 4)}, H * H};
       Ctx& wq = sd ? cs : t;                                  // (the compact last layer's attention half runs on the token rows too)
       if (sd && (rc = side_begin())) return rc;
-      if ((db3.p[0] || db3.p[1] || db3.p[2]) && (rc = bias_grad(wq, wk.dqkv, DT_F32, 3 * H, nullptr, &db3))) return rc;
+      if ((db3.p[0] || db3.p[1] || db3.p[2]) &&
+          (rc = t.lean ? bias_grad(wq, b_dqkv, g16, 3 * H, nullptr, &db3) : bias_grad(wq, wk.dqkv, DT_F32, 3 * H, nullptr, &db3))) return rc;
       bool in_place = false;
       if ((rc = linear_wgrad(wq, mixed ? (const void*)b_dqkv : (const void*)wk.dqkv, g16, L.x_in, DT_F32, wk.dw, 3 * H, H, 3, &dw3, &in_place))) return rc;
       if (!in_place)

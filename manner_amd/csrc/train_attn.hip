@@ -93,6 +93,7 @@ __device__ __forceinline__ void store_rows(char* slab, const f32x16 (&o)[2], flo
   const int lane = threadIdx.x & 63, r8 = lane >> 3, c8 = lane & 7, rr = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
+    if (!dst32) break;                                       // round 5: 16-bit-only outputs (the f32 rows have no reader)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<f32x4*>(slab + rr * 128 + (((2 * g + h) ^ ((rr >> 1) & 7)) << 4)) =
@@ -225,25 +226,37 @@ __global__ __launch_bounds__(256) void attn_train_mfma_fwd_kernel(const TE* __re
 
 // ------------------------------------------------------------------------------------------------ backward pre-pass
 // dsum[m, head] = sum_d dctx[m, 64 head + d] ctx[m, 64 head + d];  dctx16 = 16-bit copy of dctx.  One wave per row.
-template <typename TE>
-__global__ __launch_bounds__(256) void attn_train_prep_kernel(const float* __restrict__ dctx, const float* __restrict__ ctx,
+// TD / TC = storage type of dctx / ctx (float or TE).  Round 5: with 16-bit saved activations ctx exists in the 16-bit type only and
+// d ctx leaves its data-gradient GEMM in the 16-bit type (TD == TE: nothing to copy, dctx16 is not written).
+template <typename T> __device__ __forceinline__ f32x4 load4f(const T* p);
+template <> __device__ __forceinline__ f32x4 load4f<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4f<f16_t>(const f16_t* p) {
+  const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <> __device__ __forceinline__ f32x4 load4f<bf16_t>(const bf16_t* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename TE, typename TD, typename TC>
+__global__ __launch_bounds__(256) void attn_train_prep_kernel(const TD* __restrict__ dctx, const TC* __restrict__ ctx,
                                                               TE* __restrict__ dctx16, float* __restrict__ dsum, int H, int heads,
                                                               const int* __restrict__ m_total) {
   typedef typename E16<TE>::v4 e16x4;
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (m >= m_total[0]) return;
-  const f32x4* a = reinterpret_cast<const f32x4*>(dctx + (size_t)m * H);
-  const f32x4* b = reinterpret_cast<const f32x4*>(ctx + (size_t)m * H);
+  const TD* a = dctx + (size_t)m * H;
+  const TC* b = ctx + (size_t)m * H;
   e16x4* o = reinterpret_cast<e16x4*>(dctx16 + (size_t)m * H);
-  const int nf = H / 4;                                      // a head = 16 consecutive float4
+  const int nf = H / 4;                                      // a head = 16 consecutive groups of 4
   for (int f0 = 0; f0 < nf; f0 += 64) {
     const int f = f0 + lane;
     float s = 0.f;
     if (f < nf) {
-      const f32x4 x = a[f], y = b[f];
+      const f32x4 x = load4f<TD>(a + 4 * f), y = load4f<TC>(b + 4 * f);
       s = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-      o[f] = e16x4{(TE)x[0], (TE)x[1], (TE)x[2], (TE)x[3]};
+      if constexpr (sizeof(TD) == 4) o[f] = e16x4{(TE)x[0], (TE)x[1], (TE)x[2], (TE)x[3]};
     }
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
@@ -485,18 +498,31 @@ int attn_train_mfma_forward(DType dt, const void* qkv16, float* ctx, void* ctx16
   return MANNER_HIP_OK;
 }
 
-int attn_train_mfma_backward(DType dt, const void* qkv16, const float* dctx, const float* ctx, const float2* ml, float* dqkv,
-                             void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H, int max_len,
-                             Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream) {
+int attn_train_mfma_backward(DType dt, const void* qkv16, const void* dctx, bool dctx_is16, const void* ctx, bool ctx_is16, const float2* ml,
+                             float* dqkv, void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H,
+                             int max_len, Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream) {
   int rc;
   if ((rc = check_shape(dt, heads, H, max_len)) || (rc = ensure_lds())) return rc;
+  if (!dqkv && !dqkv16) return fail(MANNER_HIP_E_INVALID, "attn_train_mfma_backward: no output");
+  if (dctx_is16) dctx16 = const_cast<void*>(dctx);          // d ctx arrived in the 16-bit type: it IS the operand of the two kernels
   const int64_t pairs = n_news * heads;
   const int nkt = (max_len + 31) / 32;
   const int lds_q = nkt * 4096 + 4096, lds_kv = 2 * nkt * 4096 + 4096 + 2048;
   const dim3 g((unsigned)((pairs + 3) / 4)), b(256), gp((unsigned)((m_bound + 3) / 4));
 #define MANNER_ATTN_BWD_LAUNCH(TE_, N_)                                                                                                      \
   do {                                                                                                                                       \
-    hipLaunchKernelGGL(attn_train_prep_kernel<TE_>, gp, b, 0, stream, dctx, ctx, static_cast<TE_*>(dctx16), dsum, H, heads, m_total);         \
+    if (dctx_is16 && ctx_is16)                                                                                                                \
+      hipLaunchKernelGGL((attn_train_prep_kernel<TE_, TE_, TE_>), gp, b, 0, stream, static_cast<const TE_*>(dctx), static_cast<const TE_*>(ctx), \
+                         static_cast<TE_*>(dctx16), dsum, H, heads, m_total);                                                                 \
+    else if (dctx_is16)                                                                                                                       \
+      hipLaunchKernelGGL((attn_train_prep_kernel<TE_, TE_, float>), gp, b, 0, stream, static_cast<const TE_*>(dctx), static_cast<const float*>(ctx), \
+                         static_cast<TE_*>(dctx16), dsum, H, heads, m_total);                                                                 \
+    else if (ctx_is16)                                                                                                                        \
+      hipLaunchKernelGGL((attn_train_prep_kernel<TE_, float, TE_>), gp, b, 0, stream, static_cast<const float*>(dctx), static_cast<const TE_*>(ctx), \
+                         static_cast<TE_*>(dctx16), dsum, H, heads, m_total);                                                                 \
+    else                                                                                                                                      \
+      hipLaunchKernelGGL((attn_train_prep_kernel<TE_, float, float>), gp, b, 0, stream, static_cast<const float*>(dctx), static_cast<const float*>(ctx), \
+                         static_cast<TE_*>(dctx16), dsum, H, heads, m_total);                                                                 \
     hipLaunchKernelGGL((attn_train_mfma_bwd_q_kernel<TE_, N_>), g, b, 4 * lds_q, stream, static_cast<const TE_*>(qkv16),                      \
                        static_cast<const TE_*>(dctx16), ml, dsum, dqkv, static_cast<TE_*>(dqkv16), cu, pairs, heads, H, lds_q, drop);        \
     hipLaunchKernelGGL((attn_train_mfma_bwd_kv_kernel<TE_, N_>), g, b, 4 * lds_kv, stream, static_cast<const TE_*>(qkv16),                    \

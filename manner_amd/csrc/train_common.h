@@ -50,18 +50,28 @@ int gemm_tn_gelu_dual(DType in, const void* X, const void* W, const float* bias,
                       const int* m_total, hipStream_t stream);
 int gemm_tn_gelu_grad(DType in, const void* X, const void* W, const float* zero_bias, const float* pre, void* Y16, int64_t m_bound, int N,
                       int K, const int* m_total, hipStream_t stream);
+// Round 5 (16-bit saved activations): the same pair with the pre-activation SAVED IN THE 16-BIT TYPE — what the reference's 16-mixed
+// autocast keeps for the backward (the f16 output of `intermediate.dense`; HF applies gelu to that tensor):
+//   gemm_tn_gelu_dual16 : Pre16 [m, N] = round16(X W^T + bias) and G16 [m, N] = gelu(Pre16), both of the type `in`
+//   gemm_tn_gelu_grad16 : Y16 [m, N] = round16(X W^T) * gelu'(pre16 [m, N])
+int gemm_tn_gelu_dual16(DType in, const void* X, const void* W, const float* bias, void* Pre16, void* G16, int64_t m_bound, int N, int K,
+                        const int* m_total, hipStream_t stream);
+int gemm_tn_gelu_grad16(DType in, const void* X, const void* W, const float* zero_bias, const void* pre16, void* Y16, int64_t m_bound, int N,
+                        int K, const int* m_total, hipStream_t stream);
 
 // Training attention on the matrix pipe (train_attn.hip; 16-bit modes): S <= 128 keys per news, head_dim 64, one wave per
 // (news, head).  qkv16 [m, 3H] = [Q | K | V] of the 16-bit type `dt`.
-//   forward : ctx [m, H] f32 (+ its 16-bit copy ctx16, may be NULL) = dropout(softmax(q k^T / 8)) v;  ml[m, heads] = {row max of the
-//             RAW scores q.k, sum of exp((s - max) / 8)} so that the backward rebuilds P without a reduction pass.
-//   backward: dsum[m, heads] = dctx . ctx per head and dctx16 (scratch [m_bound, H] of `dt`) first, then d qkv [m, 3H] f32 and its
-//             16-bit copy dqkv16 (may be NULL).  Dropout bits: element ((row * heads + head) * 256 + key) of `drop`'s stream.
+//   forward : ctx [m, H] f32 (may be NULL: round 5, 16-bit saved activations) and / or its 16-bit form ctx16 (may be NULL) =
+//             dropout(softmax(q k^T / 8)) v;  ml[m, heads] = {row max of the RAW scores q.k, sum of exp((s - max) / 8)} so that the
+//             backward rebuilds P without a reduction pass.
+//   backward: dsum[m, heads] = dctx . ctx per head first — dctx / ctx f32 or (`*_is16`) of the type `dt`; an f32 dctx is also copied
+//             to dctx16 (scratch [m_bound, H] of `dt`), a 16-bit one is used where it lies — then d qkv [m, 3H] as f32 rows (dqkv,
+//             may be NULL) and / or 16-bit rows (dqkv16, may be NULL).  Dropout bits: element ((row * heads + head) * 256 + key).
 int attn_train_mfma_forward(DType dt, const void* qkv16, float* ctx, void* ctx16, float2* ml, const int32_t* cu, int64_t n_news,
                             int heads, int H, int max_len, Drop drop, hipStream_t stream);
-int attn_train_mfma_backward(DType dt, const void* qkv16, const float* dctx, const float* ctx, const float2* ml, float* dqkv,
-                             void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H, int max_len,
-                             Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream);
+int attn_train_mfma_backward(DType dt, const void* qkv16, const void* dctx, bool dctx_is16, const void* ctx, bool ctx_is16, const float2* ml,
+                             float* dqkv, void* dqkv16, void* dctx16, float* dsum, const int32_t* cu, int64_t n_news, int heads, int H,
+                             int max_len, Drop drop, int64_t m_bound, const int* m_total, hipStream_t stream);
 
 // wgrad.hip: out [slices][N, K] f32 = per-slice sums over token rows of dY[m, :]^T X[m, :] (row-major 16-bit operands read
 // transposed from LDS; slices == 1 writes dW itself); N, K % 256 == 0, rows_per_slice % 32 == 0, zero_page >= 16 zero bytes

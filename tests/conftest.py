@@ -39,7 +39,12 @@ def measured(request):
     of a session are written to gpurun_out/measured_tolerances.json (scratch that travels back from the GPU box; the copy that is
     judged lives under profiles/)."""
     def record(**values):
-        _MEASURED.setdefault(request.node.name, {}).update({k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()})
+        def plain(v):
+            try:
+                return float(v)                 # python and numpy scalars alike
+            except (TypeError, ValueError):
+                return str(v)
+        _MEASURED.setdefault(request.node.name, {}).update({k: plain(v) for k, v in values.items()})
     return record
 
 

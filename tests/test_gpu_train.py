@@ -1127,3 +1127,65 @@ def test_row_panel_height_of_the_training_gemms_gives_the_same_bits(precision, m
                 assert np.allclose(g, b[1][k], rtol=1e-5, atol=1e-5 * np.abs(g).max()), (mode, k)
             else:
                 assert np.array_equal(g, b[1][k]), (mode, k)
+
+
+@pytest.mark.parametrize("precision,cos_fp32,cos_ab,rel_ab", [("f16", 0.999, 0.99999, 5e-3), ("bf16", 0.99, 0.9999, 4e-2)])
+def test_sixteen_bit_saved_activations_track_the_f32_layout_and_fp32(precision, cos_fp32, cos_ab, rel_ab, monkeypatch, measured):
+    """Round 5: in the 16-bit training modes the tensors that only GEMMs and the attention consume are saved in
+    the 16-bit type alone — ctx, the FFN pre-activation (gelu and gelu' are taken of round16(h1 W1^T + b1), as the reference's
+    `precision: 16-mixed` autocast does: configs/trainer/default.yaml:12), d ctx and d qkv (`Ctx::lean`, csrc/train.hip).  Against the
+    previous layout (MANNER_HIP_TRAIN_SAVE16=0: f32 pre-activation / ctx / d ctx / d qkv beside the 16-bit GEMM operands), same
+    weights, inputs and dropout bits: outputs and every gradient within `rel_ab` of the tensor's largest entry, cosine >= `cos_ab`
+    — a fraction of the mode's own distance from fp32, to which both are held at the mode's bar (cosine >= 0.999 f16 / 0.99 bf16).
+    The forward records its layout against the saved buffer; the backward follows the record, not the environment.
+    mini-roberta-large (256-tileable), ~4 k tokens, the persistent GEMM for every shape (what a real batch runs)."""
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")
+    cfg = PRESETS["mini-roberta-large"]
+    w = make_plm_weights(cfg, seed=77, std=0.03, with_pooler=False)
+    ids_np, mask_np = synth_news_tokens(150, cfg, seed=77, max_len=48)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    R = torch.from_numpy(np.random.default_rng(11).standard_normal((150, cfg.hidden)).astype(np.float32)).to(DEV)
+    res = {}
+    for tag, prec, save16 in (("fp32", "fp32", None), ("f32_layout", precision, "0"), ("lean", precision, None), ("lean_flipped", precision, None)):
+        if save16 is None:
+            monkeypatch.delenv("MANNER_HIP_TRAIN_SAVE16", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_TRAIN_SAVE16", save16)
+        params = _params(w)
+        out = train.encode_train(cfg, params, ids, mask, precision=prec, p_hidden=0.1, p_attn=0.1, p_out=0.2, seed=12, token_bound=int(mask_np.sum()))
+        if tag == "lean_flipped":                                  # the backward must read the FORWARD's layout
+            monkeypatch.setenv("MANNER_HIP_TRAIN_SAVE16", "0")
+        (out * R).sum().backward()
+        res[tag] = (out.detach().cpu().numpy().astype(np.float64), _grads(params))
+    monkeypatch.delenv("MANNER_HIP_TRAIN_SAVE16", raising=False)
+    hip.check_status(DEV)
+    assert np.array_equal(res["lean"][0], res["lean_flipped"][0])
+    for k, g in res["lean"][1].items():
+        if k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):        # f32 atomics: run-to-run order
+            assert np.allclose(g, res["lean_flipped"][1][k], rtol=1e-5, atol=1e-5 * np.abs(g).max()), k
+        else:
+            assert np.array_equal(g, res["lean_flipped"][1][k]), k
+    scale = np.abs(res["fp32"][0]).max()
+    e_ab = np.abs(res["lean"][0] - res["f32_layout"][0]).max() / scale
+    e_32 = np.abs(res["lean"][0] - res["fp32"][0]).max() / scale
+    assert e_ab <= rel_ab and e_32 <= (2e-2 if precision == "f16" else 1e-1), (e_ab, e_32)
+    worst_ab, worst_32 = (0.0, 1.0, ""), (1.0, "")
+    for k, g32 in res["fp32"][1].items():
+        if g32 is None or k.endswith("key.bias"):                 # d key-bias is zero in exact arithmetic: rounding residue on every path
+            continue
+        a, b, c = (res[t][1][k].ravel().astype(np.float64) for t in ("lean", "f32_layout", "fp32"))
+        if np.abs(c).max() < 1e-7:
+            continue
+        cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-300))      # noqa: E731
+        e = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+        if e > worst_ab[0]:
+            worst_ab = (e, cos(a, b), k)
+        if cos(a, c) < worst_32[0]:
+            worst_32 = (cos(a, c), k)
+        assert e <= rel_ab and cos(a, b) >= cos_ab, (k, e, cos(a, b))
+        assert cos(a, c) >= cos_fp32, (k, cos(a, c))
+    print(f"{precision}: lean vs f32 layout: outputs {e_ab:.2e}, worst gradient {worst_ab[2]} rel-to-max {worst_ab[0]:.3e} cosine {worst_ab[1]:.7f}; "
+          f"lean vs fp32: outputs {e_32:.2e}, lowest gradient cosine {worst_32[0]:.6f} ({worst_32[1]})")
+    measured(bound_rel_vs_f32_layout=rel_ab, bound_cos_vs_f32_layout=cos_ab, bound_cos_vs_fp32=cos_fp32, outputs_rel_vs_f32_layout=e_ab,
+             outputs_rel_vs_fp32=e_32, worst_rel_vs_f32_layout=worst_ab[0], cosine_of_that_tensor=worst_ab[1], tensor=worst_ab[2],
+             lowest_cosine_vs_fp32=worst_32[0], tensor_vs_fp32=worst_32[1])
