@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 6
+#define MANNER_HIP_ABI_VERSION 7
 
 enum {
   MANNER_HIP_OK = 0,
@@ -411,6 +411,15 @@ int manner_hip_eval_loss(const float* scores, const float* labels, const int64_t
  * the last bits, vary between runs — as torch's CUDA embedding backward). */
 size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer);
 size_t manner_hip_train_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t m_bound);
+/* ABI v7 — the bytes manner_hip_train_forward needs for `saved` IN THE GIVEN PRECISION (never more than the function above, which
+ * stays valid for every mode).  Round 5: in the 16-bit modes the tensors that only GEMMs and the attention consume — Q | K | V, the
+ * attention output, the FFN pre-activation and its gelu — are saved in the 16-bit type alone (what the reference's
+ * `precision: 16-mixed` autocast keeps: configs/trainer/default.yaml:12), 31 instead of 49 KB per token and layer for bert-base.
+ * Evaluate it right before the forward call: the layout follows the same rule the forward applies (matrix-pipe attention and fused
+ * GeLU epilogues available for the shape; MANNER_HIP_TRAIN_SAVE16=0 keeps the f32 layout); a forward whose rule asks for more than
+ * it was given fails with MANNER_HIP_E_WORKSPACE, it never overruns. */
+size_t manner_hip_train_saved_bytes_for(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer,
+                                        int32_t precision);
 /* ABI v5 — optional cache of the 16-bit weight copies the 16-bit training modes make on every call (round 4).  Registers, for the NEXT
  * manner_hip_train_forward / _backward call of THIS thread (consumed by it; ignored in fp32 mode), 2 * n_weights caller-owned device
  * buffers (host array `slots`, entries may be NULL = not cached) and as many host flags `valid` (in / out):

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
@@ -72,6 +72,7 @@ SIGNATURES = {
     "manner_hip_auc": (C.c_int, [_P, _P, _I64, _I32, _P, _SZ, _P, _P, _P]),
     "manner_hip_eval_loss": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _I64, _P, _P]),
     "manner_hip_train_saved_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64, _I32]),
+    "manner_hip_train_saved_bytes_for": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64, _I32, _I32]),
     "manner_hip_train_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64]),
     "manner_hip_train_weight_cache": (C.c_int, [C.POINTER(_P), C.POINTER(_I32), _I32]),
     "manner_hip_train_forward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _P,

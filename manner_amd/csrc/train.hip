@@ -945,7 +945,9 @@ struct Saved {
   float2* st0;
   LayerSaved l[64];
 };
-void plan_saved(Bump& b, Saved& s, const manner_hip_encoder_config& c, int64_t N, int64_t Mb, int start) {
+// lean (round 5, Ctx::lean): Q | K | V, ctx, the FFN pre-activation and its gelu exist in the 16-bit type only — their slots of every
+// layer but the last (whose compact [CLS] tail keeps f32 tensors) are half the size: 31 instead of 49 KB per token and layer (bert-base)
+void plan_saved(Bump& b, Saved& s, const manner_hip_encoder_config& c, int64_t N, int64_t Mb, int start, bool lean = false) {
   const size_t H = c.hidden, I = c.intermediate;
   s.lens = b.take<int32_t>(N);
   s.cu = b.take<int32_t>(N + 1);
@@ -954,13 +956,14 @@ void plan_saved(Bump& b, Saved& s, const manner_hip_encoder_config& c, int64_t N
   s.st0 = start == 0 ? b.take<float2>(Mb) : nullptr;
   for (int l = start; l < c.layers; ++l) {
     LayerSaved& L = s.l[l];
+    const size_t half = (lean && l + 1 < c.layers) ? 2 : 1;           // 16-bit tensors in f32-typed slots (H, I even)
     L.x_in = b.take<float>(Mb * H);
-    L.qkv = b.take<float>(Mb * 3 * H);
-    L.ctx = b.take<float>(Mb * H);
+    L.qkv = b.take<float>(Mb * 3 * H / half);
+    L.ctx = b.take<float>(Mb * H / half);
     L.r1 = b.take<float>(Mb * H);
     L.h1 = b.take<float>(Mb * H);
-    L.inter = b.take<float>(Mb * I);
-    L.g = b.take<float>(Mb * I);
+    L.inter = b.take<float>(Mb * I / half);
+    L.g = b.take<float>(Mb * I / half);
     L.r2 = b.take<float>(Mb * H);
     L.st1 = b.take<float2>(Mb);
     L.st2 = b.take<float2>(Mb);
@@ -1415,7 +1418,8 @@ static WCacheArg take_wcache() {
 }
 
 int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weights, int32_t n_weights, int64_t N, int64_t Lp, int64_t Mb,
-          int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s, const WCacheArg& wc) {
+          int32_t precision, int start, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, hipStream_t s, const WCacheArg& wc,
+          bool lean_layout) {
   int rc;
   if ((rc = check_cfg(cfg, N, Lp, Mb, precision, start))) return rc;
   if (!weights || n_weights != MANNER_HIP_W_EMB_COUNT + cfg->layers * MANNER_HIP_WL_COUNT)
@@ -1432,7 +1436,7 @@ int setup(Ctx& t, const manner_hip_encoder_config* cfg, const float* const* weig
     t.wc_n = wc.n;
   }
   Bump bs(saved), bw(ws);
-  plan_saved(bs, t.sv, *cfg, N, Mb, start);
+  plan_saved(bs, t.sv, *cfg, N, Mb, start, lean_layout);
   plan_work(bw, t.wk, *cfg, Mb);
   if (bs.off > saved_bytes) return fail(MANNER_HIP_E_WORKSPACE, "train: saved buffer %zu < %zu bytes", saved_bytes, bs.off);
   if (bw.off > ws_bytes) return fail(MANNER_HIP_E_WORKSPACE, "train: workspace %zu < %zu bytes", ws_bytes, bw.off);
@@ -1564,6 +1568,16 @@ size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_
   return b.off + 256;
 }
 
+size_t manner_hip_train_saved_bytes_for(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer,
+                                        int32_t precision) {
+  if (!cfg || n_news <= 0 || m_bound <= 0 || start_layer < 0 || start_layer >= cfg->layers || cfg->layers > 64) return 0;
+  const bool lean = choose_lean(cfg, precision, m_bound, choose_attn_path(cfg, precision, false));
+  Bump b(nullptr);
+  Saved s;
+  plan_saved(b, s, *cfg, n_news, m_bound, start_layer, lean);
+  return b.off + 256;
+}
+
 size_t manner_hip_train_workspace_bytes(const manner_hip_encoder_config* cfg, int64_t m_bound) {
   if (!cfg || m_bound <= 0) return 0;
   Bump b(nullptr);
@@ -1678,12 +1692,15 @@ static int train_forward_impl(const manner_hip_encoder_config* cfg, const float*
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
+  // the attention path and the saved-tensor layout are decided BEFORE the buffers are planned (the layout sizes the slots)
+  const bool mfma_rule = cfg && choose_attn_path(cfg, precision, full);
+  const bool lean_rule = cfg && m_bound > 0 && choose_lean(cfg, precision, m_bound, mfma_rule);
   if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
-                  workspace_bytes, s, wc)))
+                  workspace_bytes, s, wc, lean_rule)))
     return rc;
   if (!ids || !mask || !cls_out) return fail(MANNER_HIP_E_INVALID, "train_forward: null pointer");
-  t.attn_mfma = choose_attn_path(cfg, precision, full);
-  t.lean = choose_lean(cfg, precision, m_bound, t.attn_mfma);
+  t.attn_mfma = mfma_rule;
+  t.lean = lean_rule;
   record_attn_path(saved, t.attn_mfma, t.lean);
   if ((start_layer > 0) != (prefix_hidden != nullptr))
     return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
@@ -1746,14 +1763,17 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
+  bool mfma_rec = false, lean_rec = false;               // what the forward of this buffer chose (it sized the slots by it)
+  if (cfg && m_bound > 0) {
+    const bool rule = choose_attn_path(cfg, precision, full);
+    mfma_rec = recorded_attn_path(saved, rule, choose_lean(cfg, precision, m_bound, rule), &lean_rec);
+  }
   if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
-                  workspace_bytes, s, wc)))
+                  workspace_bytes, s, wc, lean_rec)))
     return rc;
   if (!ids || !grad_cls || !grads) return fail(MANNER_HIP_E_INVALID, "train_backward: null pointer");
-  {                                                      // what the forward of this buffer chose
-    const bool rule = choose_attn_path(cfg, precision, full);
-    t.attn_mfma = recorded_attn_path(saved, rule, choose_lean(cfg, precision, m_bound, rule), &t.lean);
-  }
+  t.attn_mfma = mfma_rec;
+  t.lean = lean_rec;
   if (t.attn_mfma && (precision == MANNER_HIP_PREC_F32 || full)) return fail(MANNER_HIP_E_INVALID, "train_backward: the forward of this saved buffer ran another precision / row layout");
   if (grad_prefix && start_layer == 0) return fail(MANNER_HIP_E_INVALID, "train_backward: grad_prefix goes with start_layer > 0");
   const int H = cfg->hidden, I = cfg->intermediate;

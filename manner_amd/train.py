@@ -150,7 +150,7 @@ class _EncodeTrain(torch.autograd.Function):
         cc = _cfg_c(cfg)
         dev = ids.device
         with torch.cuda.device(dev):
-            saved = torch.empty(int(lib.manner_hip_train_saved_bytes(C.byref(cc), n, m_bound, start)), dtype=torch.uint8, device=dev)
+            saved = torch.empty(int(lib.manner_hip_train_saved_bytes_for(C.byref(cc), n, m_bound, start, prec)), dtype=torch.uint8, device=dev)
             ws = torch.empty(int(lib.manner_hip_train_workspace_bytes(C.byref(cc), m_bound)), dtype=torch.uint8, device=dev)
             out = torch.empty((n, cfg.hidden), dtype=torch.float32, device=dev)
             weights = [p.detach() for p in params]

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 18 and set(syms) == set(_lib.SIGNATURES)
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
-    assert lib.manner_hip_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.manner_hip_abi_version() == _lib.ABI_VERSION == 7
     assert lib.manner_hip_encoder_workspace_bytes(None, 1, 1, 0) == 0          # null handle: no crash
 
 
