@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma, int H,
                                                      float* dx, float* __restrict__ pgamma, float* __restrict__ pbeta,
                                                      const int* __restrict__ m_total, Drop drop, Out16 d16,
-                                                     const int32_t* __restrict__ rowmap) {
+                                                     const int32_t* __restrict__ rowmap, int pstride) {
   __shared__ __attribute__((aligned(16))) float red[4][64 * LN_MAX + 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t M = m_total[0];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 #pragma unroll
     for (int i = 0; i < NV4; ++i) *reinterpret_cast<f32x4*>(&red[wave][4 * (lane + 64 * i)]) = pass ? ab[i] : ag[i];
     __syncthreads();
-    float* dst = (pass ? pbeta : pgamma) + (size_t)blockIdx.x * H;
+    float* dst = (pass ? pbeta : pgamma) + (size_t)blockIdx.x * pstride;      // row `block` of the partials: [d gamma | d beta] side by side
     for (int c = threadIdx.x; c < H; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
   }
 }
@@ -1318,16 +1318,16 @@ int linear_fwd_drop_res(Ctx& t, const float* X, const void* X16, const float* W,
 int ln_backward(Ctx& t, const float* dy, const float* x, const float2* st, const float* gamma, float* dx, float* dgamma, float* dbeta,
                 Drop drop = Drop{0, 0, 0, 1.f}, void* d16 = nullptr, const int32_t* rowmap = nullptr) {
   const int H = t.c->hidden;
+  // partial rows [block][d gamma (H) | d beta (H)]: ONE fixed-order reduction writes both parameter gradients (round 5; two launches
+  // of 18 us each before — same sums in the same order)
   float* pg = dgamma ? t.wk.part : nullptr;
-  float* pb = dgamma ? t.wk.part + (size_t)LN_BWD_BLOCKS * H : nullptr;
+  float* pb = dgamma ? t.wk.part + H : nullptr;
   // H <= 768 (bert-base): three float4 pieces per lane instead of four — 36 registers fewer, one more wave per SIMD
-  if (H <= 768) hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap);
-  else hipLaunchKernelGGL(ln_bwd_kernel<LN_V4>, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap);
+  if (H <= 768) hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap, 2 * H);
+  else hipLaunchKernelGGL(ln_bwd_kernel<LN_V4>, dim3(LN_BWD_BLOCKS), dim3(256), 0, t.s, dy, x, st, gamma, H, dx, pg, pb, t.sv.m_total, drop, t.o16(d16), rowmap, 2 * H);
   MANNER_LAUNCH_CHECK();
   if (dgamma) {
-    reduce_partials(t.s, pg, LN_BWD_BLOCKS, H, dgamma);
-    MANNER_LAUNCH_CHECK();
-    reduce_partials(t.s, pb, LN_BWD_BLOCKS, H, dbeta);
+    reduce_partials(t.s, pg, LN_BWD_BLOCKS, 2 * H, SumDst{{dgamma, dbeta, nullptr}, H});
     MANNER_LAUNCH_CHECK();
   }
   return MANNER_HIP_OK;
