@@ -166,7 +166,9 @@ __device__ __forceinline__ void lds_read128(f16x8& d, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 
-template <int KS, int NW, int R, int SPS>
+// PROD (lab, MANNER_HIP_POOL_PRODUCER=1 — round 5's producer / consumer experiment, TIMING ONLY: the last wave's strip is not computed):
+// the last wave of the workgroup issues EVERY LDS-DMA piece of the ring and runs no matrix work; the other waves never issue.
+template <int KS, int NW, int R, int SPS, bool PROD = false>
 __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
     const float* __restrict__ x, const f16x8* __restrict__ Wp, const float2* __restrict__ bq, const int32_t* __restrict__ kw_p, int n_pass,
     int n_tiles, int64_t B, int S, int SP, float* __restrict__ out, unsigned long long* __restrict__ diag) {
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
   static_assert(KS % SPS == 0 && KST % R == 0, "the ring stage of a step must not depend on the pass");
   static_assert(4 * NW * D * 4 <= R * STAGE, "the partial sums (4 lane groups per wave) reuse the ring");
   static_assert((R - 1) * (P_LO + 1) < 60, "vmcnt is a 6-bit counter");
+  static_assert(!PROD || (R - 2) * PCS < 60, "the producer keeps R - 2 whole stages in flight");
   __shared__ __attribute__((aligned(1024))) char ring[R * STAGE];
   __shared__ float2 bq_s[PF_MAX_PASS * TP * 16];
   __shared__ float lg[NW * 16];
@@ -192,9 +195,17 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
   const int total = n_pass * KST;                       // ring steps (stages)
   const uint32_t ring_lds = (uint32_t)(size_t)LDS_PTR(ring);      // the ring's byte address inside LDS
 
+  const bool is_prod = PROD && wave == NW - 1;
   auto issue = [&](int gs) {                            // this wave's LDS-DMA pieces of ring step gs
     const char* src = reinterpret_cast<const char*>(Wp) + (size_t)gs * STAGE + lane * 16;
     char* dst = ring + (gs % R) * STAGE;
+    if (PROD) {
+      if (!is_prod) return;
+#pragma unroll 1
+      for (int pc = 0; pc < PCS; ++pc)
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + pc * 1024), LDS_PTR(dst + pc * 1024), 16, 0, 0);
+      return;
+    }
     for (int pc = wave; pc < PCS; pc += NW)
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + pc * 1024), LDS_PTR(dst + pc * 1024), 16, 0, 0);
   };
@@ -263,7 +274,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
       const int gs = pass * KST + u;
       PD_A();
       // this wave's pieces of stage gs have landed (the pieces of the R - 2 younger stages may fly)
-      if (gs + R - 1 < total) {
+      if (PROD) {
+        // consumers hold no DMA of their own
+      } else if (gs + R - 1 < total) {
         if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * (P_LO + 1)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * P_LO) : "memory");
       } else {
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
       // The stage of ring step gs - 1 (nobody reads it any more) takes step gs + R - 1.  8-wave workgroups: the two waves of a SIMD (w and
       // w + 4) issue their LDS-DMA pieces at OPPOSITE ends of the stage — waves 4-7 here, waves 0-3 after the matrix work — so that one
       // partner's issue time lies under the other's MFMAs instead of both stalling the pipe at the same moment.
-      const bool early = POOL_EARLY_ALL || (NW == 8 && wave >= 4);
+      const bool early = PROD || POOL_EARLY_ALL || (NW == 8 && wave >= 4);
       if (early && gs + R - 1 < total) issue(gs + R - 1);
       PD_B(2);
 #pragma unroll
@@ -323,6 +336,16 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_fused_kernel(
       }
     }
   };
+  if (is_prod) {
+    // the producer's whole pass phase: per ring step wait for its pieces, meet the consumers at their barrier, refill the freed stage
+#pragma unroll 1
+    for (int gs = 0; gs < total; ++gs) {
+      if (gs + R - 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * PCS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (gs + R - 1 < total) issue(gs + R - 1);
+    }
+  } else
 #pragma unroll 1
   for (int pass = 0; pass < n_pass; ++pass) {
     const int nsl = n_tiles - pass * TP;                // unit tiles left
@@ -436,7 +459,12 @@ int pool_fused(const float* x, const float* W, const float* bias, const float* q
   if (const char* de = getenv("MANNER_HIP_POOL_DIAG")) diag = reinterpret_cast<unsigned long long*>(strtoull(de, nullptr, 0));
 #endif
   const char* nw_env = getenv("MANNER_HIP_POOL_NW");
-  if (sp <= 4 && nw_env && atoi(nw_env) == 4) {
+  const char* prod_env = getenv("MANNER_HIP_POOL_PRODUCER");
+  if (prod_env && atoi(prod_env) == 1) {             // lab: producer / consumer timing experiment (wrong results for the last wave's strip)
+    const int bpw = 8 / sp;
+    hipLaunchKernelGGL((pool_fused_kernel<24, 8, 3, 4, true>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(512), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
+                       (int)S, sp, out, diag);
+  } else if (sp <= 4 && nw_env && atoi(nw_env) == 4) {
     const int bpw = 4 / sp;
     hipLaunchKernelGGL((pool_fused_kernel<24, 4, 3, 2>), dim3((unsigned)((B + bpw - 1) / bpw)), dim3(256), 0, stream, x, Wp, bq, kw, n_pass, n_tiles, B,
                        (int)S, sp, out, diag);
