@@ -1478,7 +1478,7 @@ def main():
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs; bench.py cannot collect counters itself): the newest profiles/r*_final/pmc_traffic.json
         traffic, traffic_src = None, None
-        for rdir in ("r4_final", "r3_final", "r2_final", "r1_final"):
+        for rdir in ("r5_final", "r4_final", "r3_final", "r2_final", "r1_final"):
             tpath = os.path.join(ROOT, "profiles", rdir, "pmc_traffic.json")
             if os.path.exists(tpath) and args.chunk_tokens == 65536 and model == "bert-base-uncased" and args.precision in ("bf16", "f16"):
                 with open(tpath) as f:

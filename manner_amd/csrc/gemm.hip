@@ -885,14 +885,16 @@ struct DlnAux {
 // whole tile times, so 61 row panels x N = 768 (183 tiles of 256 rows) are ONE round with 73 of 256 CUs idle — while the same rows
 // as 82 panels of 192 rows are 246 tiles: one round of three-quarter tiles.  A row's result does not depend on the panel height (per
 // output element the same sequence of matrix instructions over K), so the choice is free of numerical consequences: both bodies give
-// the same BITS (tests/test_gpu_parity.py holds them to torch.equal).  A 192-row tile costs ~0.8 of a 256-row tile (the weight half
-// of its DMA and LDS traffic does not shrink); 192 wins when its rounds x 0.8 undercut the 256-row rounds by at least 3 %.
+// the same BITS (tests/test_gpu_parity.py holds them to torch.equal).  A 192-row tile costs 0.80 - 0.85 of a 256-row tile (measured,
+// tools/panel_probe.py: out-projection 38.1 -> 30.3 us, FFN2 95 -> 77 us, Q|K|V 76.4 -> 65.2 us at 15.6 k tokens; the weight half of its
+// DMA and LDS traffic does not shrink); 192 wins when its rounds x 0.83 undercut the 256-row rounds by at least 3 % — in practice when
+// both heights need the same number of rounds.
 __host__ __device__ inline int panel_rows(int M, int n_tiles, int cus, int mode) {
   if (mode == 1) return 256;
   if (mode == 2) return 192;
   const int t256 = ((M + 255) / 256) * n_tiles, t192 = ((M + 191) / 192) * n_tiles;
   const int r256 = (t256 + cus - 1) / cus, r192 = (t192 + cus - 1) / cus;
-  return r192 * 80 < r256 * 97 ? 192 : 256;
+  return r192 * 83 < r256 * 97 ? 192 : 256;
 }
 
 // MBT = 16-row MFMA token blocks per wave: 8 (256-row tile, wave tile 128 x 64) or 6 (192-row tile, wave tile 96 x 64).  The weight

@@ -27,12 +27,13 @@ CLASSES = [   # (class, substrings that must all occur in the kernel name)
     ("rank_ndcg", ["rank_ndcg_kernel"]),
 ]
 # rocprofv3 prints some instantiations half-demangled; EPI_NRES appears as "<bool _Accum, int, ELi0E>"
-TEMPLATE_HINTS = {"Li3ELi0E": ", 3, 0>", "Li4ELi0E": ", 4, 0>", "Li5ELi0E": "int, ELi0E>"}
+# (round 5: the kernel has a fifth template argument — `, 3, 0, true>` / `Li3ELi0ELb1E`; the mangled substrings still match)
+TEMPLATE_HINTS = {"Li3ELi0E": (", 3, 0>", ", 3, 0, true>"), "Li4ELi0E": (", 4, 0>", ", 4, 0, true>"), "Li5ELi0E": ("int, ELi0E>", ", 5, 0, true>", "int, ELi0ELb1E>")}
 
 
 def classify(name):
     for cls, subs in CLASSES:
-        if all(s in name or TEMPLATE_HINTS.get(s, "\0") in name for s in subs):
+        if all(s in name or any(h in name for h in TEMPLATE_HINTS.get(s, ())) for s in subs):
             return cls
     return None
 
