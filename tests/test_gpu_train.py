@@ -210,6 +210,8 @@ def test_transposed_read_weight_gradient_equals_the_transposing_path(precision, 
         assert np.abs(x - y).max() <= 1e-4 * max(np.abs(y).max(), 1e-6), (k, np.abs(x - y).max(), np.abs(y).max())
 
 
+# bound vs MEASURED (round 5, profiles/r5_final/measured_tolerances.json — the `measured` fixture rewrites it on every GPU run):
+#   f16 : rel-to-max 2e-2 vs 1.8e-3, cosine 0.9999 vs 0.999999      bf16: rel-to-max 8e-2 vs 1.3e-2, cosine 0.999 vs 0.99994
 @pytest.mark.parametrize("precision,rel,cos_min", [("f16", 2e-2, 0.9999), ("bf16", 8e-2, 0.999)])
 def test_matrix_pipe_training_attention_tracks_the_valu_kernels(precision, rel, cos_min, monkeypatch, measured):
     """the matrix-pipe training attention (train_attn.hip; 16-bit Q | K | V, probabilities rounded to 16 bits for the P.V
@@ -346,6 +348,9 @@ def test_frozen_weight_copy_cache_is_bit_identical_and_follows_weight_updates(pr
     assert len(train._WCACHE) == 0
 
 
+# bound vs MEASURED (round 5, profiles/r5_final/measured_tolerances.json):
+#   bf16: rel-to-max 3e-2 vs 1.15e-2, cosine 0.9999 vs 0.99997 (round 4 widened 0.99999 -> 0.9999 after reading 0.99997)
+#   f16 : rel-to-max 1e-2 vs 1.9e-3,  cosine 0.99999 vs 0.9999996
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_gelu_inside_the_ffn_gemms_tracks_the_separate_kernels(precision, monkeypatch, measured):
     """Round 4: in the 16-bit modes FFN1 writes the saved f32 pre-activation AND its 16-bit gelu from one GEMM
