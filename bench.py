@@ -238,7 +238,7 @@ def cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp, pool, dev
         return f64_cache[i]
 
     par = {}
-    for prec in dict.fromkeys(("fp32",) + (("f16x3",) if len(encs) == 1 else ()) + (args.precision, "f16", "bf16")):
+    for prec in dict.fromkeys(("fp32", PARITY_GRADE, args.precision, "f16", "bf16")):
         scores, topk, ndcg = run_step(encs, b, prec, args.chunk_tokens, bufs, planes, fuse_w)
         top = [[v for v in row if v >= 0] for row in topk.cpu().tolist()]
         same = [t == r for t, r in zip(top, ref_top)]
