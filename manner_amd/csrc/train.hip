@@ -1388,7 +1388,6 @@ static bool choose_attn_path(const manner_hip_encoder_config* c, int32_t precisi
   const bool valu = v && *v && *v != '0';
   return precision != MANNER_HIP_PREC_F32 && !valu && !full && c->hidden == c->heads * 64;   // the MFMA kernels are written for head_dim 64
 }
-static bool gelu_fused_enabled();
 static bool choose_lean(const manner_hip_encoder_config* c, int32_t precision, int64_t Mb, bool mfma) {
   const char* v = getenv("MANNER_HIP_TRAIN_SAVE16");                       // read per call: the tests compare both layouts in one process
   const bool off = v && *v == '0';
