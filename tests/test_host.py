@@ -693,3 +693,16 @@ def test_bench_final_line_is_compact_strict_json(tmp_path, capsys):
     line2 = bench.compact_line(result)
     j2 = json.loads(line2, parse_constant=reject)
     assert len(line2.encode()) < 8192 and {"config", "roofline", "cpu_baseline"} <= set(j2) and "kernel_avg_us" not in j2.get("legs", {})
+
+
+def test_segment_offsets_without_a_host_read():
+    """hotpath.segment_offsets: sorted segment ids -> CSR offsets by a search over the sorted ids (round 5: torch.bincount, used before,
+    reads the maximum back to the host — a full device wait in the middle of a training step).  Same offsets as the counting form,
+    with empty segments in front, in the middle and at the end."""
+    from manner_amd.hotpath import segment_offsets
+    g = np.random.default_rng(3)
+    for counts in ([3, 0, 2, 5, 0, 0], [0, 0, 4], [1], [7, 1, 1, 0], list(g.integers(0, 9, 40))):
+        ids = torch.from_numpy(np.repeat(np.arange(len(counts)), counts).astype(np.int64))
+        off = segment_offsets(ids, len(counts))
+        assert off.dtype == torch.int64 and off.tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+    assert segment_offsets(torch.zeros(0, dtype=torch.int64), 3).tolist() == [0, 0, 0, 0]
