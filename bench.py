@@ -518,13 +518,20 @@ def train_leg(cfg, dev, precision, impressions=32, neg=4, frozen=(0, 1, 2, 3, 4,
             torch.cuda.synchronize()
             per_step.append(time.perf_counter() - t0)
         dt = float(np.median(per_step))                  # median of per-step wall times: one allocator hiccup does not define the figure
+        # the same steps back to back with ONE synchronisation at the end — what a training loop that does not read the loss every step
+        # sees (Lightning logs every 50 steps): the host runs ahead and the enqueue latency at the step boundaries hides under GPU work
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        dt_pipe = (time.perf_counter() - t0) / steps
         # algorithmic FLOPs: forward of every layer that runs in train() arithmetic, + the data-gradient pass of every layer the
         # activation gradient crosses, + the weight-gradient pass of the trainable layers (each pass = one forward's FLOPs)
         first_trainable = min(l for l in range(cfg.layers) if l not in frozen)
         per_layer = float(sum(cfg.flops_per_news(int(n)) for n in mask_np.sum(1))) / cfg.layers
         passes = (cfg.layers * 2 + (cfg.layers - first_trainable)) if emb_trainable else (cfg.layers - first_trainable) * 3
         flops = per_layer * passes
-        out[variant] = {"ms_per_step": dt * 1e3, "tokens_per_s": tokens / dt, "news_per_s": (n_hist + n_cand) / dt,
+        out[variant] = {"ms_per_step": dt * 1e3, "ms_per_step_unsynchronised_loop": dt_pipe * 1e3, "tokens_per_s": tokens / dt, "news_per_s": (n_hist + n_cand) / dt,
                         "tflops_algorithmic": flops / dt / 1e12, "frac_of_mfma_peak": flops / dt / 1e12 / (F32_PEAK_TFLOPS if precision == "fp32" else BF16_PEAK_TFLOPS),
                         "impressions_per_s": impressions / dt, "step_ms_each": [round(x * 1e3, 2) for x in per_step],
                         "loss_first_step": first, "loss_last_step": float(last.detach()),

@@ -23,5 +23,5 @@ if os.environ.get("TRAIN_PROBE_NODROP"):            # what the counter-based dro
 only = os.environ.get("TRAIN_PROBE_VARIANT")          # e.g. reference_default_embeddings_trainable: one variant, for a profile of it alone
 out = bench.train_leg(PRESETS["bert-base-uncased"], torch.device("cuda", 0), prec, only=(only,) if only else None,
                       steps=int(os.environ.get("TRAIN_PROBE_STEPS", "5")))
-print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "step_ms_each", "peak_GB")} if isinstance(v, dict) else v)
+print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "ms_per_step_unsynchronised_loop", "step_ms_each", "peak_GB")} if isinstance(v, dict) else v)
                   for k, v in out.items() if k != "what"}))
