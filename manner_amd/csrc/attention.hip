@@ -354,6 +354,217 @@ __device__ __forceinline__ void attn_wave_f32(const float* __restrict__ qkv, flo
   }
 }
 
+// ---- f16x3 attention (round 5): the structure of attn_wave_f32 — f32 Q | K | V rows in, f32 softmax, the out-projection's split
+// operand out — with BOTH products as split (x3) f16 products on the 16-bit matrix pipe instead of v_mfma_f32_32x32x2_f32 (4x slower per
+// FLOP and 32 instructions per 32 x 32 score tile): every f32 value v is used as hi = f16(v), lo = f16(v - hi) and a product a.b as
+// a.hi b.hi + a.hi b.lo + a.lo b.hi (f32 accumulation; the dropped lo.lo term is 2^-22 relative — the arithmetic of the mode's GEMMs).
+//   S^T = K Q^T : lane (row rr, half h) holds the 32 features 32h .. 32h+31 of its K / Q row (tile_to_frag of the f32 kernel); MFMA step
+//                 s takes elements 8s .. 8s+7 of both halves — the k-set {8s..8s+7} u {32+8s..32+8s+7}, the same for K and Q, which is
+//                 just another summation order; 12 v_mfma_f32_32x32x16_f16 per score tile.
+//   O^T = V^T P^T: V is split when it is loaded (f32 rows -> registers -> two row-major 16-bit LDS images, hi and lo: the same bytes as
+//                 the f32 kernel's one f32 image) and read key-permuted and transposed with ds_read_b64_tr_b16 exactly as in
+//                 attn_wave_bf16; the softmax numerators, split in the accumulator layout, are the B operand; 12 MFMAs per key tile.
+// |q|, |k|, |v| of an encoder are O(1..50): far inside f16's range, low parts of values below 1e-4 keep 3e-8 absolute (subnormals).
+template <int NKT>
+__device__ __forceinline__ void attn_wave_x3(const float* __restrict__ qkv, int tok0, int L, int H, int head, char* vl,
+                                             f16_t* __restrict__ a3) {
+  const int lane = threadIdx.x & 63, rr = lane & 31, h = lane >> 5;
+  char* vhi = vl;                                  // [32 NKT keys][64] f16, row-major 128-byte rows
+  char* vlo = vl + NKT * 32 * 128;
+  char* ol = vl + NKT * 32 * 256;                  // 8 KiB slab (32 rows x 256 B) behind the two V images
+  const size_t ld = 3 * (size_t)H;
+  const float* Qb = qkv + (size_t)tok0 * ld + head * 64;
+  const float* Kb = Qb + H;
+  const float* Vb = Qb + 2 * H;
+  const int r4 = lane >> 4, c16 = lane & 15;      // coalesced piece: row r4 of a 4-row group, 16-byte chunk c16 of 16
+  // the K tiles and the first Q block are requested before anything waits for a load (the kernel is latency-bound: 4 waves per CU);
+  // 8 x 16 bytes per lane and tile.  (All V tiles in flight as well: 150 spilled registers in the four-tile body.)
+  f32x4 kt_[NKT <= 3 ? NKT : 1][8], qt_[8];
+  auto tile_load = [&](const float* base, int row0, bool swz, f32x4 (&t)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(row0 + 4 * i + r4, L - 1);
+      t[i] = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + 4 * (swz ? (c16 ^ ((4 * i + r4) & 15)) : c16));
+    }
+  };
+  constexpr bool PRELOAD = NKT <= 3;               // four K tiles in flight next to everything else do not fit the register file
+#pragma unroll
+  for (int kt = 0; kt < (PRELOAD ? NKT : 1); ++kt) tile_load(Kb, 32 * kt, true, kt_[kt]);
+  tile_load(Qb, 0, true, qt_);
+  // a loaded 32-row tile of K or Q: rows -> slab (16-byte chunks XOR-swizzled with row & 15) -> lane (rr, h) takes the 32 features
+  // 32h .. 32h+31 of row rr and splits them: fh[s] / fl[s] = elements 8s .. 8s+7
+  auto tile_to_split = [&](const f32x4 (&t)[8], f16x8 (&fh)[4], f16x8 (&fl)[4]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(ol + (4 * i + r4) * 256 + (c16 << 4)) = t[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ol + rr * 256 + (((8 * h + 2 * s) ^ (rr & 15)) << 4));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ol + rr * 256 + (((8 * h + 2 * s + 1) ^ (rr & 15)) << 4));
+      f16x8 hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = (f16_t)a[e]; hi[4 + e] = (f16_t)b[e]; }
+      asm volatile("" : "+v"(hi));
+      f16x8 lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = (f16_t)(a[e] - (float)hi[e]); lo[4 + e] = (f16_t)(b[e] - (float)hi[4 + e]); }
+      fh[s] = hi;
+      fl[s] = lo;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // K tile kt is split while the V rows of tile kt (requested just before) are on their way; V: f32 rows -> hi / lo halves -> the two
+  // 16-bit images (8 bytes per lane and image; a 16-lane group writes one whole 128-byte row)
+  f16x8 kh[NKT][4], kl[NKT][4];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4 vt_[8];
+    tile_load(Vb, 32 * kt, false, vt_);
+    tile_to_split(kt_[PRELOAD ? kt : 0], kh[kt], kl[kt]);
+    if (!PRELOAD && kt + 1 < NKT) tile_load(Kb, 32 * (kt + 1), true, kt_[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f16x4 hi4, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hi4[e] = (f16_t)vt_[i][e];
+      asm volatile("" : "+v"(hi4));                 // the remainder is taken against THESE bits
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lo4[e] = (f16_t)(vt_[i][e] - (float)hi4[e]);
+      const int off = (32 * kt + 4 * i + r4) * 128 + c16 * 8;
+      *reinterpret_cast<f16x4*>(vhi + off) = hi4;
+      *reinterpret_cast<f16x4*>(vlo + off) = lo4;
+    }
+  }
+  // per-lane address of the transposed V reads (attn_wave_bf16): 16-lane group g, lane i = 4q + p of the group supplies row q,
+  // columns 4p .. 4p+3 of the group's 4 x 16 block
+  const int gi = lane & 15;
+  const int tr_base = ((gi >> 2) * 64 + 16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2 + (4 * h) * 128;
+  auto tr_frag = [&](const char* img, int kt, int s2, int dt) -> f16x8 {
+    const char* a0 = img + tr_base + (32 * kt + 16 * s2) * 128 + (32 * dt) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * 128));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, both);
+  };
+#pragma unroll
+  for (int qb = 0; qb < NKT; ++qb) {
+    if (32 * qb >= L) break;
+    f16x8 qh[4], ql[4];
+    tile_to_split(qt_, qh, ql);
+    if (qb + 1 < NKT && 32 * (qb + 1) < L) tile_load(Qb, 32 * (qb + 1), true, qt_);     // the next block's rows, under this block's arithmetic
+    // scale (1/8) and log2(e) folded into one FMA in front of v_exp_f32 (1 ulp: far inside the split products' 2^-22), as in the 16-bit
+    // kernel — expf's software expansion was a third of this kernel's VALU work.  The three split terms accumulate in SEPARATE chains
+    // (a wave has its SIMD to itself here: a dependent MFMA chain of 12 exposes 12 full latencies) and meet in one VALU add.
+    constexpr float C = 0.125f * 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2], oc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o[dt][e] = 0.f; oc[dt][e] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st, s1, s2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][s], qh[s], st, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][s], ql[s], s1, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[kt][s], qh[s], s2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        st[e] = key < L ? st[e] + (s1[e] + s2[e]) : -INFINITY;       // RAW scores q.k
+      }
+      float tmx = st[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) tmx = fmaxf(tmx, st[e]);
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+      const float mn = fmaxf(m, tmx);
+      const float nmc = -mn * C;
+      float rs = 0.f;
+      f16x8 ph[2], pl[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], C, nmc));   // exp((s - max) / 8); 0 for masked keys
+        rs += pv;
+        const f16_t hv = (f16_t)pv;
+        ph[e >> 3][e & 7] = hv;
+        pl[e >> 3][e & 7] = (f16_t)(pv - (float)hv);
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      const float alpha = kt == 0 ? 0.f : __builtin_amdgcn_exp2f((m - mn) * C);
+      l = l * alpha + rs;
+      if (kt > 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { o[dt][e] *= alpha; oc[dt][e] *= alpha; }
+      }
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i) {
+          const f16x8 vh = tr_frag(vhi, kt, s2i, dt), vlw = tr_frag(vlo, kt, s2i, dt);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2i], o[dt], 0, 0, 0);
+          oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2i], oc[dt], 0, 0, 0);
+          oc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlw, ph[s2i], oc[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] += oc[dt][e];
+    // O^T -> the split operand rows through the slab: lane (query rr, half h) owns features 32dt + 8g + 4h .. +3
+    {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = (32 * dt + 8 * g + 4 * h) >> 2;             // 16-byte chunk 0..15 of the 256-byte row
+          *reinterpret_cast<f32x4*>(ol + rr * 256 + ((c ^ (rr & 15)) << 4)) =
+              f32x4{o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + r4;
+        const int q = 32 * qb + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ol + row * 256 + (c16 << 4));
+        if (q < L) store_split4<f16_t>(a3 + (size_t)(tok0 + q) * 3 * H + head * 64 + 4 * (c16 ^ (row & 15)), H, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// (Single-wave workgroups under a 256-register budget would let a CU keep 5 instead of 4 pairs in flight at 96 tokens — LDS: 8 KiB per
+// key tile for the two V images + the 8 KiB slab — but the four-tile body then spills 238 registers: tried, not kept.)
+// NKTMAX = key tiles of the call's padded length (the host guarantees L <= 32 NKTMAX): a batch of at most 96 tokens per news — the
+// reference's tokenizer_max_length — does not carry the four-tile body, whose K tiles alone are 256 registers
+template <int NKTMAX>
+__global__ __launch_bounds__(128, 1) void attn_x3_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int64_t n_pairs,
+                                                         int heads, int H, int lds_per_wave, f16_t* __restrict__ a3) {
+  extern __shared__ __attribute__((aligned(16))) char vlds[];
+  const int wave = threadIdx.x >> 6;
+  const int64_t pair = (int64_t)blockIdx.x * 2 + wave;
+  if (pair >= n_pairs) return;
+  const int n = (int)(pair / heads), head = (int)(pair - (int64_t)n * heads);
+  const int tok0 = __builtin_amdgcn_readfirstlane(cu[n]);
+  const int L = __builtin_amdgcn_readfirstlane(cu[n + 1]) - tok0;
+  if (L <= 0) return;
+  char* vl = vlds + wave * lds_per_wave;
+  if (NKTMAX == 1 || L <= 32) attn_wave_x3<1>(qkv, tok0, L, H, head, vl, a3);
+  else if (NKTMAX == 2 || L <= 64) { if constexpr (NKTMAX >= 2) attn_wave_x3<2>(qkv, tok0, L, H, head, vl, a3); }
+  else if (NKTMAX == 3 || L <= 96) { if constexpr (NKTMAX >= 3) attn_wave_x3<3>(qkv, tok0, L, H, head, vl, a3); }
+  else { if constexpr (NKTMAX >= 4) attn_wave_x3<4>(qkv, tok0, L, H, head, vl, a3); }
+}
+
 __global__ __launch_bounds__(128, 1) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                                const int32_t* __restrict__ cu, int64_t n_pairs, int heads,
                                                                int H, int lds_per_wave, void* __restrict__ a3, int a3_dt) {
@@ -572,12 +783,31 @@ int attention_varlen(DType dt, const void* qkv, void* ctx, const int32_t* cu, in
                          static_cast<float*>(ctx), cu, heads, H);
     } else {
       const int nkt = (max_len + 31) / 32;
-      const int lds_per_wave = nkt * 32 * 256 + 8192;   // f32 V image + the 32-row slab
+      const int lds_per_wave = nkt * 32 * 256 + 8192;   // f32 V image (or its two 16-bit halves) + the 32-row slab
       static bool lds_raised_dev[MAX_DEVICES] = {};
       bool& lds_raised = lds_raised_dev[current_device_slot()];
       if (!lds_raised) {
         MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
+        MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
+        MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
+        MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
+        MANNER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (4 * 32 * 256 + 8192)));
         lds_raised = true;
+      }
+      // f16x3 mode (the rows go out as the f16 split operand): both products as split f16 products on the 16-bit matrix pipe
+      // (round 5; MANNER_HIP_ATTN_X3=0 keeps the f32-MFMA kernel for A/B — read per launch, the tests flip it)
+      const char* x3_env = getenv("MANNER_HIP_ATTN_X3");
+      if (split_out && split_dt == DT_F16 && !(x3_env && atoi(x3_env) == 0)) {
+#define MANNER_ATTN_X3(N_)                                                                                                   \
+  hipLaunchKernelGGL(attn_x3_kernel<N_>, dim3((unsigned)((pairs + 1) / 2)), dim3(128), 2 * lds_per_wave, stream,                  \
+                     static_cast<const float*>(qkv), cu, pairs, heads, H, lds_per_wave, static_cast<f16_t*>(split_out))
+        if (nkt == 1) MANNER_ATTN_X3(1);
+        else if (nkt == 2) MANNER_ATTN_X3(2);
+        else if (nkt == 3) MANNER_ATTN_X3(3);
+        else MANNER_ATTN_X3(4);
+#undef MANNER_ATTN_X3
+        MANNER_LAUNCH_CHECK();
+        return MANNER_HIP_OK;
       }
       hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(128), 2 * lds_per_wave, stream,
                          static_cast<const float*>(qkv), static_cast<float*>(ctx), cu, pairs, heads, H, lds_per_wave, split_out,

@@ -1319,3 +1319,31 @@ def test_row_panel_height_of_the_persistent_gemm_gives_the_same_bits(precision, 
         assert torch.equal(got[mode][0], cls), (mode, tokens)
         assert torch.equal(got[mode][1], hid), (mode, tokens)
     enc.close()
+
+
+@pytest.mark.parametrize("name", ["enc_bert_base_64", "enc_roberta_large"])
+def test_f16x3_attention_on_the_16bit_matrix_pipe_tracks_the_f32_matrix_pipe(golden_dir, name, monkeypatch, measured):
+    """Round 5: in the f16x3 mode the attention's two products run as split (x3) f16 products on the 16-bit matrix pipe (`attn_wave_x3`:
+    f32 Q | K | V rows split into f16 hi / lo in registers and LDS, v_exp_f32 softmax) instead of on v_mfma_f32_32x32x2_f32 — 367 -> 223 us
+    per 65 536-token launch.  MANNER_HIP_ATTN_X3=0 keeps the f32-MFMA kernel: both are held to the mode's bar against the REFERENCE
+    golden (1e-4), and differ from each other by a fraction of it (bound 5e-5; lengths 2 .. 96: one to three key tiles, ragged last tile)."""
+    z, meta = _load(golden_dir, name)
+    cfg = PRESETS[meta["preset"]]
+    enc = hip.HipEncoder(cfg, make_plm_weights(cfg, seed=meta["seed"], std=meta["std"]), precisions=("f16x3",), device=DEV)
+    ids, mask = _cuda(z["ids"]), _cuda(z["mask"])
+    got = {}
+    for x3 in ("0", None):
+        if x3 is None:
+            monkeypatch.delenv("MANNER_HIP_ATTN_X3", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_ATTN_X3", x3)
+        got[x3] = (enc.encode_cls(ids, mask, precision="f16x3", host_lengths=z["mask"].sum(1)).cpu().numpy(),
+                   enc.encode_hidden(ids, mask, min(8, cfg.layers), precision="f16x3").cpu().numpy())
+    enc.status()
+    monkeypatch.delenv("MANNER_HIP_ATTN_X3", raising=False)
+    e_new, e_old = np.abs(got[None][0] - z["out"]).max(), np.abs(got["0"][0] - z["out"]).max()
+    d_cls, d_hid = np.abs(got[None][0] - got["0"][0]).max(), np.abs(got[None][1] - got["0"][1]).max()
+    print(f"{name}: f16x3 vs reference: x3 attention {e_new:.3e}, f32-MFMA attention {e_old:.3e}; x3 vs f32 attention: [CLS] {d_cls:.3e}, hidden {d_hid:.3e}")
+    assert e_new < FP32_TOL and e_old < FP32_TOL and d_cls < 5e-5 and d_hid < 5e-5
+    measured(bound_vs_reference=FP32_TOL, x3_attention_vs_reference=e_new, f32_attention_vs_reference=e_old, bound_ab=5e-5, cls_ab=d_cls, hidden_ab=d_hid)
+    enc.close()
