@@ -1295,7 +1295,9 @@ __device__ __forceinline__ void gemm_tn_x16_body(
           }
           if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU || SPLIT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (sizeof(TOut) == 4 || SPLIT) ? gelu_erf(v[e]) : gelu_poly(v[e]);   // f32 out / split: parity-grade erf
+            // f32 out: erff; split (x3 modes' FFN1): the |error| <= 1.5e-7 erf by exp / rcp (2 transcendentals + 6 FMAs against erff's
+            // ~30-instruction expansion: this epilogue was 177 us of an 881 us launch) — two orders below the mode's measured 1e-5
+            for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf_fast(v[e]) : sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);
           }
           const int c = nl / OPC;
           const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
