@@ -19,7 +19,7 @@ unset MANNER_HIP_STREAMS
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/tail_stats" -- python3 "$R/tools/tail_probe.py" > "$O/tail_probe.json" 2> "$O/tail_stats.log"; echo "tail stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/tail_fetch" -- python3 "$R/tools/tail_probe.py" > /dev/null 2> "$O/tail_fetch.log"; echo "tail fetch done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/tail_write" -- python3 "$R/tools/tail_probe.py" > /dev/null 2> "$O/tail_write.log"; echo "tail write done"
-# the training step of the reference's default configuration alone (tools/train_probe.py: 2 warm-up + 10 timed steps; both streams, as it runs)
+# the training step of the reference's default configuration alone (tools/train_probe.py: 2 warm-up + 10 + 10 timed steps; both streams, as it runs)
 export TRAIN_PROBE_VARIANT=reference_default_embeddings_trainable TRAIN_PROBE_STEPS=10
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -- python3 "$R/tools/train_probe.py" bf16 > "$O/train_probe.json" 2> "$O/train.log"; echo "train done"
 unset TRAIN_PROBE_VARIANT TRAIN_PROBE_STEPS
