@@ -706,3 +706,35 @@ def test_segment_offsets_without_a_host_read():
         off = segment_offsets(ids, len(counts))
         assert off.dtype == torch.int64 and off.tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
     assert segment_offsets(torch.zeros(0, dtype=torch.int64), 3).tolist() == [0, 0, 0, 0]
+
+
+def test_cached_parameter_view_equals_named_parameters():
+    """MannerTextEncoder._plm_params (round 5): dict(named_parameters()) from a cached view of the module tree — 36 us instead of 250 us
+    per forward for bert-base, paid with the GPU idle behind the reference's own host synchronisations.  The view re-checks the identity
+    of every submodule and Parameter it remembers on every call: a Parameter replaced by assignment, a submodule added, replaced or
+    removed all give exactly what named_parameters() gives (names, order, objects); it is not pickled."""
+    import pickle
+    from manner_amd.models.components.news_encoder import MannerTextEncoder
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MannerTextEncoder("tiny-bert", frozen_layers=[0], dropout_probability=0.2)
+
+    def same():
+        a, b = m._plm_params(), dict(m.plm_model.named_parameters())
+        assert list(a) == list(b) and all(a[k] is b[k] for k in a)
+        return a
+    first_name, first_p = next(iter(same().items()))
+    assert m._plm_params() is m._plm_params()                       # the cached dict itself while nothing changed
+    holder = m.plm_model
+    for q in first_name.split(".")[:-1]:
+        holder = getattr(holder, q)
+    setattr(holder, first_name.split(".")[-1], torch.nn.Parameter(torch.zeros_like(first_p)))
+    assert same()[first_name] is not first_p
+    holder.extra = torch.nn.Linear(2, 2)
+    assert any(k.endswith("extra.weight") for k in same())
+    old = holder.extra.weight
+    holder.extra = torch.nn.Linear(2, 2)
+    assert all(v is not old for v in same().values())
+    del holder.extra
+    assert not any("extra" in k for k in same())
+    assert "_param_view" not in pickle.loads(pickle.dumps(m)).__dict__
