@@ -1,4 +1,4 @@
-F="--gpus 1 --steps 2 --warmup 1 --no-cpu --no-table --no-small-ops --no-collate --no-train --no-kernel-profile --no-parity-grade --dropin-only 8:eval"
+F="--gpus 1 --steps 2 --warmup 1 --no-cpu --no-table --no-small-ops --no-collate --no-train --no-kernel-profile --no-parity-grade --dropin-only ${CASE:-8:eval}"
 for i in 1 2 3; do
 for m in 0 1; do
   export MANNER_PARAM_VIEW=$m
