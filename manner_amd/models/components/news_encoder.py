@@ -9,6 +9,7 @@ the training path of SURVEY §8f-3 (``manner_amd.train``: dropouts + autograd in
 from __future__ import annotations
 
 import json
+import operator
 import os
 import warnings
 from typing import Any, Dict, List, Optional
@@ -120,40 +121,46 @@ class _ParamView:
     batch by the unchanged ``CRModule.forward`` right behind a host synchronisation of the reference's own code, i.e. with the GPU idle.
     The view remembers every ``_modules`` / ``_parameters`` dict of the tree and checks, per call, that each still holds the very
     objects it held (a submodule or Parameter replaced by assignment, an adapter added, ``.to()`` with overwrite-on-conversion: any of
-    these rebuilds the view) — 350 dict look-ups, 40 us.  Same names, order and de-duplication as ``named_parameters()``."""
+    these rebuilds the view) — 350 dict look-ups run by ``map`` / ``operator.is_`` without a Python-level loop.  Same names, order and
+    de-duplication as ``named_parameters()``.  ``state()`` is the (storage address, version counter) fingerprint of the parameters in
+    that order — what tells an optimiser step, ``load_state_dict`` or a ``p.data`` swap from "nothing changed"."""
 
     def __init__(self, root: nn.Module) -> None:
         self.root = root
         self._build()
 
     def _build(self) -> None:
-        self.lens, self.checks, self.named, seen = [], [], {}, set()
+        self.len_dicts, self.len_vals, self.dicts, self.keys, self.objs, self.named, seen = [], [], [], [], [], {}, set()
 
         def walk(m: nn.Module, prefix: str) -> None:
-            self.lens.append((m._modules, len(m._modules)))
-            self.lens.append((m._parameters, len(m._parameters)))
+            for d in (m._modules, m._parameters):
+                self.len_dicts.append(d)
+                self.len_vals.append(len(d))
             for n, p in m._parameters.items():
-                self.checks.append((m._parameters, n, p))
+                self.dicts.append(m._parameters); self.keys.append(n); self.objs.append(p)
                 if p is not None and id(p) not in seen:
                     seen.add(id(p))
                     self.named[prefix + n] = p
             for n, c in m._modules.items():
-                self.checks.append((m._modules, n, c))
+                self.dicts.append(m._modules); self.keys.append(n); self.objs.append(c)
                 if c is not None:
                     walk(c, prefix + n + ".")
         walk(self.root, "")
+        self.plist = list(self.named.values())
 
     def get(self) -> dict:
         """The name -> Parameter dict (shared between calls: do not mutate it)."""
-        for d, n in self.lens:
-            if len(d) != n:
-                self._build()
-                return self.named
-        for d, k, o in self.checks:
-            if d.get(k) is not o:
-                self._build()
-                break
+        if list(map(len, self.len_dicts)) != self.len_vals or not all(map(operator.is_, map(dict.get, self.dicts, self.keys), self.objs)):
+            self._build()
         return self.named
+
+    def state(self) -> tuple:
+        """Call after get(): (data_ptr, _version) of every parameter, as two lists built without a Python-level loop."""
+        return list(map(_DATA_PTR, self.plist)), list(map(_VERSION, self.plist))
+
+
+_DATA_PTR = torch.Tensor.data_ptr
+_VERSION = operator.attrgetter("_version")
 
 
 class MannerTextEncoder(nn.Module):
@@ -203,7 +210,10 @@ class MannerTextEncoder(nn.Module):
 
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
         params = self._plm_params()
-        key = (str(device), self.precision, tuple((p.data_ptr(), p._version) for p in params.values()))
+        view = self.__dict__.get("_param_view")
+        state = view.state() if view is not None and view.named is params else \
+            tuple((p.data_ptr(), p._version) for p in params.values())
+        key = (device, self.precision, state)
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
                 try:

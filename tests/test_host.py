@@ -738,3 +738,17 @@ def test_cached_parameter_view_equals_named_parameters():
     del holder.extra
     assert not any("extra" in k for k in same())
     assert "_param_view" not in pickle.loads(pickle.dumps(m)).__dict__
+    # state(): the (storage address, version counter) fingerprint _encoder() keys its packed weight copies on — in the order of the
+    # view, equal to the per-parameter tuple it replaces, and changed by an in-place write as well as by a swap of .data
+    params = m._plm_params()
+    view = m.__dict__["_param_view"]
+    ptrs, vers = view.state()
+    assert ptrs == [p.data_ptr() for p in params.values()] and vers == [p._version for p in params.values()]
+    assert view.state() == (ptrs, vers)
+    some = list(params.values())[3]
+    with torch.no_grad():
+        some.add_(1.0)
+    assert view.state()[1] != vers and view.state()[0] == ptrs
+    vers = view.state()[1]
+    some.data = some.data.clone()
+    assert view.state()[0] != ptrs
