@@ -59,7 +59,9 @@ def _late_fusion_ragged(hist_vec: Tensor, cand_vec: Tensor, hist_off: Tensor, ca
 def cr_forward(news_encoder, batch: Dict, late_fusion: bool = True, user_encoder=None, click_predictor=None,
                dense: bool = True) -> Tensor:
     """CRModule.forward: scores [B, Cmax] (or the ragged [sum c_i] vector with ``dense=False``).  No torch indexing
-    and — when the batch carries ``hist_max`` / ``cand_max`` — no host synchronisation."""
+    and — when the batch carries ``hist_max`` / ``cand_max`` — no host synchronisation.  Padded slots are exactly 0, as in the
+    reference — but for an impression WITHOUT history rows (which the reference's loader drops, mind_dataframe.py:313): its real
+    candidates score NaN here as there (0 / 0), its padded slots 0 here and NaN there (NaN user . zero vector)."""
     nb = batch["users"].numel() if "users" in batch and batch["users"] is not None else int(batch["batch_cand"].max()) + 1
     hip.status_poll(batch["batch_cand"].device)
     hist_vec = news_encoder(batch["x_hist"])

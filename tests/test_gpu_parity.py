@@ -787,6 +787,41 @@ def test_scorer_linearity_full_size():
         assert (s1[co[i]:co[i + 1]].cpu() - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_an_impression_without_history_scores_nan_like_the_reference():
+    """Edge case of cr_module.py:117-123: a segment id that owns no history row gets hist_size 0, torch.div(0-vector, 0) = NaN and a
+    NaN score for every slot of its row — the padded ones too (NaN user . zero vector); every other impression is untouched.  The
+    reference's data frame drops such rows at load time (mind_dataframe.py:313), so this only pins what the operators do: the fused
+    scorer divides like the reference instead of guarding the division (NaN for the real candidates, the others bit-untouched), the
+    DotProduct mirror under the reference's own dense call gives the all-NaN row, and the composed hotpath.cr_forward — which pads
+    the RAGGED scores — differs from the reference only in the padded slots of such a row (0 instead of NaN)."""
+    from manner_amd.models.components.click_predictors import DotProduct
+    n_news, d = 50, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    table = torch.randn((n_news, d), generator=g)
+    imp = _ragged_impressions([3, 0, 7, 1], [4, 5, 2, 6], n_news, seed=5)
+    ho, co = imp["hist_off"], imp["cand_off"]
+    hist_vec, cand_vec = table[imp["hist_idx"].astype(np.int64)], table[imp["cand_idx"].astype(np.int64)]
+    bh, bc = segment_ids(ho), segment_ids(co)
+    ref = O.cr_scores(hist_vec, torch.from_numpy(bh), cand_vec, torch.from_numpy(bc))              # [4, 6]
+    assert torch.isnan(ref[1]).all() and not torch.isnan(ref[[0, 2, 3]]).any()
+    s = hip.score_late_fusion(table.to(DEV), _cuda(imp["hist_idx"]), _cuda(ho), _cuda(imp["cand_idx"]), _cuda(co)).cpu()
+    rr = O.ragged(ref, torch.from_numpy(bc))
+    assert torch.equal(torch.isnan(s), torch.isnan(rr)) and int(torch.isnan(rr).sum()) == 5
+    keep = ~torch.isnan(rr)
+    assert (s[keep] - rr[keep]).abs().max() < FP32_TOL
+    # the reference's own call shape over the mirror: DotProduct(user [B, 1, D], cand^T [B, D, Cmax]) with the NaN user row
+    hist_agg, mask_hist = O.to_dense_batch(hist_vec, torch.from_numpy(bh))
+    cand_agg, _ = O.to_dense_batch(cand_vec, torch.from_numpy(bc))
+    user = torch.div(hist_agg.sum(dim=1), mask_hist.sum(dim=1).unsqueeze(-1))
+    out = DotProduct()(user.unsqueeze(1).to(DEV), cand_agg.to(DEV).permute(0, 2, 1)).cpu()
+    assert out.shape == ref.shape and torch.equal(torch.isnan(out), torch.isnan(ref))
+    assert (out[~torch.isnan(ref)] - ref[~torch.isnan(ref)]).abs().max() < FP32_TOL
+    batch = {"x_hist": hist_vec.to(DEV), "x_cand": cand_vec.to(DEV), "batch_hist": _cuda(bh), "batch_cand": _cuda(bc)}
+    dense = hotpath.cr_forward(lambda x: x, batch, late_fusion=True).cpu()
+    assert dense.shape == ref.shape and torch.isnan(dense[1, :5]).all() and (dense[1, 5:] == 0).all()
+    assert (dense[[0, 2, 3]] - ref[[0, 2, 3]]).abs().max() < FP32_TOL
+
+
 def test_scorer_gives_identical_scores_to_repeated_candidates():
     """Exact ties must stay ties: the same news at several candidate positions of an impression (it happens in MIND, and the
     reference's bmm gives both occurrences the same bits) gets BIT-identical scores whatever wave / slot of the kernel handles
