@@ -130,33 +130,45 @@ class _ParamView:
         self._build()
 
     def _build(self) -> None:
-        self.len_dicts, self.len_vals, self.dicts, self.keys, self.objs, self.named, seen = [], [], [], [], [], {}, set()
+        # built into locals and published by ONE attribute assignment: a second thread in get() sees the old or the new snapshot whole
+        len_dicts, len_vals, dicts, keys, objs, named, seen = [], [], [], [], [], {}, set()
 
         def walk(m: nn.Module, prefix: str) -> None:
             for d in (m._modules, m._parameters):
-                self.len_dicts.append(d)
-                self.len_vals.append(len(d))
+                len_dicts.append(d)
+                len_vals.append(len(d))
             for n, p in m._parameters.items():
-                self.dicts.append(m._parameters); self.keys.append(n); self.objs.append(p)
+                dicts.append(m._parameters); keys.append(n); objs.append(p)
                 if p is not None and id(p) not in seen:
                     seen.add(id(p))
-                    self.named[prefix + n] = p
+                    named[prefix + n] = p
             for n, c in m._modules.items():
-                self.dicts.append(m._modules); self.keys.append(n); self.objs.append(c)
+                dicts.append(m._modules); keys.append(n); objs.append(c)
                 if c is not None:
                     walk(c, prefix + n + ".")
         walk(self.root, "")
-        self.plist = list(self.named.values())
+        self._snap = (len_dicts, len_vals, dicts, keys, objs, named, list(named.values()))
+
+    @property
+    def named(self) -> dict:
+        return self._snap[5]
 
     def get(self) -> dict:
         """The name -> Parameter dict (shared between calls: do not mutate it)."""
-        if list(map(len, self.len_dicts)) != self.len_vals or not all(map(operator.is_, map(dict.get, self.dicts, self.keys), self.objs)):
+        len_dicts, len_vals, dicts, keys, objs, named, _ = self._snap
+        if list(map(len, len_dicts)) != len_vals or not all(map(operator.is_, map(dict.get, dicts, keys), objs)):
             self._build()
-        return self.named
+            return self._snap[5]
+        return named
 
-    def state(self) -> tuple:
-        """Call after get(): (data_ptr, _version) of every parameter, as two lists built without a Python-level loop."""
-        return list(map(_DATA_PTR, self.plist)), list(map(_VERSION, self.plist))
+    def state(self, named: Optional[dict] = None) -> Optional[tuple]:
+        """(data_ptr, _version) of every parameter, as two lists built without a Python-level loop.  ``named``: the dict get() returned
+        to this caller — None comes back if the view has been rebuilt since (another thread), so that a fingerprint never pairs with
+        another snapshot's parameters."""
+        snap = self._snap
+        if named is not None and snap[5] is not named:
+            return None
+        return list(map(_DATA_PTR, snap[6])), list(map(_VERSION, snap[6]))
 
 
 _DATA_PTR = torch.Tensor.data_ptr
@@ -211,8 +223,9 @@ class MannerTextEncoder(nn.Module):
     def _encoder(self, device: torch.device) -> hip.HipEncoder:
         params = self._plm_params()
         view = self.__dict__.get("_param_view")
-        state = view.state() if view is not None and view.named is params else \
-            tuple((p.data_ptr(), p._version) for p in params.values())
+        state = view.state(params) if view is not None else None
+        if state is None:
+            state = tuple((p.data_ptr(), p._version) for p in params.values())
         key = (device, self.precision, state)
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
