@@ -1382,3 +1382,33 @@ def test_f16x3_attention_on_the_16bit_matrix_pipe_tracks_the_f32_matrix_pipe(gol
     assert e_new < FP32_TOL and e_old < FP32_TOL and d_cls < 5e-5 and d_hid < 5e-5
     measured(bound_vs_reference=FP32_TOL, x3_attention_vs_reference=e_new, f32_attention_vs_reference=e_old, bound_ab=5e-5, cls_ab=d_cls, hidden_ab=d_hid)
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["bert-256", "mini-roberta-large"])
+def test_f16x3_attention_with_four_key_tiles_matches_the_oracle(preset, monkeypatch):
+    """The longest rows the engine takes (97 .. 128 tokens: FOUR 32-key tiles — the x3 attention's path without preloaded K fragments,
+    which the 96-token goldens never reach), mixed with short ones, in the f16x3 mode: within the fp32 bar (1e-4) of the oracle, and
+    the split-product kernel within 5e-5 of the f32-MFMA kernel it replaced.  RoBERTa positions (offset 2) need max_pos >= 130."""
+    from manner_amd.config import EncoderConfig
+    # (the split modes need H and I in multiples of 256: a two-layer 256-wide BERT, and the two roberta-large-shaped layers)
+    cfg = EncoderConfig(hidden=256, layers=2, heads=4, intermediate=1024, vocab=2048, max_pos=128) if preset == "bert-256" else PRESETS[preset]
+    max_len = min(128, cfg.max_pos - (2 if cfg.arch == 1 else 0))
+    lengths = np.array([max_len, max_len - 1, 97, 100, 113, 2, 33, 64, 96, 65, max_len, 31, 98, 120, 5, 127 if max_len >= 127 else 99])
+    lengths = np.minimum(lengths, max_len)
+    ids, mask = synth_news_tokens(len(lengths), cfg, seed=23, lengths=lengths)
+    w = make_plm_weights(cfg, seed=23, std=0.05)
+    ref = O.encode_cls(ids, mask, w, cfg).numpy()
+    enc = hip.HipEncoder(cfg, w, precisions=("f16x3",), device=DEV)
+    got = {}
+    for x3 in ("0", None):
+        if x3 is None:
+            monkeypatch.delenv("MANNER_HIP_ATTN_X3", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_ATTN_X3", x3)
+        got[x3] = enc.encode_cls(_cuda(ids), _cuda(mask), precision="f16x3").cpu().numpy()
+    enc.status()
+    enc.close()
+    e_new, e_old, d = np.abs(got[None] - ref).max(), np.abs(got["0"] - ref).max(), np.abs(got[None] - got["0"]).max()
+    print(f"{preset}: lengths up to {max_len}: x3 attention vs oracle {e_new:.3e}, f32-MFMA attention {e_old:.3e}, A/B {d:.3e}")
+    assert e_new < FP32_TOL and e_old < FP32_TOL and d < 5e-5
