@@ -1396,6 +1396,9 @@ static bool choose_lean(const manner_hip_encoder_config* c, int32_t precision, i
 }
 static void record_attn_path(const void* saved, bool mfma, bool lean) {
   std::lock_guard<std::mutex> g(g_attn_mu);
+  // one entry per distinct saved-buffer ADDRESS (an allocator recycles them, so a handful in practice); bounded all the same: past
+  // the cap the table starts over, and a backward that no longer finds its record falls back to the rule its forward applied
+  if (g_attn_path.size() >= 4096 && g_attn_path.find(saved) == g_attn_path.end()) g_attn_path.clear();
   g_attn_path[saved] = (mfma ? 1 : 0) | (lean ? 2 : 0);
 }
 static bool recorded_attn_path(const void* saved, bool rule, bool lean_rule, bool* lean) {
