@@ -1225,6 +1225,10 @@ def compact_line(result, limit=COMPACT_LIMIT):
     kern = result.get("kernels") or {}
     if kern:
         legs["kernel_avg_us"] = {k: v.get("avg_us") for k, v in kern.items()}
+    errors = {k: _tag(str(result[k]["error"])) for k in ("table_mode", "small_ops", "cpu_baseline", "train_mode", "dropin", "collate")
+              if isinstance(result.get(k), dict) and result[k].get("error")}
+    if errors:
+        legs["errors"] = errors
     line["legs"] = legs
     line["full_record"] = result.get("full_record")
     line = _clean(line)
@@ -1249,7 +1253,10 @@ def compact_line(result, limit=COMPACT_LIMIT):
 
 def emit(result, args):
     """Full record -> file (and nothing of it on stdout); compact line -> the LAST line of stdout."""
-    summarise_for_driver(result, args)
+    try:
+        summarise_for_driver(result, args)
+    except Exception as e:      # noqa: BLE001   (copies of figures already in the record: never worth the line)
+        log(f"summarise_for_driver failed: {type(e).__name__}: {e}")
     path = args.full_json
     try:
         with open(path, "w") as f:
@@ -1259,11 +1266,22 @@ def emit(result, args):
         if os.path.isdir(side) and os.path.dirname(os.path.abspath(path)) == ROOT:
             with open(os.path.join(side, "bench_full.json"), "w") as f:
                 json.dump(result, f, indent=1, default=str)
-    except OSError as e:
+    except (OSError, TypeError, ValueError) as e:
         log(f"could not write {path}: {e}")
         result["full_record"] = None
     sys.stderr.flush()
     print(compact_line(result), flush=True)
+
+
+def guarded(name, fn, *a, **kw):
+    """A side leg must not take the headline line with it: run it, and on ANY failure log the reason and return {"error": ...}."""
+    try:
+        return fn(*a, **kw)
+    except Exception as exc:      # noqa: BLE001
+        import traceback
+        log(f"{name} FAILED: " + "".join(traceback.format_exception_only(type(exc), exc)).strip())
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
 # --------------------------------------------------------------------------------------------------- main
@@ -1509,7 +1527,7 @@ def main():
     barrier()
 
     if rank == 0 and not args.no_collate:
-        result["collate"] = collate_leg(args, cfg, imp_all, pool_ids_np, pool_len, batches[-1], (n_steps - 1) * args.impressions, dev)
+        result["collate"] = guarded("collate leg", collate_leg, args, cfg, imp_all, pool_ids_np, pool_len, batches[-1], (n_steps - 1) * args.impressions, dev)
     del batches, table_bufs
     if not args.no_table:
         log("table mode")
@@ -1531,19 +1549,21 @@ def main():
             sys.stderr.flush()
             os._exit(0)
         if rank == 0 and par_scale is not None:
-            if K == 1:
+            def spread_weights_parity():
                 log("at-scale parity on spread weights (std 0.05)")
                 w2 = make_plm_weights(cfg, seed=44, std=0.05)
                 enc2 = hip.HipEncoder(cfg, w2, precisions=("bf16", "f16", "fp32"), device=dev)
                 dimp, labels = held
                 sc = {}
                 for prec in ("bf16", "f16", "fp32"):
-                    tab = enc2.encode_cls(pool_ids, pool_mask, precision=prec, host_lengths=pool_len, max_chunk_tokens=args.chunk_tokens)
-                    sc[prec] = hip.score_late_fusion(tab, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
-                    del tab
-                par_scale["spread_weights_std0.05"] = {m: ranking_agreement(sc[m], sc["fp32"], labels, dimp["cand_off"]) for m in ("bf16", "f16")}
+                    t_ = enc2.encode_cls(pool_ids, pool_mask, precision=prec, host_lengths=pool_len, max_chunk_tokens=args.chunk_tokens)
+                    sc[prec] = hip.score_late_fusion(t_, dimp["hist_idx"], dimp["hist_off"], dimp["cand_idx"], dimp["cand_off"])
+                    del t_
+                out = {m: ranking_agreement(sc[m], sc["fp32"], labels, dimp["cand_off"]) for m in ("bf16", "f16")}
                 enc2.close()
-                del sc
+                return out
+            if K == 1:
+                par_scale["spread_weights_std0.05"] = guarded("at-scale parity on spread weights", spread_weights_parity)
             result["parity_at_scale"] = par_scale
             # the parity mode's own throughput, in the driver-run line
             result["parity_mode"] = {"dtype": "fp32", "news_encoded_per_s": par_scale["parity_mode_news_per_s"],
@@ -1554,24 +1574,27 @@ def main():
         del held
     if rank == 0 and world == 1 and not args.no_small_ops:
         log("small-kernel legs (pooler, dot, z-score, to_dense)")
-        result["small_ops"] = small_ops_leg(dev)
+        result["small_ops"] = guarded("small-kernel legs", small_ops_leg, dev)
     if rank == 0 and world == 1 and not args.no_cpu:
         log("CPU baseline (oracle) + parity on the bounded sample")
         nb = max(2, args.cpu_impressions // K)
         args.parity_impressions = max(nb, args.parity_impressions // K // (4 if cfg.layers * cfg.hidden > 12 * 768 else 1))   # bounded CPU time
-        cpu, par = cpu_baseline_and_parity(args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
-        result["cpu_baseline"] = cpu
-        result["parity"] = par
+        got = guarded("CPU baseline", cpu_baseline_and_parity, args, cfg, weight_sets, fuse_w, encs, imp_all, (pool_ids_np, pool_mask_np, pool_len), dev, nb)
+        if isinstance(got, tuple):
+            result["cpu_baseline"], result["parity"] = got
+        else:
+            result["cpu_baseline"] = dict(got, value=None, unit="candidates/s", cores=None, kind="port", sample=None)
     if rank == 0 and world == 1 and not args.no_train and cfg.head_dim == 64 and args.config == 1:
         log("training-step leg (train() mode encoder + scorer + SupCon + backward + AdamW)")
         # bf16 GEMM operands: f32's exponent range, so the step needs no loss scaling (f16 needs the caller's GradScaler, as the
         # reference's 16-mixed Lightning plugin provides — manner_amd/models/components/news_encoder.py train_precision)
-        result["train_mode"] = train_leg(cfg, dev, args.precision if args.precision in ("bf16", "fp32") else "bf16")
+        result["train_mode"] = guarded("training-step leg", train_leg, cfg, dev, args.precision if args.precision in ("bf16", "fp32") else "bf16")
     if rank == 0 and world == 1 and not args.no_dropin and cfg.head_dim == 64 and args.config == 1:
         log("drop-in leg (mirror classes under the unchanged CRModule.forward, B = 8 and 64, eval + train)")
         for e in encs:
             e.close()
-        result["dropin"] = dropin_leg(cfg, model, weight_sets[0], (pool_ids, pool_mask, pool_len), dev, args.precision if args.precision in ("f16", "bf16", "fp32") else "f16", only=args.dropin_only)
+        result["dropin"] = guarded("drop-in leg", dropin_leg, cfg, model, weight_sets[0], (pool_ids, pool_mask, pool_len), dev,
+                                   args.precision if args.precision in ("f16", "bf16", "fp32") else "f16", only=args.dropin_only)
     if rank == 0:
         emit(result, args)
     if world > 1:
