@@ -88,6 +88,9 @@ def parse():
     p.add_argument("--parity-impressions", type=int, default=64,
                    help="impressions of the oracle parity bridge (SURVEY §8d's slice): the oracle runs them once, every HIP mode is compared")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--strict", action="store_true",
+                   help="exit with status 3 (after the line has been printed) when any guarded side leg failed — for CI; the default "
+                        "keeps status 0 so that a broken side leg never costs the driver its headline line (legs.errors names it)")
     p.add_argument("--no-parity-grade", action="store_true", help="skip the repeat of the timed steps in the parity-grade arithmetic (f16x3)")
     p.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"), help="where the complete result (every leg) is written")
     p.add_argument("--no-kernel-profile", action="store_true")
@@ -578,7 +581,15 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
     enc.load_state_dict({"text_encoder.plm_model." + k: torch.from_numpy(v) for k, v in weights_np.items()
                          if "text_encoder.plm_model." + k in own}, strict=False)
     enc = enc.to(dev)
-    enc.text_encoder.precision = precision
+    # The arithmetic is chosen as a reference run chooses it: by trainer.precision.  Lightning's `16-mixed` (the shipped
+    # configs/trainer/default.yaml:12) / `bf16-mixed` plugins wrap every *_step in torch.autocast and, for fp16, scale the loss with a
+    # GradScaler; the mirror reads that state (MannerTextEncoder.precision = None).  --precision fp32 = trainer.precision=32: no autocast.
+    import contextlib
+    amp_dtype = {"f16": torch.float16, "bf16": torch.bfloat16}.get(precision)
+    amp = (lambda: torch.autocast("cuda", dtype=amp_dtype)) if amp_dtype is not None else contextlib.nullcontext
+    trainer_precision = {"f16": "16-mixed", "bf16": "bf16-mixed"}.get(precision, "32")
+    if os.environ.get("MANNER_HIP_PRECISION") or os.environ.get("MANNER_HIP_TRAIN_PRECISION"):
+        log("drop-in leg: MANNER_HIP_(TRAIN_)PRECISION is set and overrides the autocast state")
     click = DotProduct()
 
     def to_dense_batch(x, batch, nb, width):
@@ -594,13 +605,14 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
         return dense.view(nb, width, *x.shape[1:]), mask.view(nb, width)
 
     def forward(b):                                             # cr_module.py:105-131, late_fusion=True, line by line
-        clicked = enc(b["x_hist"])
-        clicked_agg, mask_hist = to_dense_batch(clicked, b["batch_hist"], b["nb"], b["hist_max"])
-        cand = enc(b["x_cand"])
-        cand_agg, _ = to_dense_batch(cand, b["batch_cand"], b["nb"], b["cand_max"])
-        hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])], device=dev)
-        user = torch.div(clicked_agg.sum(dim=1), hist_size.unsqueeze(dim=-1))
-        return click(user.unsqueeze(dim=1), cand_agg.permute(0, 2, 1))
+        with amp():                                             # what the trainer's precision plugin wraps the step in
+            clicked = enc(b["x_hist"])
+            clicked_agg, mask_hist = to_dense_batch(clicked, b["batch_hist"], b["nb"], b["hist_max"])
+            cand = enc(b["x_cand"])
+            cand_agg, _ = to_dense_batch(cand, b["batch_cand"], b["nb"], b["cand_max"])
+            hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])], device=dev)
+            user = torch.div(clicked_agg.sum(dim=1), hist_size.unsqueeze(dim=-1))
+            return click(user.unsqueeze(dim=1), cand_agg.permute(0, 2, 1))
 
     def make_batch(imp, lo, hi, train_mode, g):
         ho, co = imp["hist_off"], imp["cand_off"]
@@ -630,8 +642,10 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
                 "hist_max": int(hsz.max()), "cand_max": int(csz.max()), "labels": torch.from_numpy(lab.astype(np.float32)).to(dev),
                 "n_cand": int(csz.sum()), "n_news": int(hsz.sum() + csz.sum())}
 
-    out = {"what": dropin_leg.__doc__.split("eval:")[0].strip(), "model": model_name, "eval_precision": precision,
-           "train_precision": enc.text_encoder.train_precision}
+    with amp():
+        out = {"what": dropin_leg.__doc__.split("eval:")[0].strip(), "model": model_name, "trainer_precision": trainer_precision,
+               "eval_precision": enc.text_encoder.resolved_precision(), "train_precision": enc.text_encoder.resolved_train_precision(),
+               "grad_scaler": precision == "f16"}
     g = np.random.default_rng(3)
     for bs in batch_sizes:
         imp = synth_impressions(bs * (iters + 2), n_pool, seed=900 + bs)
@@ -648,14 +662,22 @@ def dropin_leg(cfg, model_name, weights_np, pool, dev, precision, batch_sizes=(8
             else:
                 enc.train()
                 opt = torch.optim.AdamW([p for p in enc.parameters() if p.requires_grad], lr=1e-5, fused=True)
+                # 16-mixed: Lightning's plugin scales the loss and steps through the scaler (the fused AdamW takes the scale and the
+                # found-inf flag on the device: no host read); bf16-mixed / 32: none
+                scaler = torch.amp.GradScaler("cuda") if precision == "f16" else None
 
-                def step(b):
+                def step(b, opt=opt, scaler=scaler):
                     scores = forward(b)                                        # dense [B, Cmax]
                     off = hotpath.segment_offsets(b["batch_cand"], b["nb"])
                     ragged = scores.reshape(-1)                                 # every impression has 5 candidates: dense == ragged
                     loss, _ = train.model_step_loss(ragged, b["labels"], off, supcon=True, temperature=0.36)
-                    loss.backward()
-                    opt.step()
+                    if scaler is not None:
+                        scaler.scale(loss).backward()
+                        scaler.step(opt)
+                        scaler.update()
+                    else:
+                        loss.backward()
+                        opt.step()
                     opt.zero_grad(set_to_none=True)
                     return loss
             for b in batches[:2]:
@@ -1273,12 +1295,17 @@ def emit(result, args):
     print(compact_line(result), flush=True)
 
 
+FAILED_LEGS = []
+
+
 def guarded(name, fn, *a, **kw):
-    """A side leg must not take the headline line with it: run it, and on ANY failure log the reason and return {"error": ...}."""
+    """A side leg must not take the headline line with it: run it, and on ANY failure log the reason and return {"error": ...}.
+    Every guarded leg runs on rank 0 of a single-rank job only (no collective inside one), so a failure cannot strand a peer."""
     try:
         return fn(*a, **kw)
     except Exception as exc:      # noqa: BLE001
         import traceback
+        FAILED_LEGS.append(name)
         log(f"{name} FAILED: " + "".join(traceback.format_exception_only(type(exc), exc)).strip())
         traceback.print_exc(file=sys.stderr)
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
@@ -1599,6 +1626,10 @@ def main():
         emit(result, args)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if FAILED_LEGS:
+        log(f"side legs that FAILED (named in legs.errors of the line): {FAILED_LEGS}" + ("" if args.strict else "  [--strict turns this into exit status 3]"))
+        if args.strict:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MANNER_HIP_ABI_VERSION 7
+#define MANNER_HIP_ABI_VERSION 8
 
 enum {
   MANNER_HIP_OK = 0,
@@ -159,6 +159,15 @@ int manner_hip_encoder_status(manner_hip_encoder_t enc, manner_hip_stream_t stre
  * the module mirror surfaces bad inputs of call k at call k+1 without a host synchronisation per forward. */
 int manner_hip_encoder_status_async(manner_hip_encoder_t enc, int32_t* host_flag /*pinned host*/, manner_hip_stream_t stream);
 #define MANNER_HIP_MAX_LEN 128
+
+/* ABI v8 — sampled fingerprint of a set of tensors, for hosts that cache copies of caller-owned parameters (the module mirror's
+ * inference handle packs the PLM weights once; torch's version counters do not see a write through `p.data`).  out[i] = a 32-bit
+ * hash of min(counts[i], samples) evenly strided 32-bit words of tensors[i] (first and last word included) mixed with counts[i]:
+ * a bulk rewrite of a tensor (scaling, a copy, an optimiser step through .data) changes its word; a poke into single elements
+ * between the samples does not — this is a tripwire, not a checksum.  tensors / counts / out are DEVICE arrays of n entries;
+ * one launch, no host synchronisation. */
+int manner_hip_fingerprint(const void* const* tensors /*device*/, const int64_t* counts /*device*/, int32_t n, int32_t samples,
+                           uint32_t* out /*device*/, manner_hip_stream_t stream);
 
 /* Optional per-kernel timing (the reference delegates profiling to Lightning's `profiler: simple`,
  * configs/trainer/default.yaml:21; this is the build's equivalent for the roofline report).
@@ -440,6 +449,15 @@ int manner_hip_train_backward(const manner_hip_encoder_config* cfg, const float*
                               int32_t start_layer, float p_hidden, float p_attn, float p_out, uint64_t seed,
                               const float* grad_cls, void* saved, size_t saved_bytes, float* const* grads /*host*/,
                               float* grad_prefix, void* workspace, size_t workspace_bytes, manner_hip_stream_t stream);
+/* ABI v8 — the layout of `saved` travels WITH the call pair instead of being guessed.  manner_hip_train_layout_last() returns the
+ * layout word of the most recent successful manner_hip_train_forward / _full_forward of THIS thread (bit 0: attention on the matrix
+ * pipe with 16-bit Q | K | V, bit 1: 16-bit-only saved activations; -1: no forward yet); manner_hip_train_layout_next(word) hands it
+ * to the NEXT manner_hip_train_backward / _full_backward of this thread (consumed by it, like manner_hip_train_weight_cache).  A host
+ * keeps the word next to the saved buffer (the mirror: in the autograd ctx).  A backward that gets no word falls back to the
+ * per-address record its forward left in this process image; one that finds neither FAILS with MANNER_HIP_E_INVALID rather than
+ * deriving a layout from the environment of the moment (which may differ from the forward's and would plan other slot offsets). */
+int32_t manner_hip_train_layout_last(void);
+int manner_hip_train_layout_next(int32_t word);
 int manner_hip_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, uint8_t* keep, manner_hip_stream_t stream);
 
 /* The same training path with "full rows" — the PLM inside PLMTextEncoder in train() mode (manner/models/components/

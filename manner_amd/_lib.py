@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmanner_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "manner_hip.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 STATUS_MASK, STATUS_TOKEN, STATUS_FUSED, STATUS_INDEX, STATUS_LENGTHS = 1, 2, 4, 8, 16
 PREC_F32, PREC_BF16 = 0, 1
 PREC_BF16X3 = 2
@@ -45,6 +45,7 @@ SIGNATURES = {
     "manner_hip_encode_hidden": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "manner_hip_encoder_status": (C.c_int, [_P, _P]),
     "manner_hip_encoder_status_async": (C.c_int, [_P, _P, _P]),
+    "manner_hip_fingerprint": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "manner_hip_encoder_profile": (C.c_int, [_P, _I32]),
     "manner_hip_encoder_profile_read": (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "manner_hip_additive_pool": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P]),
@@ -75,6 +76,8 @@ SIGNATURES = {
     "manner_hip_train_saved_bytes_for": (_SZ, [C.POINTER(EncoderConfigC), _I64, _I64, _I32, _I32]),
     "manner_hip_train_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I64]),
     "manner_hip_train_weight_cache": (C.c_int, [C.POINTER(_P), C.POINTER(_I32), _I32]),
+    "manner_hip_train_layout_last": (_I32, []),
+    "manner_hip_train_layout_next": (C.c_int, [_I32]),
     "manner_hip_train_forward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _P,
                                            C.c_float, C.c_float, C.c_float, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P, _P]),
     "manner_hip_train_backward": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(_P), _I32, _P, _I64, _I64, _I64, _I32, _I32,

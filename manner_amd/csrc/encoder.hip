@@ -356,6 +356,27 @@ int run_cls_tail(manner_hip_encoder* e, int prec, const Workspace& ws, int64_t r
   return MANNER_HIP_OK;
 }
 
+// word t = order-independent sum of mixed samples of tensor t (see manner_hip_fingerprint in the header)
+__global__ void __launch_bounds__(256) fingerprint_kernel(const uint32_t* const* __restrict__ tensors, const int64_t* __restrict__ counts, int samples,
+                                                          uint32_t* __restrict__ out) {
+  __shared__ uint32_t part[4];
+  const int t = blockIdx.x;
+  const uint32_t* p = tensors[t];
+  const int64_t n = counts[t], m = n < samples ? n : (int64_t)samples;
+  uint32_t h = 0;
+  for (int64_t j = threadIdx.x; j < m; j += 256) {
+    const int64_t idx = (m == n || m < 2) ? j : (j * (n - 1)) / (m - 1);
+    uint32_t v = p[idx] ^ ((uint32_t)j * 0x9E3779B9u);
+    v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+    h += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) out[t] = part[0] + part[1] + part[2] + part[3] + (uint32_t)n * 0x27D4EB2Fu;
+}
+
 }  // namespace
 }  // namespace manner
 
@@ -364,6 +385,15 @@ using namespace manner;
 extern "C" {
 
 int manner_hip_abi_version(void) { return MANNER_HIP_ABI_VERSION; }
+
+int manner_hip_fingerprint(const void* const* tensors, const int64_t* counts, int32_t n, int32_t samples, uint32_t* out, manner_hip_stream_t stream) {
+  if (n == 0) return MANNER_HIP_OK;
+  if (!tensors || !counts || !out || n < 0 || samples <= 0) return fail(MANNER_HIP_E_INVALID, "fingerprint: null table or n=%d samples=%d", n, samples);
+  hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t* const*>(tensors), counts,
+                     samples, out);
+  MANNER_LAUNCH_CHECK();
+  return MANNER_HIP_OK;
+}
 const char* manner_hip_last_error(void) { return g_err; }
 
 int manner_hip_encoder_profile(manner_hip_encoder_t enc, int32_t enable) {

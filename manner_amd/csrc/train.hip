@@ -1401,11 +1401,15 @@ static void record_attn_path(const void* saved, bool mfma, bool lean) {
   if (g_attn_path.size() >= 4096 && g_attn_path.find(saved) == g_attn_path.end()) g_attn_path.clear();
   g_attn_path[saved] = (mfma ? 1 : 0) | (lean ? 2 : 0);
 }
-static bool recorded_attn_path(const void* saved, bool rule, bool lean_rule, bool* lean) {
+static thread_local int32_t g_layout_last = -1, g_layout_next = -1;      // ABI v8: the layout word carried by the caller
+// the layout the forward of `saved` chose: the word the caller handed over (consumed), else this process image's record; -1 = neither
+static int recorded_layout(const void* saved) {
+  const int32_t w = g_layout_next;
+  g_layout_next = -1;
+  if (w >= 0) return w & 3;
   std::lock_guard<std::mutex> g(g_attn_mu);
   auto it = g_attn_path.find(saved);
-  *lean = it == g_attn_path.end() ? lean_rule : (it->second & 2) != 0;
-  return it == g_attn_path.end() ? rule : (it->second & 1) != 0;
+  return it == g_attn_path.end() ? -1 : it->second;
 }
 
 struct WCacheArg { void* const* slots = nullptr; int32_t* valid = nullptr; int n = 0; };
@@ -1562,6 +1566,13 @@ int manner_hip_train_weight_cache(void* const* slots, int32_t* valid, int32_t n_
   return MANNER_HIP_OK;
 }
 
+int32_t manner_hip_train_layout_last(void) { return g_layout_last; }
+int manner_hip_train_layout_next(int32_t word) {
+  if (word < -1 || word > 3) return fail(MANNER_HIP_E_INVALID, "train_layout_next: %d is not a layout word", word);
+  g_layout_next = word;
+  return MANNER_HIP_OK;
+}
+
 size_t manner_hip_train_saved_bytes(const manner_hip_encoder_config* cfg, int64_t n_news, int64_t m_bound, int32_t start_layer) {
   if (!cfg || n_news <= 0 || m_bound <= 0 || start_layer < 0 || start_layer >= cfg->layers || cfg->layers > 64) return 0;
   Bump b(nullptr);
@@ -1704,6 +1715,7 @@ static int train_forward_impl(const manner_hip_encoder_config* cfg, const float*
   t.attn_mfma = mfma_rule;
   t.lean = lean_rule;
   record_attn_path(saved, t.attn_mfma, t.lean);
+  g_layout_last = (t.attn_mfma ? 1 : 0) | (t.lean ? 2 : 0);
   if ((start_layer > 0) != (prefix_hidden != nullptr))
     return fail(MANNER_HIP_E_INVALID, "train_forward: prefix_hidden goes with start_layer > 0");
   for (float p : {p_hidden, p_attn, p_out})
@@ -1765,11 +1777,13 @@ static int train_backward_impl(const manner_hip_encoder_config* cfg, const float
   Ctx t;
   int rc;
   hipStream_t s = (hipStream_t)stream;
-  bool mfma_rec = false, lean_rec = false;               // what the forward of this buffer chose (it sized the slots by it)
-  if (cfg && m_bound > 0) {
-    const bool rule = choose_attn_path(cfg, precision, full);
-    mfma_rec = recorded_attn_path(saved, rule, choose_lean(cfg, precision, m_bound, rule), &lean_rec);
-  }
+  // what the forward of this buffer chose (it sized the slots by it): carried by the caller (manner_hip_train_layout_next) or recorded
+  // per address by that forward — never re-derived from the environment, whose switches may have changed since
+  const int layout = recorded_layout(saved);
+  if (layout < 0 && cfg && m_bound > 0)
+    return fail(MANNER_HIP_E_INVALID, "train_backward: no layout for this saved buffer (no manner_hip_train_layout_next word and no forward "
+                                      "of this process recorded it)");
+  const bool mfma_rec = layout > 0 && (layout & 1), lean_rec = layout > 0 && (layout & 2);
   if ((rc = setup(t, cfg, weights, n_weights, n_news, padded_len, m_bound, precision, start_layer, saved, saved_bytes, workspace,
                   workspace_bytes, s, wc, lean_rec)))
     return rc;

@@ -197,7 +197,7 @@ __device__ __forceinline__ void fwd_wave(const TE* __restrict__ qkv, float* __re
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) o[dt] = E16<TE>::mfma32(tr_frag<TE>(vl, tr_base, kt, s2, dt), pf[s2], o[dt]);
     }
-    store_rows<TE>(ol, o, 1.0f / l, 32 * qb, L, ctx + (size_t)tok0 * H + head * 64, (size_t)H,
+    store_rows<TE>(ol, o, 1.0f / l, 32 * qb, L, ctx ? ctx + (size_t)tok0 * H + head * 64 : nullptr, (size_t)H,
                    ctx16 ? ctx16 + (size_t)tok0 * H + head * 64 : nullptr, (size_t)H);
     if (h == 0 && q < L) ml[(size_t)(tok0 + q) * heads + head] = float2{m, l};
   }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void bwd_q_wave(const TE* __restrict__ qkv, const TE*
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) dq[dt] = E16<TE>::mfma32(tr_frag<TE>(vl, tr_base, kt, s2, dt), dsf[s2], dq[dt]);
     }
-    store_rows<TE>(ol, dq, 1.0f, 32 * qb, L, dqkv + (size_t)tok0 * ld + head * 64, ld,
+    store_rows<TE>(ol, dq, 1.0f, 32 * qb, L, dqkv ? dqkv + (size_t)tok0 * ld + head * 64 : nullptr, ld,
                    dqkv16 ? dqkv16 + (size_t)tok0 * ld + head * 64 : nullptr, ld);
   }
 }
@@ -416,9 +416,9 @@ __device__ __forceinline__ void bwd_kv_wave(const TE* __restrict__ qkv, const TE
           dk[dt] = E16<TE>::mfma32(tr_frag<TE>(ql, tr_base, qt, s2, dt), dsf[s2], dk[dt]);
         }
     }
-    store_rows<TE>(ol, dk, 1.0f, 32 * kb, L, dqkv + (size_t)tok0 * ld + H + head * 64, ld,
+    store_rows<TE>(ol, dk, 1.0f, 32 * kb, L, dqkv ? dqkv + (size_t)tok0 * ld + H + head * 64 : nullptr, ld,
                    dqkv16 ? dqkv16 + (size_t)tok0 * ld + H + head * 64 : nullptr, ld);
-    store_rows<TE>(ol, dv, 1.0f, 32 * kb, L, dqkv + (size_t)tok0 * ld + 2 * H + head * 64, ld,
+    store_rows<TE>(ol, dv, 1.0f, 32 * kb, L, dqkv ? dqkv + (size_t)tok0 * ld + 2 * H + head * 64 : nullptr, ld,
                    dqkv16 ? dqkv16 + (size_t)tok0 * ld + 2 * H + head * 64 : nullptr, ld);
   }
 }

@@ -334,6 +334,77 @@ class HipEncoder:
             raise RuntimeError(f"manner_hip input error in an earlier encode call: {_status_message(flag)}")
 
 
+class WeightFingerprint:
+    """Tripwire for writes autograd's version counters cannot see (``p.data.mul_(2)``, ``p.data.copy_(ema)``: the ``.data`` alias has a
+    version counter of its own) under a host that caches packed copies of the parameters — the module mirror's inference handle.
+
+    One launch of ``manner_hip_fingerprint`` hashes up to ``SAMPLES`` evenly strided words of every tensor into one word per tensor.
+    ``baseline`` is taken (blocking) when the packed copies are made; ``arm()`` enqueues a fresh fingerprint and its copy into a pinned
+    slot behind an event, ``changed()`` compares the snapshots that have completed — every one but the newest is waited for, as
+    ``_FlagRing`` does for the status word — so a bulk rewrite surfaces at the next call when the device has kept up and at the call
+    after next at the latest, with no host synchronisation per forward; ``changed_now()`` is the blocking form.  A poke into single
+    elements between the samples is not seen: documented limit, ``MannerTextEncoder.invalidate()`` is the exact tool."""
+
+    SAMPLES = 1024
+    SLOTS = 8
+
+    def __init__(self, tensors: Sequence[Tensor], device: torch.device):
+        self.device = torch.device(device)
+        self._keep = [t for t in tensors]
+        n = len(self._keep)
+        with torch.cuda.device(self.device):
+            self._ptrs = torch.tensor([t.data_ptr() for t in self._keep], dtype=torch.int64, device=self.device)
+            self._counts = torch.tensor([t.numel() * t.element_size() // 4 for t in self._keep], dtype=torch.int64, device=self.device)
+            self._out = torch.empty(n, dtype=torch.int32, device=self.device)
+            self._host = torch.zeros((self.SLOTS, n), dtype=torch.int32).pin_memory()
+        self._pending: list = []
+        self._next = 0
+        self.baseline = self._blocking()
+
+    def _launch(self) -> None:
+        _lib.check(_lib.load().manner_hip_fingerprint(_ptr(self._ptrs), _ptr(self._counts), len(self._keep), self.SAMPLES, _ptr(self._out), _stream()))
+
+    def _blocking(self) -> Tensor:
+        with torch.cuda.device(self.device):
+            self._launch()
+            return self._out.cpu()
+
+    def changed_now(self) -> bool:
+        return not torch.equal(self._blocking(), self.baseline)
+
+    def arm(self) -> None:
+        with torch.cuda.device(self.device):
+            i = self._next
+            self._next = (i + 1) % self.SLOTS
+            stale = False
+            for j, (sl, ev) in enumerate(self._pending):
+                if sl == i:                    # the slot comes round before its snapshot was looked at: look now
+                    ev.synchronize()
+                    stale = not torch.equal(self._host[sl], self.baseline)
+                    del self._pending[j]
+                    break
+            self._carry = getattr(self, "_carry", False) or stale
+            self._launch()
+            self._host[i].copy_(self._out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((i, ev))
+
+    def changed(self) -> bool:
+        hit, keep = getattr(self, "_carry", False), []
+        self._carry = False
+        last = len(self._pending) - 1
+        for j, (i, ev) in enumerate(self._pending):
+            if j < last:
+                ev.synchronize()
+            if j < last or ev.query():
+                hit = hit or not torch.equal(self._host[i], self.baseline)
+            else:
+                keep.append((i, ev))
+        self._pending = keep
+        return hit
+
+
 class NewsEmbeddingCache:
     """Content-addressed table of text-encoder outputs (csrc/cache.hip; SURVEY.md §8d mode T behind the drop-in call pattern).
 

@@ -26,6 +26,22 @@ from manner_amd.weights import plm_param_shapes
 _warned_eval_graph = False
 
 
+def autocast_mode(device_type: str = "cuda") -> Optional[str]:
+    """The 16-bit mode the CALLER's autocast state asks for: "f16" under ``torch.autocast("cuda", torch.float16)`` — what Lightning's
+    ``precision: 16-mixed`` plugin wraps every ``*_step`` in (reference configs/trainer/default.yaml:12) — "bf16" under bfloat16
+    autocast (``bf16-mixed``), None outside any autocast region (``trainer.precision=32``).  The reference's modules are plain torch,
+    so this state IS their arithmetic; the mirrors read the same knob instead of a switch of their own."""
+    try:
+        if not torch.is_autocast_enabled(device_type):
+            return None
+        dt = torch.get_autocast_dtype(device_type)
+    except TypeError:                                    # torch < 2.4: the argument-free CUDA forms
+        if not torch.is_autocast_enabled():
+            return None
+        dt = torch.get_autocast_gpu_dtype()
+    return "f16" if dt == torch.float16 else "bf16" if dt == torch.bfloat16 else None
+
+
 def _wants_graph(module: nn.Module, *inputs) -> bool:
     """Does autograd have to record this forward?  The reference's modules are plain torch: whenever grad mode is on and a
     parameter (or an input) requires grad, their output carries a grad_fn — in eval() too (dropout-free fine-tuning,
@@ -120,8 +136,8 @@ class _ParamView:
     """``dict(module.named_parameters())`` without walking the module tree on every forward: 250 us for bert-base, paid twice per
     batch by the unchanged ``CRModule.forward`` right behind a host synchronisation of the reference's own code, i.e. with the GPU idle.
     The view remembers every ``_modules`` / ``_parameters`` dict of the tree and checks, per call, that each still holds the very
-    objects it held (a submodule or Parameter replaced by assignment, an adapter added, ``.to()`` with overwrite-on-conversion: any of
-    these rebuilds the view) — 350 dict look-ups run by ``map`` / ``operator.is_`` without a Python-level loop.  Same names, order and
+    objects it held and still IS the container its module owns (a submodule or Parameter replaced by assignment, an adapter added,
+    ``.to()`` with overwrite-on-conversion, a wrapper that swaps ``module._parameters`` wholesale: any of these rebuilds the view) — 350 dict look-ups run by ``map`` / ``operator.is_`` without a Python-level loop.  Same names, order and
     de-duplication as ``named_parameters()``.  ``state()`` is the (storage address, version counter) fingerprint of the parameters in
     that order — what tells an optimiser step, ``load_state_dict`` or a ``p.data`` swap from "nothing changed"."""
 
@@ -132,9 +148,12 @@ class _ParamView:
     def _build(self) -> None:
         # built into locals and published by ONE attribute assignment: a second thread in get() sees the old or the new snapshot whole
         len_dicts, len_vals, dicts, keys, objs, named, seen = [], [], [], [], [], {}, set()
+        owners, attrs = [], []          # the module __dict__ each container hangs in: a container REPLACED wholesale is seen too
 
         def walk(m: nn.Module, prefix: str) -> None:
-            for d in (m._modules, m._parameters):
+            for a in ("_modules", "_parameters"):
+                d = m.__dict__[a]
+                owners.append(m.__dict__); attrs.append(a)
                 len_dicts.append(d)
                 len_vals.append(len(d))
             for n, p in m._parameters.items():
@@ -147,7 +166,7 @@ class _ParamView:
                 if c is not None:
                     walk(c, prefix + n + ".")
         walk(self.root, "")
-        self._snap = (len_dicts, len_vals, dicts, keys, objs, named, list(named.values()))
+        self._snap = (len_dicts, len_vals, dicts, keys, objs, named, list(named.values()), owners, attrs)
 
     @property
     def named(self) -> dict:
@@ -155,8 +174,9 @@ class _ParamView:
 
     def get(self) -> dict:
         """The name -> Parameter dict (shared between calls: do not mutate it)."""
-        len_dicts, len_vals, dicts, keys, objs, named, _ = self._snap
-        if list(map(len, len_dicts)) != len_vals or not all(map(operator.is_, map(dict.get, dicts, keys), objs)):
+        len_dicts, len_vals, dicts, keys, objs, named, _, owners, attrs = self._snap
+        if (list(map(len, len_dicts)) != len_vals or not all(map(operator.is_, map(dict.get, dicts, keys), objs))
+                or not all(map(operator.is_, map(dict.get, owners, attrs), len_dicts))):
             self._build()
             return self._snap[5]
         return named
@@ -178,10 +198,29 @@ _VERSION = operator.attrgetter("_version")
 class MannerTextEncoder(nn.Module):
     """reference news_encoder.py:11-37."""
 
-    #: arithmetic of the HIP encoder: "bf16" (MFMA bf16, f32 accumulate), "f16" (the same kernels on IEEE half — what the
-    #: reference's `precision: 16-mixed` computes in; ~8x closer to fp32 than bf16 at the same speed), "fp32" (f32 MFMA
-    #: parity mode) or "bf16x3" (f32 activations, split-operand bf16 GEMMs: 2x the fp32 mode, within 2.5e-4)
-    precision: str = os.environ.get("MANNER_HIP_PRECISION", "f16")
+    #: Arithmetic of the HIP inference engine.  None (the default) = FOLLOW THE CALLER, as the reference's plain-torch module does:
+    #: under fp16 autocast (Lightning `precision: 16-mixed`, the shipped configs/trainer/default.yaml:12) "f16" — the MFMA path on
+    #: IEEE half; under bf16 autocast (`bf16-mixed`) "bf16"; outside autocast (`trainer.precision=32`) the parity-grade mode
+    #: "f16x3" (f32 activations, split-operand f16 GEMMs with f32 accumulation: within 1e-4 of the reference's fp32 path, ranking
+    #: indices as the oracle's).  A string pins one mode whatever the caller's state ("f16", "bf16", "fp32" = f32 MFMA, "f16x3",
+    #: "bf16x3"); the environment variable MANNER_HIP_PRECISION pins it for a whole process (A/B runs).
+    precision: Optional[str] = os.environ.get("MANNER_HIP_PRECISION") or None
+
+    def resolved_precision(self) -> str:
+        """The mode the next eval() forward computes in (see ``precision``)."""
+        if self.precision is not None:
+            return self.precision
+        ac = autocast_mode()
+        if ac is not None:
+            return ac
+        cfg = self.plm_model.cfg                       # the split-operand GEMMs tile K in 256s: tiny test models take the f32 MFMA mode
+        return "f16x3" if cfg.hidden % 256 == 0 and cfg.intermediate % 256 == 0 else "fp32"
+
+    def resolved_train_precision(self) -> str:
+        """The GEMM arithmetic of the next train() forward (see ``train_precision``)."""
+        if self.train_precision is not None:
+            return self.train_precision
+        return autocast_mode() or "fp32"
 
     def __init__(self, plm_model: str, frozen_layers: List[int], dropout_probability: float) -> None:
         super().__init__()
@@ -207,6 +246,9 @@ class MannerTextEncoder(nn.Module):
         d["_hip"], d["_hip_key"] = None, None
         d["_cache"] = None
         d.pop("_param_view", None)
+        d.pop("_hip_modes", None)
+        d.pop("_cache_mode", None)
+        d.pop("_fp", None)
         d["_hip_prefix"], d["_hip_prefix_key"] = None, None
         d["_prefix_cache"], d["_prefix_cache_key"] = None, None
         return d
@@ -220,45 +262,90 @@ class MannerTextEncoder(nn.Module):
             view = self.__dict__["_param_view"] = _ParamView(self.plm_model)
         return view.get()
 
-    def _encoder(self, device: torch.device) -> hip.HipEncoder:
+    def _encoder(self, device: torch.device, precision: Optional[str] = None) -> hip.HipEncoder:
         params = self._plm_params()
         view = self.__dict__.get("_param_view")
         state = view.state(params) if view is not None else None
         if state is None:
             state = tuple((p.data_ptr(), p._version) for p in params.values())
-        key = (device, self.precision, state)
-        if self._hip is None or self._hip_key != key:
+        # the handle packs the weights once per mode it has been asked for: a caller that alternates autocast states (a 16-mixed fit
+        # whose sanity check ran outside autocast, an A/B) grows the set instead of rebuilding the engine at every flip
+        mode = precision if precision is not None else self.resolved_precision()
+        key = (device, state)
+        packed = self.__dict__.get("_hip_modes", ())
+        if self._hip is None or self._hip_key != key or mode not in packed:
+            same_weights = self._hip is not None and self._hip_key == key
             if self._hip is not None:
                 try:
                     self._hip.status()           # input-validation flags still pending on the old handle surface here, not never
                 finally:
                     self._hip.close()
                     self._hip = None
-            if getattr(self, "_cache", None) is not None:    # other weights / another precision: every cached embedding is stale
+            if getattr(self, "_cache", None) is not None and not same_weights:    # other weights: every cached embedding is stale
                 self._cache.clear()
-            precisions = tuple(dict.fromkeys(("bf16", "fp32", self.precision)))
+            precisions = tuple(dict.fromkeys((("bf16", "fp32") if not same_weights else tuple(packed)) + (mode,)))
             self._hip = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in params.items()},
                                        precisions=precisions, device=device)
             self._hip_key = key
+            self.__dict__["_hip_modes"] = precisions
+            if not same_weights or self.__dict__.get("_fp") is None:
+                self.__dict__["_fp"] = (hip.WeightFingerprint(list(params.values()), device)
+                                        if self.weight_fingerprint != "0" else None)
         return self._hip
+
+    #: How the inference handle notices parameter writes that torch's version counters do not see (``p.data.mul_(2)``, an EMA swap
+    #: through ``p.data.copy_``; everything autograd-visible — optimiser steps, ``load_state_dict``, ``.to()`` — is caught by the
+    #: (storage address, version) key at once).  "async" (default): a sampled device-side fingerprint of the parameters is enqueued
+    #: after every eval() forward and examined, without blocking, on the way into the next ones — a bulk rewrite rebuilds the handle
+    #: and RAISES at the forward after the stale one (the call after next at the latest), like the input-validation flags: never
+    #: silent, no host synchronisation.  "sync": the fingerprint is read back BEFORE every forward (one small launch + a blocking
+    #: 1 KB copy): the very next forward already computes with the new values.  "0": off.  After a raw ``.data`` write the exact,
+    #: free tool is ``invalidate()``.  Env: MANNER_HIP_WEIGHT_FINGERPRINT.
+    weight_fingerprint: str = os.environ.get("MANNER_HIP_WEIGHT_FINGERPRINT", "async")
+
+    def invalidate(self) -> None:
+        """Forget every copy made of the parameters: the inference handle's packed weights (rebuilt by the next eval() forward), the
+        embedding / frozen-prefix caches computed with them and the training path's 16-bit copies of frozen weights
+        (``train.invalidate_weight_cache``).  Call it after writing parameters through ``.data`` (or any other route that bypasses
+        autograd's version counters)."""
+        if self._hip is not None:
+            try:
+                self._hip.status()
+            finally:
+                self._hip.close()
+                self._hip, self._hip_key = None, None
+        self.__dict__.pop("_hip_modes", None)
+        self.__dict__.pop("_fp", None)
+        if getattr(self, "_cache", None) is not None:
+            self._cache.clear()
+        if getattr(self, "_hip_prefix", None) is not None:
+            self._hip_prefix.close()
+            self._hip_prefix, self._hip_prefix_key = None, None
+        if getattr(self, "_prefix_cache", None) is not None:
+            self._prefix_cache.clear()
+        train.invalidate_weight_cache()
 
     #: GEMM arithmetic of the training path: "f16" / "bf16" ("16-mixed": 16-bit GEMM operands, f32 accumulation, f32
     #: activations and gradients) or "fp32"
-    #: Default bf16: f32's exponent range, so activation gradients need no loss scaling.  "f16" is the arithmetic of the
+    #: "bf16" has f32's exponent range, so activation gradients need no loss scaling.  "f16" is the arithmetic of the
     #: reference's `precision: 16-mixed` and, exactly as there, needs the caller's GradScaler (Lightning's 16-mixed plugin
     #: scales the loss before backward() and unscales .grad afterwards — the engine then sees scaled gradients): token-level
     #: gradients of a fine-tuning step routinely fall below f16's normal range (6e-5) and would flush to zero unscaled.
-    train_precision: str = os.environ.get("MANNER_HIP_TRAIN_PRECISION", "bf16")
+    #: None (the default) = follow the caller's autocast state, as for ``precision``: fp16 autocast (`16-mixed`) -> "f16" — with the
+    #: caller's GradScaler present exactly as in the reference —, bf16 autocast (`bf16-mixed`) -> "bf16", no autocast
+    #: (`trainer.precision=32`) -> "fp32".  A string (or MANNER_HIP_TRAIN_PRECISION for a whole process) pins one mode.
+    train_precision: Optional[str] = os.environ.get("MANNER_HIP_TRAIN_PRECISION") or None
 
     def _prefix_encoder(self, device: torch.device, params) -> hip.HipEncoder:
         """Inference engine for the frozen prefix of the training path: rebuilt only when a FROZEN tensor changes (the
         trainable layers' packed copies go stale after every optimiser step, but encode_hidden never reaches them)."""
-        key = (str(device), self.train_precision,
+        tp = self.resolved_train_precision()
+        key = (str(device), tp,
                tuple((p.data_ptr(), p._version) for p in params.values() if not p.requires_grad))
         if getattr(self, "_hip_prefix", None) is None or self._hip_prefix_key != key:
             if getattr(self, "_hip_prefix", None) is not None:
                 self._hip_prefix.close()
-            prec = self.train_precision if self.train_precision in ("f16", "bf16") else "fp32"
+            prec = tp if tp in ("f16", "bf16") else "fp32"
             self._hip_prefix = hip.HipEncoder(self.plm_model.cfg, {k: v.detach() for k, v in self.plm_model.named_parameters()},
                                               precisions=(prec,), device=device)
             self._hip_prefix_key = key
@@ -270,6 +357,7 @@ class MannerTextEncoder(nn.Module):
         reference's default); with the embeddings frozen too, the frozen prefix runs once on the inference engine.
         ``dropout=False``: the same differentiable engine with every dropout off (eval() with grad mode on)."""
         plm = self.plm_model
+        tp = self.resolved_train_precision()
         params = {k: v for k, v in self._plm_params().items() if not k.startswith("pooler.")}
         emb_frozen = not any(p.requires_grad for k, p in params.items() if k.startswith("embeddings."))
         first_frozen = not any(p.requires_grad for k, p in params.items() if "layer.0." in k)
@@ -290,9 +378,9 @@ class MannerTextEncoder(nn.Module):
                         pc = self._prefix_cache = hip.PrefixCache(plm.cfg.hidden, self.prefix_cache_len, self.prefix_cache_rows, ids.device)
                     self._prefix_cache_key = want
                 with torch.no_grad():
-                    ph = pc.hidden_states(engine, ids, mask, start, self.train_precision if self.train_precision != "fp32" else "fp32")
+                    ph = pc.hidden_states(engine, ids, mask, start, tp)
                 extra = dict(prefix_hidden=ph, start_layer=start)
-        return train.encode_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=on * plm.hidden_dropout_prob,
+        return train.encode_train(plm.cfg, params, ids, mask, precision=tp, p_hidden=on * plm.hidden_dropout_prob,
                                   p_attn=on * plm.attention_probs_dropout_prob, p_out=on * self.dropout.p, seed=seed, prefix_engine=engine,
                                   **extra)
 
@@ -320,22 +408,42 @@ class MannerTextEncoder(nn.Module):
             if not self.training:
                 _warn_eval_graph("MannerTextEncoder")
             return self._forward_train(ids, mask, dropout=self.training)
-        enc = self._encoder(ids.device)
+        mode = self.resolved_precision()
+        enc = self._encoder(ids.device, mode)
+        fp = self.__dict__.get("_fp")
+        if fp is not None:
+            if self.weight_fingerprint == "sync":
+                if fp.changed_now():
+                    self.invalidate()
+                    enc = self._encoder(ids.device, mode)
+                    fp = None
+            elif fp.changed():
+                self.invalidate()
+                raise RuntimeError("MannerTextEncoder: the PLM parameters were rewritten behind autograd's version counters (a write "
+                                   "through p.data?) — up to two earlier eval() forwards computed with the old values.  The handle has "
+                                   "been rebuilt (a retry runs on the new values); call .invalidate() right after such a write, or set "
+                                   "MANNER_HIP_WEIGHT_FINGERPRINT=sync")
         enc.status_poll()
         if self.embedding_cache_rows > 0:
-            out = self._forward_cached(enc, ids, mask)
+            out = self._forward_cached(enc, ids, mask, mode)
         else:
-            out = enc.encode_cls(ids, mask, precision=self.precision)
+            out = enc.encode_cls(ids, mask, precision=mode)
         enc.status_arm()
+        if fp is not None and self.weight_fingerprint != "sync":
+            fp.arm()
         return out
 
-    def _forward_cached(self, enc: hip.HipEncoder, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    def _forward_cached(self, enc: hip.HipEncoder, ids: torch.Tensor, mask: torch.Tensor, mode: str) -> torch.Tensor:
         """eval() forward through the content-addressed cache: encode the rows not seen before, return every row from the table.
         One host read per call (how many rows are new) — the unchanged callers synchronise anyway (`to_dense_batch`, the
         per-row `torch.where` loop of cr_module.py:117-120)."""
         cache = getattr(self, "_cache", None)
         if cache is None or cache.capacity != self.embedding_cache_rows or cache.device != ids.device or cache.dim != self.plm_model.cfg.hidden:
             cache = self._cache = hip.NewsEmbeddingCache(self.plm_model.cfg.hidden, self.embedding_cache_rows, ids.device)
+        if self.__dict__.get("_cache_mode") != mode:          # rows computed in another arithmetic are not this mode's rows
+            if self.__dict__.get("_cache_mode") is not None:
+                cache.clear()
+            self.__dict__["_cache_mode"] = mode
         try:
             rows, state = cache.lookup(ids, mask)
             todo = torch.nonzero(state != 0).squeeze(1)                          # the host read
@@ -343,7 +451,7 @@ class MannerTextEncoder(nn.Module):
             cache.encoded += int(todo.numel())
             out = None
             if todo.numel():
-                fresh = enc.encode_cls(ids.index_select(0, todo), mask.index_select(0, todo), precision=self.precision)
+                fresh = enc.encode_cls(ids.index_select(0, todo), mask.index_select(0, todo), precision=mode)
                 keep = state.index_select(0, todo) == 1
                 cache.table.index_copy_(0, rows.index_select(0, todo)[keep].long(), fresh[keep])
                 if todo.numel() == ids.shape[0]:
@@ -400,7 +508,8 @@ class MannerTextEncoder(nn.Module):
         if not ids.is_cuda:
             raise RuntimeError("MannerTextEncoder.frozen_hidden_states needs GPU tensors — no CPU fallback")
         with torch.no_grad():
-            return self._encoder(ids.device).encode_hidden(ids, mask, n_layers, precision=self.precision, out_dtype=dtype)
+            mode = self.resolved_precision()
+            return self._encoder(ids.device, mode).encode_hidden(ids, mask, n_layers, precision=mode, out_dtype=dtype)
 
 
 class MannerEntityEncoder(nn.Module):
@@ -485,8 +594,9 @@ class PLMTextEncoder(nn.Module):
     the hidden states AT PADDED POSITIONS take part in both — ``hip.encode_full`` (and, with autograd, ``train.encode_full_train``)
     therefore computes them as HF does."""
 
-    #: GEMM arithmetic of the PLM in this class: "fp32" (default: these are baselines, not the throughput path), "f16", "bf16"
-    precision: str = "fp32"
+    #: GEMM arithmetic of the PLM in this class.  None (default) = the caller's autocast state, as MannerTextEncoder: fp16 autocast ->
+    #: "f16", bf16 autocast -> "bf16", none -> "fp32" (these are baselines, not the throughput path); a string pins one mode
+    precision: Optional[str] = None
 
     def __init__(self, plm_model: str, frozen_layers: List[int], text_embedding_dim: int, num_attention_heads: int,
                  query_vector_dim: int, dropout_probability: float) -> None:
@@ -500,8 +610,9 @@ class PLMTextEncoder(nn.Module):
                 if "layer." + str(layer) + "." in name:
                     param.requires_grad = False
 
-    #: GEMM arithmetic of the PLM in train() mode ("fp32", "bf16" or "f16": see MannerTextEncoder.train_precision)
-    train_precision: str = "fp32"
+    #: GEMM arithmetic of the PLM in train() mode ("fp32", "bf16" or "f16"; None = the caller's autocast state, "fp32" outside it: see
+    #: MannerTextEncoder.train_precision)
+    train_precision: Optional[str] = None
 
     def forward(self, tokenized_text) -> torch.Tensor:
         ids, mask = tokenized_text["input_ids"], tokenized_text["attention_mask"]
@@ -520,14 +631,15 @@ class PLMTextEncoder(nn.Module):
             plm = self.plm_model
             params = {k: v for k, v in plm.named_parameters() if not k.startswith("pooler.")}
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            x = train.encode_full_train(plm.cfg, params, ids, mask, precision=self.train_precision, p_hidden=on * plm.hidden_dropout_prob,
+            x = train.encode_full_train(plm.cfg, params, ids, mask, precision=self.train_precision or autocast_mode() or "fp32",
+                                        p_hidden=on * plm.hidden_dropout_prob,
                                         p_attn=on * plm.attention_probs_dropout_prob, seed=seed)
             x = train.dropout(x, on * self.dropout.p, seed, site=4)
             x = train.mha_axis0(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, mha.num_heads)
             x = train.dropout(x, on * self.dropout.p, seed, site=5)
             return train.additive_pool(x, pool.linear.weight, pool.linear.bias, pool.query)
         params = {k: v.detach() for k, v in self.plm_model.named_parameters() if not k.startswith("pooler.")}
-        hidden = hip.encode_full(self.plm_model.cfg, params, ids, mask, precision=self.precision)       # [B, S, D], pads included
+        hidden = hip.encode_full(self.plm_model.cfg, params, ids, mask, precision=self.precision or autocast_mode() or "fp32")   # [B, S, D], pads incl.
         mha, pool = self.multihead_attention, self.additive_attention
         mixed = hip.mha_axis0(hidden, mha.in_proj_weight.detach(), mha.in_proj_bias.detach(), mha.out_proj.weight.detach(),
                               mha.out_proj.bias.detach(), mha.num_heads)

@@ -163,6 +163,7 @@ class _EncodeTrain(torch.autograd.Function):
                 hip._ptr(prefix), C.c_float(opts["p_hidden"]), C.c_float(opts["p_attn"]), C.c_float(opts["p_out"]),
                 C.c_uint64(opts["seed"]), hip._ptr(out), hip._ptr(saved), saved.numel(), hip._ptr(ws), ws.numel(),
                 hip._ptr(status.word), hip._stream()))
+            ctx.layout = int(lib.manner_hip_train_layout_last())    # ABI v8: the saved buffer's layout travels with the autograd ctx
             if wc is not None:
                 _WeightCopyCache.commit(wc[1], wc[2])
             status.arm()                      # snapshot behind an event: examined, without blocking, by the next poll
@@ -188,6 +189,7 @@ class _EncodeTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             g = grad_out.to(torch.float32).contiguous()
             wc = _register_weight_cache(lib, cfg, params, ctx.needs, opts, ctx.start, dev)
+            _lib.check(lib.manner_hip_train_layout_next(ctx.layout))
             _lib.check(lib.manner_hip_train_backward(
                 C.byref(cc), _table([p.detach() for p in params]), len(params), hip._ptr(ids), n, lp, ctx.m_bound, ctx.prec,
                 ctx.start, C.c_float(opts["p_hidden"]), C.c_float(opts["p_attn"]), C.c_float(opts["p_out"]),
@@ -282,6 +284,7 @@ class _EncodeFullTrain(torch.autograd.Function):
                 C.byref(cc), _table(weights), len(weights), hip._ptr(ids), hip._ptr(mask), n, lp, prec, C.c_float(opts["p_hidden"]),
                 C.c_float(opts["p_attn"]), C.c_uint64(opts["seed"]), hip._ptr(out), hip._ptr(saved), saved.numel(), hip._ptr(ws), ws.numel(),
                 hip._ptr(status.word), hip._stream()))
+            ctx.layout = int(lib.manner_hip_train_layout_last())
             status.arm()
         ctx.opts, ctx.prec = opts, prec
         ctx.saved_buf, ctx.ws = saved, ws
@@ -299,6 +302,7 @@ class _EncodeFullTrain(torch.autograd.Function):
         cc = _cfg_c(cfg)
         with torch.cuda.device(ids.device):
             g = grad_out.to(torch.float32).contiguous()
+            _lib.check(lib.manner_hip_train_layout_next(ctx.layout))
             _lib.check(lib.manner_hip_train_full_backward(
                 C.byref(cc), _table([p.detach() for p in params]), len(params), hip._ptr(ids), n, lp, ctx.prec, C.c_float(opts["p_hidden"]),
                 C.c_float(opts["p_attn"]), C.c_uint64(opts["seed"]), hip._ptr(g), hip._ptr(ctx.saved_buf), ctx.saved_buf.numel(), _table(grads),

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 18 and set(syms) == set(_lib.SIGNATURES)
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
-    assert lib.manner_hip_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.manner_hip_abi_version() == _lib.ABI_VERSION == 8
     assert lib.manner_hip_encoder_workspace_bytes(None, 1, 1, 0) == 0          # null handle: no crash
 
 
@@ -752,3 +752,25 @@ def test_cached_parameter_view_equals_named_parameters():
     vers = view.state()[1]
     some.data = some.data.clone()
     assert view.state()[0] != ptrs
+
+
+def test_precision_resolution_follows_the_autocast_state(monkeypatch):
+    """VERDICT r5 item 1 (host logic; the arithmetic itself is tests/test_gpu_boundary.py): the mirror's mode is the caller's
+    autocast state — `trainer.precision` of the reference (configs/trainer/default.yaml:12) — unless a mode is pinned."""
+    import warnings
+    from manner_amd.models.components import news_encoder as ne
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tiny = ne.MannerTextEncoder("tiny-bert", [], 0.2)
+        base = ne.MannerTextEncoder.__new__(ne.MannerTextEncoder)        # resolution needs the config only: no 110 M-parameter init
+        torch.nn.Module.__init__(base)
+        base.plm_model = type("P", (), {"cfg": PRESETS["bert-base-uncased"]})()
+    assert ne.autocast_mode() is None                                     # no autocast region here
+    for state, ev, tr in ((None, "f16x3", "fp32"), ("f16", "f16", "f16"), ("bf16", "bf16", "bf16")):
+        monkeypatch.setattr(ne, "autocast_mode", lambda s=state: s)
+        assert (base.resolved_precision(), base.resolved_train_precision()) == (ev, tr)
+    monkeypatch.setattr(ne, "autocast_mode", lambda: None)
+    assert tiny.resolved_precision() == "fp32"                            # hidden 128: the split-operand GEMMs tile K in 256s
+    base.precision, base.train_precision = "bf16", "f16"                  # pinned modes win
+    monkeypatch.setattr(ne, "autocast_mode", lambda: "f16")
+    assert (base.resolved_precision(), base.resolved_train_precision()) == ("bf16", "f16")
