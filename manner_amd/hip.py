@@ -352,7 +352,8 @@ class WeightFingerprint:
         self.device = torch.device(device)
         self._keep = [t for t in tensors]
         n = len(self._keep)
-        with torch.cuda.device(self.device):
+        # (normal tensors even when the first forward runs under inference_mode: they are updated in place by later no_grad calls)
+        with torch.inference_mode(False), torch.cuda.device(self.device):
             self._ptrs = torch.tensor([t.data_ptr() for t in self._keep], dtype=torch.int64, device=self.device)
             self._counts = torch.tensor([t.numel() * t.element_size() // 4 for t in self._keep], dtype=torch.int64, device=self.device)
             self._out = torch.empty(n, dtype=torch.int32, device=self.device)

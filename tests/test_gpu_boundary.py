@@ -76,7 +76,7 @@ def test_eval_arithmetic_follows_the_callers_autocast_state(golden_dir):
 
 def test_embedding_cache_rows_are_per_mode():
     """Rows cached under one autocast state are not served under another."""
-    enc, cfg = _text_encoder("bert-256", 5, 0.05)
+    enc, cfg = _text_encoder("mini-roberta-large", 5, 0.03)
     enc.eval()
     enc.embedding_cache_rows = 64
     ids, mask = synth_news_tokens(12, cfg, seed=5, max_len=24)

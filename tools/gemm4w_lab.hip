@@ -1,0 +1,342 @@
+// Development lab (round 6): the one work-removing GEMM design DESIGN.md named and never built — FOUR waves per
+// CU, one per SIMD, each owning a 128 x 128 wave tile of the 256 x 256 workgroup tile (256 accumulator registers per lane), against
+// the production main loop (8 waves, 128 x 64 wave tiles) on the same box in the same process.  Per k32 step a wave reads 8 + 8
+// operand fragments for 64 v_mfma_f32_16x16x32 (0.25 ds_read_b128 per MFMA) where the production loop reads 4 + 8 for 32 (0.375):
+// -33 % LDS fragment traffic, and a 4-wave barrier per K-step instead of an 8-wave one.  MAIN LOOPS ONLY, equal pipeline depth
+// (cross-tile prefetch, persistent grid, the production tile order and LDS image).  Not shipped, not part of libmanner_hip.so.
+//
+//   VAR 0  register staging: global_load_dwordx4 -> VGPR -> ds_write_b128, two 64 KiB stages, loads one K-step ahead of their
+//          ds_write (two ahead of their use); with one wave per SIMD an LDS-DMA piece's 60-100 issue cycles come straight out of
+//          the matrix pipe's issue time, a global_load + ds_write_b128 pair costs ~20.
+//   VAR 1  LDS-DMA (global_load_lds_dwordx4), the production pipeline (2 weight + 3 activation stages, activations two K-steps
+//          ahead) with every wave issuing 8 weight + 8 activation pieces per K-step.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imanner_amd/csrc tools/gemm4w_lab.hip -o tools/bin/gemm4w_lab
+//   tools/bin/gemm4w_lab [M=65536] [check]      (check: both variants against a float64 host reference on sampled outputs)
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <random>
+#include "../manner_amd/csrc/gemm.hip"
+namespace manner { int fail(int code, const char* fmt, ...) { fprintf(stderr, "fail %d: %s\n", code, fmt); return code; } }
+using namespace manner;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+namespace lab4 {
+constexpr int BK = 64, ROWB = 128, OPB = 256 * ROWB;      // one operand tile of a K-step: 256 rows x 64 elements = 32 KiB
+constexpr int NPOST = 2;                                  // clusters of a K-step behind its barrier (they compute from registers)
+
+// cluster (0..15) in which piece p (0..15) of the next K-step is written to LDS / requested: spread over the clusters in front of the barrier
+__host__ __device__ constexpr int piece_cluster(int p) { return (p * (16 - NPOST - 1)) / 16; }
+
+template <typename TE, int VAR, bool STORE>
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const TE* __restrict__ X, const TE* __restrict__ W, float* __restrict__ Y,
+                                                        int N, int K, int M, int n_tiles) {
+  typedef typename E16<TE>::v8 e16x8;
+  __shared__ __attribute__((aligned(1024))) char lds[(VAR == 0 ? 4 : 5) * OPB];      // 128 KiB / 160 KiB
+  // ---- the production tile walk: persistent grid, XCD-remapped slot, row-panel-major tile order
+  const int G = gridDim.x, blk = blockIdx.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = blk & 7;
+  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
+  const int valid = (M / 256) * n_tiles;
+  if (slot >= valid) return;
+  const int my_tiles = (valid - slot + G - 1) / G;
+  const int nk = K / BK;
+  const int total = my_tiles * nk;                         // K-steps of this workgroup, across its tiles
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wn = wave & 1, wm = wave >> 1;                 // wave tile: columns 128 wn .., rows 128 wm ..
+  const int l15 = lane & 15, lq = lane >> 4, lrow = lane >> 3, lc = lane & 7;
+
+  // ---- fragment addresses (the production LDS image: 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
+  const int swz = (l15 >> 1) & 7;
+  const int wfrag = (128 * wn + l15) * ROWB, xfrag = (128 * wm + l15) * ROWB;
+  auto coff = [&](int s2) { return ((4 * s2 + lq) ^ swz) << 4; };
+  // stage bases: VAR 0: stage s = [W | X] at s * 2 OPB;  VAR 1: W stage s at s * OPB, X stage x at 2 OPB + x * OPB
+  auto wbase = [&](int cur, int xs) -> const char* { return lds + (VAR == 0 ? cur * 2 * OPB : cur * OPB); };
+  auto xbase = [&](int cur, int xs) -> const char* { return lds + (VAR == 0 ? cur * 2 * OPB + OPB : 2 * OPB + xs * OPB); };
+
+  // ---- the load stream: runs ahead of the compute stream, across tiles
+  // VAR 0: wave (op = wave >> 1, hf = wave & 1) stages rows 128 hf .. + 127 of operand op: 16 pieces of 8 rows;
+  // VAR 1: every wave brings rows 64 wave .. + 63 of BOTH operands: 8 + 8 pieces
+  const int op = wave >> 1, hf = wave & 1;
+  int ld_step = 0;                                         // the K-step the load stream requests next
+  int ld_tile = slot, ld_kt = 0;
+  auto tile_ptr = [&](int tile, int which /*0 W, 1 X*/, int row0) -> const TE* {
+    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+    return (which == 0 ? W + (size_t)(nt * 256 + row0) * K : X + (size_t)(mt * 256 + row0) * K);
+  };
+  const TE* ld_w = nullptr;                                // VAR 0: this wave's operand;  VAR 1: the weight tile
+  const TE* ld_x = nullptr;                                // VAR 1: the activation tile
+  auto ld_point = [&]() {
+    if (VAR == 0) ld_w = tile_ptr(ld_tile, op, 128 * hf + lrow) + lc * 8;
+    else { ld_w = tile_ptr(ld_tile, 0, 64 * wave + lrow) ; ld_x = tile_ptr(ld_tile, 1, 64 * wave + lrow); }
+  };
+  ld_point();
+  auto ld_advance = [&]() {                                // after a whole K-step has been requested
+    ++ld_step;
+    if (++ld_kt == nk) { ld_kt = 0; ld_tile += G; if (ld_step < total) ld_point(); }
+  };
+
+  // VAR 0 staging registers and LDS destinations
+  e16x8 S[16];
+  const int sdst = op * OPB + (128 * hf + lrow) * ROWB;    // + i * 1024 + swizzled chunk
+  auto sdst_of = [&](int i) { return sdst + i * 1024 + ((lc ^ ((4 * (i & 1) + (lrow >> 1)) & 7)) << 4); };
+  auto gload = [&](int i) { S[i] = *reinterpret_cast<const e16x8*>(ld_w + (size_t)(8 * i) * K + ld_kt * BK); };
+  auto swrite = [&](int i, int stage) { *reinterpret_cast<e16x8*>(lds + stage * 2 * OPB + sdst_of(i)) = S[i]; };
+  // VAR 1 LDS-DMA: lane -> (row lrow, source chunk lc ^ f(row)), linear 1 KiB destination per piece
+  auto dma = [&](const TE* src, char* dst, int i) {
+    const int voff = lrow * 0 + ((lc ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * 8);
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + (size_t)(8 * i) * K + ld_kt * BK + voff), LDS_PTR(dst + i * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][8];
+  e16x8 wf[2][8], xf[4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: K-step 0 in LDS, K-step 1 requested (VAR 0: in the staging registers; VAR 1: in flight), first fragments in registers
+  int xs = 0;                                              // VAR 1: activation stage of the current K-step (ring of 3)
+  if (VAR == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gload(i);
+    ld_advance();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) swrite(i, 0);
+    if (ld_step < total) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gload(i);
+      ld_advance();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma(ld_w, lds + 0 * OPB + 64 * wave * ROWB, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma(ld_x, lds + 2 * OPB + 0 * OPB + 64 * wave * ROWB, i);
+    ld_advance();
+    if (ld_step < total) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma(ld_w, lds + 1 * OPB + 64 * wave * ROWB, i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma(ld_x, lds + 2 * OPB + 1 * OPB + 64 * wave * ROWB, i);
+      // (ld_advance for step 1 happens when its successor's activations are issued: see the loop — VAR 1 keeps W and X streams apart)
+    }
+    if (ld_step < total) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int a = 0; a < 8; ++a) wf[0][a] = *reinterpret_cast<const e16x8*>(wbase(0, 0) + wfrag + a * 16 * ROWB + coff(0));
+  xf[0] = *reinterpret_cast<const e16x8*>(xbase(0, 0) + xfrag + coff(0));
+
+  // VAR 1 bookkeeping of its two request streams: weights of step s+2 are issued behind the barrier of step s, activations of step
+  // s+2 in front of it; both walk (tile, kt) on their own
+  int w_tile = slot, w_kt = 2, x_tile = slot, x_kt = 2;
+  if (VAR == 1) {
+    auto norm = [&](int& tile, int& kt) { while (kt >= nk) { kt -= nk; tile += G; } };
+    norm(w_tile, w_kt); norm(x_tile, x_kt);
+  }
+
+  // one K-step; MODE 0: steady state (two more steps follow), 1: second-to-last step of the workgroup, 2: its last step — compile-time,
+  // so that the sixteen clusters of a step are ONE basic block
+  auto kstep = [&](int s, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool more1 = MODE <= 1, more2 = MODE == 0;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+    const char* wb = wbase(cur, xs);
+    const char* xb = xbase(cur, xs);
+    const char* wb1 = wbase(nxt, xs1);
+    const char* xb1 = xbase(nxt, xs1);
+    const TE* xsrc = VAR == 1 && more2 ? tile_ptr(x_tile, 1, 64 * wave + lrow) : nullptr;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int s2 = c >> 3, b = c & 7;
+      const int slot_c = c < 14 ? (c & 1) : c - 12;        // x-fragment slots: 0 / 1 alternate, clusters 14, 15 own slots 2, 3
+      __builtin_amdgcn_sched_barrier(0);
+      // -- the next K-step's operands
+      if (VAR == 0) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          if (piece_cluster(p) == c) {
+            if (more1) swrite(p, nxt);                     // S[p] was requested one K-step ago
+            if (more2) gload(p);                           // ... and is requested again for the step after
+          }
+        if (c == 16 - NPOST - 1 && more2) ld_advance();
+      } else {
+        if (c < 4 && more2) {                              // activations two steps ahead: 2 pieces per cluster
+#pragma unroll
+          for (int i = 2 * c; i < 2 * c + 2; ++i) {
+            const int voff = (lc ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xsrc + (size_t)(8 * i) * K + x_kt * BK + voff),
+                                             LDS_PTR(lds + 2 * OPB + xs2 * OPB + 64 * wave * ROWB + i * 1024), 16, 0, 0);
+          }
+        }
+        if (c == 3 && more2) { if (++x_kt == nk) { x_kt = 0; x_tile += G; } }
+      }
+      // -- fragments of the coming clusters
+      if (c < 8) wf[1][c] = *reinterpret_cast<const e16x8*>(wb + wfrag + c * 16 * ROWB + coff(1));          // s2 = 1's weights
+      if (c < 12) {                                        // cluster c + 1's activation fragment
+        const int cn = c + 1;
+        xf[cn & 1] = *reinterpret_cast<const e16x8*>(xb + xfrag + (cn & 7) * 16 * ROWB + coff(cn >> 3));
+      } else if (c < 14) {                                 // clusters 14 and 15 (slots 2, 3): in registers before the barrier
+        const int cn = c + 2;
+        xf[cn - 12] = *reinterpret_cast<const e16x8*>(xb + xfrag + (cn & 7) * 16 * ROWB + coff(1));
+      }
+      if (c == 12) xf[1] = *reinterpret_cast<const e16x8*>(xb + xfrag + 5 * 16 * ROWB + coff(1));            // cluster 13 (slot 1)
+      if (c >= 14 && more1) {                              // behind the barrier: the next K-step's first fragments from the other stage
+#pragma unroll
+        for (int a = 4 * (c - 14); a < 4 * (c - 14) + 4; ++a)
+          wf[0][a] = *reinterpret_cast<const e16x8*>(wb1 + wfrag + a * 16 * ROWB + coff(0));
+        if (c == 15) xf[0] = *reinterpret_cast<const e16x8*>(xb1 + xfrag + coff(0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // -- 8 matrix instructions: one activation fragment against the wave's 8 weight fragments
+#pragma unroll
+      for (int a = 0; a < 8; ++a) acc[a][b] = E16<TE>::mfma16(wf[s2][a], xf[slot_c], acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 16 - NPOST - 1) {
+        // every read of this step's stage is complete (its last two clusters compute from registers), the next step's operands are in LDS
+        if (VAR == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (more2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (VAR == 1 && more2) {                           // weights two steps ahead into the stage this step has finished with
+          const TE* src = tile_ptr(w_tile, 0, 64 * wave + lrow);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int voff = (lc ^ ((4 * (i & 1) + (lane >> 4)) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + (size_t)(8 * i) * K + w_kt * BK + voff),
+                                             LDS_PTR(lds + cur * OPB + 64 * wave * ROWB + i * 1024), 16, 0, 0);
+          }
+          if (++w_kt == nk) { w_kt = 0; w_tile += G; }
+        }
+      }
+    }
+    xs = xs1;
+  };
+  typedef std::integral_constant<int, 0> Mode0;
+  typedef std::integral_constant<int, 1> Mode1;
+  typedef std::integral_constant<int, 2> Mode2;
+
+  int kt = 0, tile = slot;
+  for (int s = 0; s < total; ++s) {
+    if (s + 2 < total) kstep(s, Mode0{});
+    else if (s + 1 < total) kstep(s, Mode1{});
+    else kstep(s, Mode2{});
+    if (++kt == nk) {                                      // tile done: the lab's "epilogue"
+      if (STORE) {
+        const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int n = nt * 256 + 128 * wn + 16 * a + 4 * lq, m = mt * 256 + 128 * wm + 16 * b + l15;
+            *reinterpret_cast<f32x4*>(Y + (size_t)m * N + n) = acc[a][b];
+          }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) asm volatile("" ::"a"(acc[a][b]));
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      kt = 0;
+      tile += G;
+    }
+  }
+}
+}  // namespace lab4
+
+template <typename F>
+static double time_us(F f, int iters) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); f();
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+  return 1e3 * ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 65536;
+  const bool check = argc > 2 && !strcmp(argv[2], "check");
+  const char* only = argc > 3 ? argv[3] : "";             // "prod" | "v0" | "v1": one arm only (counter passes)
+  struct Shape { const char* name; int N, K; };
+  const Shape shapes[] = {{"qkv", 2304, 768}, {"out", 768, 768}, {"ffn1", 3072, 768}, {"ffn2", 768, 3072}};
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  const size_t xe = (size_t)M * 3072, we = (size_t)3072 * 3072;
+  std::vector<bf16_t> hx(xe), hw(we);
+  for (auto& v : hx) v = (bf16_t)nd(rng);
+  for (auto& v : hw) v = (bf16_t)(0.05f * nd(rng));
+  bf16_t *X, *W; float* bias; float* Y; bf16_t* Y16; int* mtot;
+  CK(hipMalloc(&X, xe * 2)); CK(hipMalloc(&W, we * 2)); CK(hipMalloc(&bias, 3072 * 4)); CK(hipMalloc(&mtot, 4));
+  CK(hipMalloc(&Y, (size_t)M * 3072 * 4)); CK(hipMalloc(&Y16, (size_t)M * 3072 * 2));
+  CK(hipMemcpy(X, hx.data(), xe * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hw.data(), we * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, 3072 * 4));
+  CK(hipMemcpy(mtot, &M, 4, hipMemcpyHostToDevice));
+
+  if (check) {
+    int bad = 0;
+    for (const auto& s : shapes)
+      for (int var = 0; var < 2; ++var) {
+        const int n_tiles = s.N / 256, tiles = (M / 256) * n_tiles;
+        dim3 g(tiles < 256 ? tiles : 256), b(256);
+        CK(hipMemset(Y, 0xff, (size_t)M * s.N * 4));
+        if (var == 0) hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
+        else hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
+        CK(hipDeviceSynchronize());
+        std::vector<float> hy((size_t)M * s.N);
+        CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0.0; size_t nan = 0;
+        std::mt19937 pick(7 + var);
+        for (int q = 0; q < 20000; ++q) {
+          // every tile position gets hit: rows / columns drawn over the whole problem, plus the first and last of each
+          const int m = q < 4 ? (q & 1 ? M - 1 : 0) : (int)(pick() % (unsigned)M), n = q < 4 ? (q & 2 ? s.N - 1 : 0) : (int)(pick() % (unsigned)s.N);
+          double ref = 0.0;
+          for (int k = 0; k < s.K; ++k) ref += (double)(float)hx[(size_t)m * s.K + k] * (double)(float)hw[(size_t)n * s.K + k];
+          const float got = hy[(size_t)m * s.N + n];
+          if (got != got) ++nan;
+          const double err = fabs((double)got - ref) / (1.0 + fabs(ref));
+          if (err > worst) worst = err;
+        }
+        size_t unwritten = 0;
+        for (size_t i = 0; i < hy.size(); i += 97) { uint32_t u; memcpy(&u, &hy[i], 4); if (u == 0xffffffffu) ++unwritten; }
+        printf("check %-4s var %d: worst rel err %.3e over 20000 sampled outputs, NaN %zu, unwritten (sampled) %zu  %s\n", s.name, var, worst, nan,
+               unwritten, worst < 2e-3 && !nan && !unwritten ? "ok" : "WRONG");
+        if (!(worst < 2e-3) || nan || unwritten) bad = 1;
+      }
+    return bad;
+  }
+
+  printf("M = %d, bf16, N(0,1) activations, main loops only (no epilogue); production = gemm_tn_x16_kernel<ABL=1> (8 waves, 128x64 wave tiles)\n", M);
+  for (int rep = 0; rep < 3; ++rep)                        // alternate the arms: same box, same minute
+    for (const auto& s : shapes) {
+      const int n_tiles = s.N / 256, tiles = (M / 256) * n_tiles;
+      const double fl = 2.0 * M * s.N * s.K;
+      dim3 g(tiles < 256 ? tiles : 256);
+      DlnAux aux{};
+      aux.panel_mode = 1; aux.x_rows = M;
+      double tp = 0, t0 = 0, t1 = 0;
+      if (!*only || !strcmp(only, "prod"))
+        tp = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 1>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, 20);
+      if (!*only || !strcmp(only, "v0"))
+        t0 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
+      if (!*only || !strcmp(only, "v1"))
+        t1 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
+      printf("rep %d %-4s N=%4d K=%4d  production %7.1f us %6.0f TF | 4-wave VGPR-staged %7.1f us %6.0f TF (%+5.1f %%) | 4-wave LDS-DMA %7.1f us %6.0f TF (%+5.1f %%)\n",
+             rep, s.name, s.N, s.K, tp, tp ? fl / tp / 1e6 : 0, t0, t0 ? fl / t0 / 1e6 : 0, tp && t0 ? 100 * (t0 / tp - 1) : 0, t1, t1 ? fl / t1 / 1e6 : 0,
+             tp && t1 ? 100 * (t1 / tp - 1) : 0);
+    }
+  return 0;
+}
