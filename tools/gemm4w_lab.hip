@@ -266,10 +266,50 @@ static double time_us(F f, int iters) {
   return 1e3 * ms / iters;
 }
 
+// ---- the hand-scheduled kernel (tools/gen_gemm4w_asm.py -> tools/bin/gemm4w.co): loaded as a code object, tiles from a host-built table
+struct AsmKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  int* table = nullptr;
+  int stride = 0, grid = 0;
+  bool load(const char* path) {
+    if (hipModuleLoad(&mod, path) != hipSuccess) { fprintf(stderr, "cannot load %s (build it: see tools/gen_gemm4w_asm.py)\n", path); return false; }
+    CK(hipModuleGetFunction(&fn, mod, "gemm4w_asm"));
+    return true;
+  }
+  // the production walk: persistent grid of G workgroups, XCD-remapped slot, tile = slot + r G, row-panel-major (mt = tile / n_tiles)
+  void plan(int M, int n_tiles) {
+    const int valid = (M / 256) * n_tiles, G = valid < 256 ? valid : 256;
+    const int maxt = (valid + G - 1) / G;
+    stride = 2 + 2 * (maxt + 1);
+    std::vector<int> h((size_t)G * stride, -1);
+    const int q8 = G >> 3, r8 = G & 7;
+    for (int blk = 0; blk < G; ++blk) {
+      const int xcd = blk & 7;
+      const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
+      int n = 0;
+      for (int t = slot; t < valid; t += G, ++n) { h[(size_t)blk * stride + 2 + 2 * n] = t / n_tiles; h[(size_t)blk * stride + 3 + 2 * n] = t % n_tiles; }
+      h[(size_t)blk * stride] = n;
+      h[(size_t)blk * stride + 1] = 0;
+    }
+    if (table) CK(hipFree(table));
+    CK(hipMalloc(&table, h.size() * 4));
+    CK(hipMemcpy(table, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    grid = G;
+  }
+  void launch(const bf16_t* X, const bf16_t* W, float* Y, int K, int N, int store) {
+    struct { const void* x; const void* w; void* y; const void* t; int k, n, stride, store; } args{X, W, Y, table, K, N, stride, store};
+    size_t sz = sizeof(args);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    CK(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, nullptr, cfg));
+  }
+};
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 65536;
   const bool check = argc > 2 && !strcmp(argv[2], "check");
-  const char* only = argc > 3 ? argv[3] : "";             // "prod" | "v0" | "v1": one arm only (counter passes)
+  const char* only = argc > 3 ? argv[3] : "";             // "prod" | "asm" | "v0" | "v1": one arm only (counter passes); "all": hipcc arms too
+  const bool hipcc_vars = !strcmp(only, "all") || !strcmp(only, "v0") || !strcmp(only, "v1");
   struct Shape { const char* name; int N, K; };
   const Shape shapes[] = {{"qkv", 2304, 768}, {"out", 768, 768}, {"ffn1", 3072, 768}, {"ffn2", 768, 3072}};
   std::mt19937 rng(1);
@@ -285,23 +325,48 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(W, hw.data(), we * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 3072 * 4));
   CK(hipMemcpy(mtot, &M, 4, hipMemcpyHostToDevice));
+  AsmKernel ak;
+  const char* co = getenv("GEMM4W_CO") ? getenv("GEMM4W_CO") : "tools/bin/gemm4w.co";
+  const bool have_asm = ak.load(co);
 
+  if (argc > 2 && !strcmp(argv[2], "debug") && have_asm) {   // register dump of the epilogue's address path (see the generator): first tile of every workgroup
+    const Shape& s = shapes[0];
+    ak.plan(M, s.N / 256);
+    CK(hipMemset(Y, 0, 256 * 256 * 64));
+    ak.launch(X, W, Y, s.K, s.N, (int)(0x80000000u | (unsigned)M));
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> d(256 * 256 * 16);
+    CK(hipMemcpy(d.data(), Y, d.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long y = (unsigned long long)Y;
+    printf("Y = 0x%llx  N = %d\n", y, s.N);
+    for (int wg : {0, 1, 9, 143})
+      for (int t : {0, 1, 63, 64, 128, 192, 255}) {
+        const uint32_t* r = &d[((size_t)wg * 256 + t) * 16];
+        printf("wg %3d tid %3d: v176 %10u  s40:41 (Y + %lld)  N %u | at start: s26 %u s27 %u s28 %u v0 0x%x | at end: s26 %u s27 %u s28 %u mt %d\n", wg, t, r[0],
+               (long long)(((unsigned long long)r[2] << 32 | r[1]) - y), r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], (int)r[11]);
+      }
+    return 0;
+  }
   if (check) {
     int bad = 0;
+    std::vector<int> vars;
+    if (have_asm) vars.push_back(2);
+    if (hipcc_vars) { vars.push_back(0); vars.push_back(1); }
     for (const auto& s : shapes)
-      for (int var = 0; var < 2; ++var) {
+      for (int var : vars) {
         const int n_tiles = s.N / 256, tiles = (M / 256) * n_tiles;
         dim3 g(tiles < 256 ? tiles : 256), b(256);
         CK(hipMemset(Y, 0xff, (size_t)M * s.N * 4));
         if (var == 0) hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
-        else hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
+        else if (var == 1) hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
+        else { ak.plan(M, n_tiles); ak.launch(X, W, Y, s.K, s.N, M); }     // store = rows of Y: the epilogue's address guard
         CK(hipDeviceSynchronize());
         std::vector<float> hy((size_t)M * s.N);
         CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
         double worst = 0.0; size_t nan = 0;
         std::mt19937 pick(7 + var);
         for (int q = 0; q < 20000; ++q) {
-          // every tile position gets hit: rows / columns drawn over the whole problem, plus the first and last of each
+          // rows / columns drawn over the whole problem (every wave, fragment and tile position gets hit), plus the four corners
           const int m = q < 4 ? (q & 1 ? M - 1 : 0) : (int)(pick() % (unsigned)M), n = q < 4 ? (q & 2 ? s.N - 1 : 0) : (int)(pick() % (unsigned)s.N);
           double ref = 0.0;
           for (int k = 0; k < s.K; ++k) ref += (double)(float)hx[(size_t)m * s.K + k] * (double)(float)hw[(size_t)n * s.K + k];
@@ -312,31 +377,39 @@ int main(int argc, char** argv) {
         }
         size_t unwritten = 0;
         for (size_t i = 0; i < hy.size(); i += 97) { uint32_t u; memcpy(&u, &hy[i], 4); if (u == 0xffffffffu) ++unwritten; }
-        printf("check %-4s var %d: worst rel err %.3e over 20000 sampled outputs, NaN %zu, unwritten (sampled) %zu  %s\n", s.name, var, worst, nan,
-               unwritten, worst < 2e-3 && !nan && !unwritten ? "ok" : "WRONG");
-        if (!(worst < 2e-3) || nan || unwritten) bad = 1;
+        const bool ok = worst < 2e-3 && !nan && !unwritten;
+        printf("check %-4s %s: worst rel err %.3e over 20000 sampled outputs, NaN %zu, unwritten (sampled) %zu  %s\n", s.name,
+               var == 2 ? "asm 4-wave" : var == 0 ? "hipcc VAR 0" : "hipcc VAR 1", worst, nan, unwritten, ok ? "ok" : "WRONG");
+        if (!ok) bad = 1;
       }
     return bad;
   }
 
   printf("M = %d, bf16, N(0,1) activations, main loops only (no epilogue); production = gemm_tn_x16_kernel<ABL=1> (8 waves, 128x64 wave tiles)\n", M);
-  for (int rep = 0; rep < 3; ++rep)                        // alternate the arms: same box, same minute
+  auto want = [&](const char* arm) { return !*only || !strcmp(only, "all") || !strcmp(only, arm); };
+  const int iters = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 20, reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 3;
+  for (int rep = 0; rep < reps; ++rep)                        // alternate the arms: same box, same minute
     for (const auto& s : shapes) {
       const int n_tiles = s.N / 256, tiles = (M / 256) * n_tiles;
       const double fl = 2.0 * M * s.N * s.K;
       dim3 g(tiles < 256 ? tiles : 256);
       DlnAux aux{};
       aux.panel_mode = 1; aux.x_rows = M;
-      double tp = 0, t0 = 0, t1 = 0;
-      if (!*only || !strcmp(only, "prod"))
-        tp = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 1>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, 20);
-      if (!*only || !strcmp(only, "v0"))
+      double tp = 0, ta = 0, t0 = 0, t1 = 0;
+      if (want("prod"))
+        tp = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 1>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
+      if (have_asm && want("asm")) {
+        ak.plan(M, n_tiles);
+        ta = time_us([&] { ak.launch(X, W, Y, s.K, s.N, 0); }, iters);
+      }
+      if (hipcc_vars && want("v0"))
         t0 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
-      if (!*only || !strcmp(only, "v1"))
+      if (hipcc_vars && want("v1"))
         t1 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
-      printf("rep %d %-4s N=%4d K=%4d  production %7.1f us %6.0f TF | 4-wave VGPR-staged %7.1f us %6.0f TF (%+5.1f %%) | 4-wave LDS-DMA %7.1f us %6.0f TF (%+5.1f %%)\n",
-             rep, s.name, s.N, s.K, tp, tp ? fl / tp / 1e6 : 0, t0, t0 ? fl / t0 / 1e6 : 0, tp && t0 ? 100 * (t0 / tp - 1) : 0, t1, t1 ? fl / t1 / 1e6 : 0,
-             tp && t1 ? 100 * (t1 / tp - 1) : 0);
+      printf("rep %d %-4s N=%4d K=%4d  production %7.1f us %6.0f TF | 4-wave asm %7.1f us %6.0f TF (%+5.1f %%)", rep, s.name, s.N, s.K, tp,
+             tp ? fl / tp / 1e6 : 0, ta, ta ? fl / ta / 1e6 : 0, tp && ta ? 100 * (ta / tp - 1) : 0);
+      if (hipcc_vars) printf(" | hipcc VAR 0 %7.1f us (%+5.1f %%) | hipcc VAR 1 %7.1f us (%+5.1f %%)", t0, tp && t0 ? 100 * (t0 / tp - 1) : 0, t1, tp && t1 ? 100 * (t1 / tp - 1) : 0);
+      printf("\n");
     }
   return 0;
 }

@@ -79,57 +79,54 @@ class LdsQueue:
         self.q = []
 
 
-POST_READS = [("w", 0, a) for a in range(8)] + [("x", 0)]      # issue order of the reads behind the barrier (and of the prologue)
+# issue order of the reads behind the barrier (and of the prologue): what a step finds in flight when it starts
+POST_READS = [("x", 0)] + [("w", 0, a) for a in range(4)] + [("x", 1)] + [("w", 0, a) for a in range(4, 8)]
 
 
 def kstep(first):
-    """One K-step.  `first`: the tile's first step — its s2 = 0 clusters accumulate onto 0."""
+    """One K-step.  `first`: the tile's first step — its s2 = 0 clusters accumulate onto 0.
+    Activation fragments are read TWO clusters ahead into slot (cluster % 4): the reads of clusters 14 / 15 are issued in 12 / 13
+    (in front of the barrier), clusters 14 / 15 read the NEXT step's clusters 0 / 1 from the other stage."""
     q = LdsQueue(POST_READS)
     for c in range(16):
         s2, b = c >> 3, c & 7
-        slot = (c & 1) if c < 14 else c - 12
+        slot = c & 3
         cmt(f"cluster {c}")
-        mem = []            # (kind, text, tag) issued one per MFMA gap, in order
+        mem = []            # (kind, text, tag) in issue order
+        cn = c + 2          # the activation fragment two clusters ahead first: it is the read with the least slack
+        if cn < 16:
+            mem.append(("lds", f"ds_read_b128 {vr(XF + 4 * (cn & 3))}, v{RX1 if cn >> 3 else RX0} offset:{(cn & 7) * 2048}", ("x", cn)))
+        else:
+            mem.append(("lds", f"ds_read_b128 {vr(XF + 4 * (cn & 3))}, v{RX0} offset:{(cn & 7) * 2048}", ("nx", cn & 7)))
+        if c < 8:
+            mem.append(("lds", f"ds_read_b128 {vr(WF[1] + 4 * c)}, v{RW1} offset:{c * 2048}", ("w", 1, c)))
+        if c >= 14:
+            for a in range(4 * (c - 14), 4 * (c - 14) + 4):
+                mem.append(("lds", f"ds_read_b128 {vr(WF[0] + 4 * a)}, v{RW0} offset:{a * 2048}", ("nw", a)))
         for p in range(16):
             if piece_cluster(p) == c:
                 mem.append(("wait", "s_waitcnt vmcnt(15)", None))
                 mem.append(("lds", f"ds_write_b128 v{WA[p & 1]}, {vr(S0 + 4 * p)} offset:{p * 1024}", ("s", p)))
                 mem.append(("vm", f"global_load_dwordx4 {vr(S0 + 4 * p)}, v{GOFF + p}, s[20:21]", None))
-        if c < 8:
-            mem.append(("lds", f"ds_read_b128 {vr(WF[1] + 4 * c)}, v{RW1} offset:{c * 2048}", ("w", 1, c)))
-        if c < 12:
-            cn = c + 1
-            mem.append(("lds", f"ds_read_b128 {vr(XF + 4 * (cn & 1))}, v{RX1 if cn >> 3 else RX0} offset:{(cn & 7) * 2048}", ("x", cn)))
-        elif c < 14:
-            if c == 12:
-                mem.append(("lds", f"ds_read_b128 {vr(XF + 4)}, v{RX1} offset:{5 * 2048}", ("x", 13)))
-            cn = c + 2
-            mem.append(("lds", f"ds_read_b128 {vr(XF + 4 * (cn - 12))}, v{RX1} offset:{(cn & 7) * 2048}", ("x", cn)))
-        else:
-            for a in range(4 * (c - 14), 4 * (c - 14) + 4):
-                mem.append(("lds", f"ds_read_b128 {vr(WF[0] + 4 * a)}, v{RW0} offset:{a * 2048}", ("w", 0, a)))
-            if c == 15:
-                mem.append(("lds", f"ds_read_b128 {vr(XF)}, v{RX0}", ("x", 0)))
         # address / stream bookkeeping placed after the last use of each register (VALU / SALU fillers in MFMA gaps)
         if c == 8:
             mem.append(("alu", f"v_xor_b32 v{RX0}, 0x10000, v{RX0}", None))
+            mem.append(("alu", f"v_xor_b32 v{RW1}, 0x10000, v{RW1}", None))
         if c == 13:
             mem.append(("alu", f"v_xor_b32 v{WA[0]}, 0x10000, v{WA[0]}", None))
             mem.append(("alu", f"v_xor_b32 v{WA[1]}, 0x10000, v{WA[1]}", None))
             mem.append(("alu", "s_add_u32 s20, s20, 128", None))
             mem.append(("alu", "s_addc_u32 s21, s21, 0", None))
-        # the ("x", 0) tag of the NEXT step must not be confused with this step's: rename on issue
-        gaps = [[] for _ in range(8)]
-        # spread: memory ops of a piece stay together (wait, write, load), everything in issue order, at most ~2 per gap
-        per = max(1, -(-len(mem) // 8))
-        gi = 0
+        # one group per MFMA gap: a piece's (wait, write, load) stays together
+        groups = []
         i = 0
         while i < len(mem):
             take = 3 if mem[i][0] == "wait" else 1
-            if len(gaps[gi]) + take > max(per, take) and gi < 7:
-                gi += 1
-            gaps[gi].extend(mem[i:i + take])
+            groups.append(mem[i:i + take])
             i += take
+        gaps = [[] for _ in range(8)]
+        for gi, g in enumerate(groups):
+            gaps[min(gi, 7) if len(groups) <= 8 else (gi * 8) // len(groups)].extend(g)
         for a in range(8):
             q.need(("w", s2, a))
             if a == 0:
@@ -139,21 +136,17 @@ def kstep(first):
             for kind, text, tag in gaps[a]:
                 e(text)
                 if kind == "lds":
-                    # reads behind the barrier carry next-step tags
-                    if c >= 14:
-                        q.issue(("nw", tag[2]) if tag[0] == "w" else ("nx", 0))
-                    else:
-                        q.issue(tag)
+                    q.issue(tag)
         if c == NPRE - 1:
             e("s_waitcnt lgkmcnt(0)")
             e("s_barrier")
             q.drain()
         if c == 14:
-            e(f"v_xor_b32 v{RW1}, 0x10000, v{RW1}")
             e(f"v_xor_b32 v{RX1}, 0x10000, v{RX1}")
     e(f"v_xor_b32 v{RW0}, 0x10000, v{RW0}")
     # sanity: what is in flight at the end of a step is exactly what the next step assumes
-    assert q.q == [("nw", a) for a in range(8)] + [("nx", 0)], q.q
+    want = [("nx", 0)] + [("nw", a) for a in range(4)] + [("nx", 1)] + [("nw", a) for a in range(4, 8)]
+    assert q.q == want, q.q
 
 
 def calc_base(mt, nt):
@@ -218,7 +211,8 @@ def main(out):
     e("s_lshl_b32 s17, s12, 1")                      # bytes per operand row
     e(f"v_mov_b32 v{VTID}, v0")
     e(f"v_lshrrev_b32 v{VWAVE}, 6, v{VTID}")
-    e(f"v_readfirstlane_b32 s26, v{VWAVE}")
+    e("s_nop 4")                                     # gfx940+: a VALU write of a VGPR needs a wait state before v_readlane / v_readfirstlane reads it
+    e(f"v_readfirstlane_b32 s26, v{VWAVE}")           # (found the hard way: the wave index came back as the register's previous content)
     e(f"v_and_b32 v{VLANE}, 63, v{VTID}")
     e(f"v_and_b32 v{VL15}, 15, v{VLANE}")
     e(f"v_lshrrev_b32 v{VLQ}, 4, v{VLANE}")
@@ -229,6 +223,10 @@ def main(out):
     e("s_nop 4")
     e("s_lshr_b32 s27, s26, 1")                      # op = wm = wave >> 1
     e("s_and_b32 s28, s26, 1")                       # hf = wn = wave & 1
+    e("v_mov_b32 v188, s26")                         # debug copies (dumped by the store-bit-31 path)
+    e("v_mov_b32 v189, s27")
+    e("v_mov_b32 v190, s28")
+    e("v_mov_b32 v191, v0")
     cmt("fragment read addresses: R?s2 = (128 w? + l15) * 128 + (((4 s2 + lq) ^ swz) << 4) [+ 32768 for activations]")
     for s2, rw, rx in ((0, RW0, RX0), (1, RW1, RX1)):
         e(f"v_add_u32 v{VT}, {4 * s2}, v{VLQ}")
@@ -286,9 +284,12 @@ def main(out):
     advance_load_stream(True)
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")
-    for a in range(8):
-        e(f"ds_read_b128 {vr(WF[0] + 4 * a)}, v{RW0} offset:{a * 2048}")
     e(f"ds_read_b128 {vr(XF)}, v{RX0}")
+    for a in range(4):
+        e(f"ds_read_b128 {vr(WF[0] + 4 * a)}, v{RW0} offset:{a * 2048}")
+    e(f"ds_read_b128 {vr(XF + 4)}, v{RX0} offset:2048")
+    for a in range(4, 8):
+        e(f"ds_read_b128 {vr(WF[0] + 4 * a)}, v{RW0} offset:{a * 2048}")
     for r in (WA[0], WA[1], RW0):
         e(f"v_xor_b32 v{r}, 0x10000, v{r}")
     lab(".Ltile")
@@ -315,9 +316,53 @@ def main(out):
     e("s_add_u32 s40, s8, s36")
     e("s_addc_u32 s41, s9, s37")
     e("s_lshl_b32 s38, s13, 6")                      # 16 rows * N * 4 bytes
-    for b in range(8):
-        for a in range(8):
-            e(f"global_store_dwordx4 v{VY}, {ar(a, b)}, s[40:41] offset:{64 * a}")
+    cmt("debug dump (store bit 31): per thread {v176, s40, s41, N, s32, s33, s18, s27|s28<<8} to Y + (min(wg, 255) * 256 + (tid & 255)) * 32")
+    e("s_bitcmp1_b32 s15, 31")
+    e("s_cbranch_scc0 .Lnodump")
+    e("s_min_u32 s44, s2, 255")
+    e("s_lshl_b32 s44, s44, 14")
+    e(f"v_and_b32 v{VT + 4}, 255, v{VTID}")
+    e(f"v_lshlrev_b32 v{VT + 4}, 6, v{VT + 4}")
+    e(f"v_add_u32 v{VT + 4}, s44, v{VT + 4}")
+    e(f"v_mov_b32 v{VT + 1}, s9")
+    e(f"v_add_co_u32 v{VT + 2}, vcc, s8, v{VT + 4}")
+    e(f"v_addc_co_u32 v{VT + 3}, vcc, 0, v{VT + 1}, vcc")
+    e(f"v_mov_b32 v{VT + 6}, v{VY}")
+    e(f"v_mov_b32 v{VT + 7}, s40")
+    e(f"v_mov_b32 v{VT + 8}, s41")
+    e(f"v_mov_b32 v{VT + 9}, s13")
+    e(f"global_store_dwordx4 v[{VT + 2}:{VT + 3}], v[{VT + 6}:{VT + 9}], off")
+    e("s_nop 4")
+    e(f"global_store_dwordx4 v[{VT + 2}:{VT + 3}], v[188:191], off offset:16")
+    e("v_mov_b32 v192, s26")
+    e("v_mov_b32 v193, s27")
+    e("v_mov_b32 v194, s28")
+    e("v_mov_b32 v195, s32")
+    e("s_nop 4")
+    e(f"global_store_dwordx4 v[{VT + 2}:{VT + 3}], v[192:195], off offset:32")
+    e("s_nop 4")
+    e("s_waitcnt vmcnt(0)")
+    e("s_branch .Lexit")
+    lab(".Lnodump")
+    cmt("guard: kernarg `store` = rows M of Y; every lane's 64-bit address is held to [Y, Y + M N 4 - 464] before its 8 stores")
+    e("s_mul_i32 s42, s15, s13")                     # M * N elements (< 2^32 for the lab's sizes)
+    e("s_mov_b32 s43, 0")
+    e("s_lshl_b64 s[42:43], s[42:43], 2")
+    e("s_add_u32 s42, s8, s42")
+    e("s_addc_u32 s43, s9, s43")
+    e("s_sub_u32 s42, s42, 463")
+    e("s_subb_u32 s43, s43, 0")
+    for b_ in range(8):
+        e(f"v_mov_b32 v{VT + 1}, s41")
+        e(f"v_add_co_u32 v{VT + 2}, vcc, s40, v{VY}")
+        e(f"v_addc_co_u32 v{VT + 3}, vcc, 0, v{VT + 1}, vcc")
+        e(f"v_cmp_lt_u64 vcc, v[{VT + 2}:{VT + 3}], s[42:43]")
+        e("s_and_saveexec_b64 s[46:47], vcc")
+        e(f"v_cmp_ge_u64 vcc, v[{VT + 2}:{VT + 3}], s[8:9]")
+        e("s_and_b64 exec, exec, vcc")
+        for a_ in range(8):
+            e(f"global_store_dwordx4 v[{VT + 2}:{VT + 3}], {ar(a_, b_)}, off offset:{64 * a_}")
+        e("s_mov_b64 exec, s[46:47]")
         e("s_add_u32 s40, s40, s38")
         e("s_addc_u32 s41, s41, 0")
     e("s_waitcnt vmcnt(0)")
