@@ -221,7 +221,7 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
         const int64_t n_bound = round_up(n_news, 256);
         const int32_t* n_total = ws.m_total + 1;
         const char* wkv = static_cast<const char*>(w.wqkv_f) + (size_t)H * H * 2;
-        PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, wkv, p.cq2 + H, w.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s))
+        PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, wkv, p.cq2 + H, w.cq1 + H, ws.mr_in, nullptr, ws.qkv, m_bound, 2 * H, H, ws.m_total, s, expect_tokens))
         char* ax = static_cast<char*>(ws.acc_x) + (size_t)cls_off * H * es;
         char* actx = static_cast<char*>(ws.acc_ctx) + (size_t)cls_off * H * es;
         PROF_STEP(MANNER_HIP_PROF_GATHER, gather_cls_ln(dt, ws.x, ws.mr_in, ws.cu, n_news, H, g_in, b_in, ax, s))
@@ -229,12 +229,12 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
         PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_cls(dt, ws.qcls, ws.qkv, actx, ws.cu, n_news, c.heads, H, s))
         break;
       }
-      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, w.wqkv_f, p.cq2, w.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, w.wqkv_f, p.cq2, w.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
       PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
       if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(dt, EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, w.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(dt, EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, w.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
     }

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "train_common.h"
+#include "gemm_w4_asm.inc"
 
 namespace manner {
 namespace {
@@ -897,6 +898,332 @@ __host__ __device__ inline int panel_rows(int M, int n_tiles, int cus, int mode)
   return r192 * 83 < r256 * 97 ? 192 : 256;
 }
 
+// The epilogue of one wave's 128(m) x 64(n) accumulator block acc[a][bb] (a = 16-column block 0..3, bb = 16-row block) of the tile
+// (mt, nt): shared by the 8-wave kernel (ew = its wave: column group ew & 3, row half ew >> 2) and by the 4-wave kernel (round 6), whose
+// waves own 128 x 128 and call it once per 64-column half with the virtual wave index 4 wm + 2 wn + half — the same expressions in the
+// same order, hence the same bits.  slab / rslab1: two wave-private 4 KiB LDS slabs (rslab1: EPI_NRES only).
+template <typename TE, typename TOut, int EPI, int ABL, int MBT>
+__device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, char* rslab1, int lane, int ew, int mt, int nt, int M, int N,
+                                             const float* __restrict__ bias, const TE* __restrict__ R, TOut* __restrict__ Y, const DlnAux& dln) {
+  typedef typename E16<TE>::v8 e16x8;
+  typedef typename E16<TE>::v4 e16x4;
+  constexpr int TM = 32 * MBT, WROWS = TM / 2;
+  constexpr int OUT_ROW = 64 * sizeof(TOut);
+  constexpr int CHUNKS = OUT_ROW / 16;
+  constexpr int OPC = 16 / sizeof(TOut);
+  constexpr int ROWS_PER_INST = 64 / CHUNKS;
+  if constexpr (EPI == EPI_NRES) {
+    // ---- residual epilogue of the deferred-LayerNorm path (K4/K6 tails, modeling_bert.py:289-293, 347-351), in
+    // the MFMA register layout (lane = token 16b + l15, features 16a + 4lq .. +3), in place on R == Y:
+    //   v = acc + (bias + beta) + ((raw - mean) * rstd) * gamma        (f32; `bias` already holds bias + beta)
+    //   per row {sum, sum of squares} over the wave's 64 columns -> part[m][4 nt + wn]
+    //   v -> bf16 slab -> whole 128-byte row segments.
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
+    const int nbase = nt * G_BN + wn * 64;
+    const int mrow0 = mt * TM + wm * WROWS;
+    if (ABL == 1) {                                  // lab: main loop only
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < MBT; ++bb) asm volatile("" ::"v"(acc[a][bb]));
+    } else {
+      f32x4 bv[4], g4[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+        g4[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
+      }
+      // The residual is fetched as whole 128-byte row segments (16 B per lane, the same coalesced shape as the
+      // output stores) and turned into the MFMA layout through two wave-private 4 KiB LDS slabs: 8-byte loads
+      // straight in the MFMA layout touch 16 rows per instruction and cost ~10 us per tile in the address path.
+      char* rslab0 = slab;                                          // 32 rows each, XOR-swizzled 16-byte chunks (rslab1: the caller's second slab)
+      const int rrow0 = el >> 3, rsl = el & 7;
+#pragma unroll
+      for (int hb = 0; hb < (MBT + 3) / 4; ++hb) {     // halves of 4 token blocks (64 rows = two slabs; a 192-row tile's
+        const int nsb = MBT / 2 - 2 * hb >= 2 ? 2 : 1; // second half has one: 32 rows); keeping more loads in flight (all 16,
+        const int nb4 = 2 * nsb;                       // or half 1 under half 0's arithmetic) measured 15 % slower per tile
+        f32x4 rawres[2][4];
+        float2 ms[4];
+#pragma unroll
+        for (int sb = 0; sb < nsb; ++sb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + rrow0;
+            const int m = min(mrow0 + 64 * hb + 32 * sb + row, M - 1);
+            rawres[sb][q] = ABL == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R + (size_t)m * N + nbase + 8 * (rsl ^ (row & 7)));
+          }
+#pragma unroll
+        for (int b4 = 0; b4 < nb4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
+#pragma unroll
+        for (int sb = 0; sb < nsb; ++sb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + rrow0;
+            *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
+          }
+        __builtin_amdgcn_wave_barrier();
+        e16x4 res[4][4];
+#pragma unroll
+        for (int b4 = 0; b4 < nb4; ++b4) {
+          const int row = 16 * (b4 & 1) + l15;
+          const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int c = (16 * a + 4 * lq) / 8;
+            res[b4][a] = *reinterpret_cast<const e16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b4 = 0; b4 < nb4; ++b4) {
+          const int bb = 4 * hb + b4;
+          const float rs = ms[b4].y, nm = -ms[b4].x * ms[b4].y;
+          float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float r = fmaf((float)res[b4][a][e], rs, nm);
+              const float x = fmaf(r, g4[a][e], acc[a][bb][e] + bv[a][e]);
+              acc[a][bb][e] = x;
+              p1 += x;
+              p2 = fmaf(x, x, p2);
+            }
+          p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
+          p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
+          const int m = mrow0 + 16 * bb + l15;
+          if (ABL == 4) asm volatile("" ::"v"(p1), "v"(p2));
+          else if (ABL != 2 && lq == 0 && m < M) dln.part[(size_t)(4 * nt + wn) * dln.part_stride + m] = float2{p1, p2};
+        }
+      }
+    }
+    if (ABL != 1) {
+      const int row0 = el >> 3, sl = el & 7;
+#pragma unroll
+      for (int j = 0; j < MBT / 2; ++j) {
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int row = 16 * b2 + l15;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int c = (16 * a + 4 * lq) / 8;
+            store4<TE>(reinterpret_cast<TE*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)),
+                           acc[a][2 * j + b2][0], acc[a][2 * j + b2][1], acc[a][2 * j + b2][2], acc[a][2 * j + b2][3]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 8 * q + row0;
+          const int c = sl ^ (row & 7);
+          const int m = mrow0 + 32 * j + row;
+          const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * 128 + (sl << 4));
+          if (m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<TE*>(Y) + (size_t)m * N + nbase + 8 * c) = raw;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    return;
+  }
+  // ---- epilogue: 4 KiB slabs through a wave-private XOR-swizzled LDS slab, whole-row 16-byte stores.
+  // The epilogue's lane-constant addressing is recomputed per tile from an opaque copy of the lane
+  // id: hoisted out of the tile loop it would stay live across the K-loop and spill (the K-loop
+  // already uses ~240 of the 256 registers).
+  int el = lane;
+  asm volatile("" : "+v"(el));
+  const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
+  // slabs: 4 KiB per wave (the caller's `slab`: in the activation stage the last K-step has finished with); the
+  // f32 output path therefore moves 16-token half slabs
+  const int nbase = nt * G_BN + wn * 64;
+  const int row0 = el / CHUNKS, sl = el % CHUNKS;
+  f32x4 bv[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
+  constexpr bool NORM = EPI == EPI_NORM || EPI == EPI_NORM_GELU;   // deferred LayerNorm of the A operand
+  constexpr bool SPLIT = EPI == EPI_BIAS_GELU_SPLIT3;              // 16-bit [hi | hi | lo] output rows of 3 N elements
+  const size_t ldy = SPLIT ? (size_t)3 * N : (size_t)N;
+  f32x4 cv[NORM ? 4 : 1];
+  float2 ms[NORM ? MBT : 1];
+  const int mrow0 = mt * TM + wm * WROWS;            // first row of this wave's tile
+  if constexpr (NORM) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cv[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
+#pragma unroll
+    for (int bb = 0; bb < MBT; ++bb) ms[bb] = dln.mr[min(mrow0 + 16 * bb + l15, M - 1)];
+  }
+  constexpr int SLAB_ROWS = 4096 / OUT_ROW;          // 32 tokens (bf16) / 16 tokens (f32) per slab
+  constexpr int MB = SLAB_ROWS / 16;                 // MFMA token blocks per slab
+  constexpr int SQ = SLAB_ROWS / ROWS_PER_INST;      // row-contiguous 16-byte instructions per slab (4)
+#pragma unroll
+  for (int j = 0; j < WROWS / SLAB_ROWS; ++j) {
+#pragma unroll
+    for (int b2 = 0; b2 < MB; ++b2) {
+      const int row = 16 * b2 + l15;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int nl = 16 * a + 4 * lq;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (NORM) v[e] = fmaf(ms[MB * j + b2].y, fmaf(-ms[MB * j + b2].x, cv[a][e], acc[a][MB * j + b2][e]), bv[a][e]);
+          else v[e] = acc[a][MB * j + b2][e] + bv[a][e];
+        }
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU || SPLIT) {
+#pragma unroll
+          // f32 out: erff; split (x3 modes' FFN1): the |error| <= 1.5e-7 erf by exp / rcp (2 transcendentals + 6 FMAs against erff's
+          // ~30-instruction expansion: this epilogue was 177 us of an 881 us launch) — two orders below the mode's measured 1e-5
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf_fast(v[e]) : sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);
+        }
+        const int c = nl / OPC;
+        const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
+        if constexpr (SPLIT) {
+          // hi is converted ONCE and the remainder is taken against that very value (a second f32 -> 16-bit conversion of v may
+          // be a different instruction — packed vs scalar — and round a tie the other way: hi + lo would then miss v by an ulp
+          // of hi); the remainders go through the slab in a second pass
+          typedef TOut o4 __attribute__((ext_vector_type(4)));
+          o4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (TOut)v[e];
+          asm volatile("" : "+v"(hv));                 // opaque: the store and the remainder below use THESE bits
+          *reinterpret_cast<o4*>(slab + off) = hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a][MB * j + b2][e] = v[e] - (float)hv[e];
+        } else {
+          store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (SPLIT) {
+      // pass 1: the hi rows go out twice (columns n and N + n); pass 2: the lo rows (columns 2 N + n)
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int c = sl ^ (row & (CHUNKS - 1));
+        const int m = mrow0 + SLAB_ROWS * j + row;
+        const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+        if (m < M) {
+          TOut* dst = Y + (size_t)m * ldy + nbase + c * OPC;
+          __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst));
+          __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst + N));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b2 = 0; b2 < MB; ++b2) {
+        const int row = 16 * b2 + l15;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int c = (16 * a + 4 * lq) / OPC;
+          const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + 8 * (lq & 1);
+          store4<TOut>(reinterpret_cast<TOut*>(slab + off), acc[a][MB * j + b2][0], acc[a][MB * j + b2][1], acc[a][MB * j + b2][2],
+                       acc[a][MB * j + b2][3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int c = sl ^ (row & (CHUNKS - 1));
+        const int m = mrow0 + SLAB_ROWS * j + row;
+        const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+        if (m < M) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + 2 * (size_t)N + nbase + c * OPC));
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    e16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
+    f32x4 resf[EPI == EPI_BIAS_RES_F32 ? SQ : 1];
+    if ((EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_F32) && ABL != 1) {   // TOut == float: the slab's residual loads in one batch
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
+        const size_t idx = (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC;
+        if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const e16x4*>(R + idx);
+        else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
+      }
+    }
+    f32x4 pre16v[EPI == EPI_GELU_GRAD16 ? SQ : 1];
+    if constexpr (EPI == EPI_GELU_GRAD16) {                              // TOut == TE: 8 outputs per chunk, their 8 saved 16-bit pre-activations
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
+        pre16v[q] = *reinterpret_cast<const f32x4*>(static_cast<const TE*>(dln.pre16) + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+      }
+    }
+    f32x4 pre[EPI == EPI_GELU_GRAD ? SQ : 1][2];
+    if constexpr (EPI == EPI_GELU_GRAD) {                                // TOut == TE: 8 outputs per chunk, their 8 saved f32 pre-activations
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int row = q * ROWS_PER_INST + row0;
+        const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
+        const f32x4* ip = reinterpret_cast<const f32x4*>(dln.aux32 + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
+        pre[q][0] = ip[0];
+        pre[q][1] = ip[1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int row = q * ROWS_PER_INST + row0;
+      const int c = sl ^ (row & (CHUNKS - 1));
+      const int m = mrow0 + SLAB_ROWS * j + row;
+      f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
+      if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
+      if constexpr (EPI == EPI_GELU_GRAD) {
+        e16x8 d = __builtin_bit_cast(e16x8, raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast(pre[q][e >> 2][e & 3]));
+        raw = __builtin_bit_cast(f32x4, d);
+      }
+      if constexpr (EPI == EPI_GELU_GRAD16) {
+        e16x8 d = __builtin_bit_cast(e16x8, raw);
+        const e16x8 pv = __builtin_bit_cast(e16x8, pre16v[q]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast((float)pv[e]));
+        raw = __builtin_bit_cast(f32x4, d);
+      }
+      if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
+      }
+      if (EPI == EPI_BIAS_RES_F32) {
+        if (dln.drop_thr != 0) {                                   // dropout on the GEMM output, then the residual (r = dropout(y) + x)
+          const uint64_t di = (uint64_t)(dln.drop_rowmap ? dln.drop_rowmap[min(m, M - 1)] : m) * N + (nbase + c * OPC);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) raw[e] = drop_bits(dln.drop_seed, dln.drop_site, di + e) >= dln.drop_thr ? raw[e] * dln.drop_scale : 0.f;
+        }
+        raw += resf[q];
+      }
+      if (m < M) {
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
+        // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
+        // that they do not push the weight tiles, re-read by every row panel, out of the XCD's 4 MB L2
+        if (NORM && ABL != 5 && !dln.plain_stores) __builtin_nontemporal_store(raw, dst);
+        else *dst = raw;
+        if constexpr (EPI == EPI_BIAS_GELU_DUAL) {                       // TOut == float: 4 pre-activations -> 4 gelu values, 8-byte store
+          e16x4 gv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] = (TE)gelu_erf_fast(raw[e]);
+          *reinterpret_cast<e16x4*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
+        }
+        if constexpr (EPI == EPI_BIAS_GELU_DUAL16) {                     // TOut == TE: 8 rounded pre-activations -> their 8 gelu values
+          const e16x8 pv = __builtin_bit_cast(e16x8, raw);
+          e16x8 gv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gv[e] = (TE)gelu_erf_fast((float)pv[e]);
+          *reinterpret_cast<e16x8*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
 // MBT = 16-row MFMA token blocks per wave: 8 (256-row tile, wave tile 128 x 64) or 6 (192-row tile, wave tile 96 x 64).  The weight
 // half of a tile (256 columns: 4 waves x 64) is the same for both; the activation stage keeps its 32 KiB stride and holds 24 KiB.
 template <typename TE, typename TOut, int EPI, int ABL, int MBT>
@@ -905,7 +1232,6 @@ __device__ __forceinline__ void gemm_tn_x16_body(
     const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, int M, int n_tiles, const DlnAux& dln) {
   typedef TE TIn;                               // bf16_t or f16_t (E16<TE>: vector types and the MFMA of the type)
   typedef typename E16<TE>::v8 e16x8;
-  typedef typename E16<TE>::v4 e16x4;
   constexpr int EPC = 8, BK = 64;
   constexpr int TM = 32 * MBT;                  // rows of a tile
   constexpr int HB = MBT / 2;                   // token blocks per m-half of a K-step chunk (and DMA piece pairs of an activation wave)
@@ -1075,10 +1401,6 @@ __device__ __forceinline__ void gemm_tn_x16_body(
   typedef std::integral_constant<int, 1> Mode1;
   typedef std::integral_constant<int, 2> Mode2;
 
-  constexpr int OUT_ROW = 64 * sizeof(TOut);
-  constexpr int CHUNKS = OUT_ROW / 16;
-  constexpr int OPC = 16 / sizeof(TOut);
-  constexpr int ROWS_PER_INST = 64 / CHUNKS;
   const int nk = K / BK;
 
   Src gsrc = tile_src(t);
@@ -1128,321 +1450,11 @@ __device__ __forceinline__ void gemm_tn_x16_body(
     const int xfree = xs;              // activation stage of the last step: free for the epilogue slabs
     xs = xs == 2 ? 0 : xs + 1;
 
-    if constexpr (EPI == EPI_NRES) {
-      // ---- residual epilogue of the deferred-LayerNorm path (K4/K6 tails, modeling_bert.py:289-293, 347-351), in
-      // the MFMA register layout (lane = token 16b + l15, features 16a + 4lq .. +3), in place on R == Y:
-      //   v = acc + (bias + beta) + ((raw - mean) * rstd) * gamma        (f32; `bias` already holds bias + beta)
-      //   per row {sum, sum of squares} over the wave's 64 columns -> part[m][4 nt + wn]
-      //   v -> bf16 slab -> whole 128-byte row segments.
-      int el = lane, ew = wave;
-      asm volatile("" : "+v"(el), "+s"(ew));
-      const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
-      char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;       // 32 rows x 64 bf16, XOR-swizzled chunks
-      const int nbase = nt * G_BN + wn * 64;
-      const int mrow0 = mt * TM + wm * WROWS;
-      if (ABL == 1) {                                  // lab: main loop only
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int bb = 0; bb < MBT; ++bb) asm volatile("" ::"v"(acc[a][bb]));
-      } else {
-        f32x4 bv[4], g4[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
-          g4[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
-        }
-        // The residual is fetched as whole 128-byte row segments (16 B per lane, the same coalesced shape as the
-        // output stores) and turned into the MFMA layout through two wave-private 4 KiB LDS slabs: 8-byte loads
-        // straight in the MFMA layout touch 16 rows per instruction and cost ~10 us per tile in the address path.
-        char* rslab0 = slab;                                          // 32 rows each, XOR-swizzled 16-byte chunks
-        char* rslab1 = lds + last * G_OP_BYTES + ew * 4096;           // the weight stage of the last K-step is free too
-        const int rrow0 = el >> 3, rsl = el & 7;
-#pragma unroll
-        for (int hb = 0; hb < (MBT + 3) / 4; ++hb) {     // halves of 4 token blocks (64 rows = two slabs; a 192-row tile's
-          const int nsb = MBT / 2 - 2 * hb >= 2 ? 2 : 1; // second half has one: 32 rows); keeping more loads in flight (all 16,
-          const int nb4 = 2 * nsb;                       // or half 1 under half 0's arithmetic) measured 15 % slower per tile
-          f32x4 rawres[2][4];
-          float2 ms[4];
-#pragma unroll
-          for (int sb = 0; sb < nsb; ++sb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = 8 * q + rrow0;
-              const int m = min(mrow0 + 64 * hb + 32 * sb + row, M - 1);
-              rawres[sb][q] = ABL == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R + (size_t)m * N + nbase + 8 * (rsl ^ (row & 7)));
-            }
-#pragma unroll
-          for (int b4 = 0; b4 < nb4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
-#pragma unroll
-          for (int sb = 0; sb < nsb; ++sb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = 8 * q + rrow0;
-              *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
-            }
-          __builtin_amdgcn_wave_barrier();
-          e16x4 res[4][4];
-#pragma unroll
-          for (int b4 = 0; b4 < nb4; ++b4) {
-            const int row = 16 * (b4 & 1) + l15;
-            const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const int c = (16 * a + 4 * lq) / 8;
-              res[b4][a] = *reinterpret_cast<const e16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int b4 = 0; b4 < nb4; ++b4) {
-            const int bb = 4 * hb + b4;
-            const float rs = ms[b4].y, nm = -ms[b4].x * ms[b4].y;
-            float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float r = fmaf((float)res[b4][a][e], rs, nm);
-                const float x = fmaf(r, g4[a][e], acc[a][bb][e] + bv[a][e]);
-                acc[a][bb][e] = x;
-                p1 += x;
-                p2 = fmaf(x, x, p2);
-              }
-            p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
-            p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
-            const int m = mrow0 + 16 * bb + l15;
-            if (ABL == 4) asm volatile("" ::"v"(p1), "v"(p2));
-            else if (ABL != 2 && lq == 0 && m < M) dln.part[(size_t)(4 * nt + wn) * dln.part_stride + m] = float2{p1, p2};
-          }
-        }
-      }
-      if (ABL != 1) {
-        const int row0 = el >> 3, sl = el & 7;
-#pragma unroll
-        for (int j = 0; j < MBT / 2; ++j) {
-#pragma unroll
-          for (int b2 = 0; b2 < 2; ++b2) {
-            const int row = 16 * b2 + l15;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const int c = (16 * a + 4 * lq) / 8;
-              store4<TE>(reinterpret_cast<TE*>(slab + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1)),
-                             acc[a][2 * j + b2][0], acc[a][2 * j + b2][1], acc[a][2 * j + b2][2], acc[a][2 * j + b2][3]);
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 8 * q + row0;
-            const int c = sl ^ (row & 7);
-            const int m = mrow0 + 32 * j + row;
-            const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * 128 + (sl << 4));
-            if (m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<TE*>(Y) + (size_t)m * N + nbase + 8 * c) = raw;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      if (!has_next) break;
-      t = tn;
-      gsrc = gnext;
-      buf = last ^ 1;
-      continue;
-    }
-    // ---- epilogue: 4 KiB slabs through a wave-private XOR-swizzled LDS slab, whole-row 16-byte stores.
-    // The epilogue's lane-constant addressing is recomputed per tile from an opaque copy of the lane
-    // id: hoisted out of the tile loop it would stay live across the K-loop and spill (the K-loop
-    // already uses ~240 of the 256 registers).
-    int el = lane, ew = wave;
-    asm volatile("" : "+v"(el), "+s"(ew));
-    const int l15 = el & 15, lq = el >> 4, wn = ew & 3, wm = ew >> 2;
-    // slabs: 4 KiB per wave in the activation stage the last K-step has finished with (32 KiB); the
-    // f32 output path therefore moves 16-token half slabs
-    char* slab = lds + XB + xfree * G_OP_BYTES + ew * 4096;
-    const int nbase = nt * G_BN + wn * 64;
-    const int row0 = el / CHUNKS, sl = el % CHUNKS;
-    f32x4 bv[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + nbase + 16 * a + 4 * lq);
-    constexpr bool NORM = EPI == EPI_NORM || EPI == EPI_NORM_GELU;   // deferred LayerNorm of the A operand
-    constexpr bool SPLIT = EPI == EPI_BIAS_GELU_SPLIT3;              // 16-bit [hi | hi | lo] output rows of 3 N elements
-    const size_t ldy = SPLIT ? (size_t)3 * N : (size_t)N;
-    f32x4 cv[NORM ? 4 : 1];
-    float2 ms[NORM ? MBT : 1];
-    const int mrow0 = mt * TM + wm * WROWS;            // first row of this wave's tile
-    if constexpr (NORM) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cv[a] = *reinterpret_cast<const f32x4*>(dln.vec + nbase + 16 * a + 4 * lq);
-#pragma unroll
-      for (int bb = 0; bb < MBT; ++bb) ms[bb] = dln.mr[min(mrow0 + 16 * bb + l15, M - 1)];
-    }
-    constexpr int SLAB_ROWS = 4096 / OUT_ROW;          // 32 tokens (bf16) / 16 tokens (f32) per slab
-    constexpr int MB = SLAB_ROWS / 16;                 // MFMA token blocks per slab
-    constexpr int SQ = SLAB_ROWS / ROWS_PER_INST;      // row-contiguous 16-byte instructions per slab (4)
-#pragma unroll
-    for (int j = 0; j < WROWS / SLAB_ROWS; ++j) {
-#pragma unroll
-      for (int b2 = 0; b2 < MB; ++b2) {
-        const int row = 16 * b2 + l15;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int nl = 16 * a + 4 * lq;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if constexpr (NORM) v[e] = fmaf(ms[MB * j + b2].y, fmaf(-ms[MB * j + b2].x, cv[a][e], acc[a][MB * j + b2][e]), bv[a][e]);
-            else v[e] = acc[a][MB * j + b2][e] + bv[a][e];
-          }
-          if (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU || SPLIT) {
-#pragma unroll
-            // f32 out: erff; split (x3 modes' FFN1): the |error| <= 1.5e-7 erf by exp / rcp (2 transcendentals + 6 FMAs against erff's
-            // ~30-instruction expansion: this epilogue was 177 us of an 881 us launch) — two orders below the mode's measured 1e-5
-            for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf_fast(v[e]) : sizeof(TOut) == 4 ? gelu_erf(v[e]) : gelu_poly(v[e]);
-          }
-          const int c = nl / OPC;
-          const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + (sizeof(TOut) == 2 ? 8 * (lq & 1) : 0);
-          if constexpr (SPLIT) {
-            // hi is converted ONCE and the remainder is taken against that very value (a second f32 -> 16-bit conversion of v may
-            // be a different instruction — packed vs scalar — and round a tie the other way: hi + lo would then miss v by an ulp
-            // of hi); the remainders go through the slab in a second pass
-            typedef TOut o4 __attribute__((ext_vector_type(4)));
-            o4 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (TOut)v[e];
-            asm volatile("" : "+v"(hv));                 // opaque: the store and the remainder below use THESE bits
-            *reinterpret_cast<o4*>(slab + off) = hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][MB * j + b2][e] = v[e] - (float)hv[e];
-          } else {
-            store4<TOut>(reinterpret_cast<TOut*>(slab + off), v[0], v[1], v[2], v[3]);
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (SPLIT) {
-        // pass 1: the hi rows go out twice (columns n and N + n); pass 2: the lo rows (columns 2 N + n)
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          const int row = q * ROWS_PER_INST + row0;
-          const int c = sl ^ (row & (CHUNKS - 1));
-          const int m = mrow0 + SLAB_ROWS * j + row;
-          const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
-          if (m < M) {
-            TOut* dst = Y + (size_t)m * ldy + nbase + c * OPC;
-            __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst));
-            __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(dst + N));
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int b2 = 0; b2 < MB; ++b2) {
-          const int row = 16 * b2 + l15;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int c = (16 * a + 4 * lq) / OPC;
-            const int off = row * OUT_ROW + ((c ^ (row & (CHUNKS - 1))) << 4) + 8 * (lq & 1);
-            store4<TOut>(reinterpret_cast<TOut*>(slab + off), acc[a][MB * j + b2][0], acc[a][MB * j + b2][1], acc[a][MB * j + b2][2],
-                         acc[a][MB * j + b2][3]);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          const int row = q * ROWS_PER_INST + row0;
-          const int c = sl ^ (row & (CHUNKS - 1));
-          const int m = mrow0 + SLAB_ROWS * j + row;
-          const f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
-          if (m < M) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + 2 * (size_t)N + nbase + c * OPC));
-        }
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-      e16x4 res[EPI == EPI_BIAS_RES ? SQ : 1];
-      f32x4 resf[EPI == EPI_BIAS_RES_F32 ? SQ : 1];
-      if ((EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_F32) && ABL != 1) {   // TOut == float: the slab's residual loads in one batch
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
-          const size_t idx = (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC;
-          if (EPI == EPI_BIAS_RES) res[q] = *reinterpret_cast<const e16x4*>(R + idx);
-          else resf[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + idx);
-        }
-      }
-      f32x4 pre16v[EPI == EPI_GELU_GRAD16 ? SQ : 1];
-      if constexpr (EPI == EPI_GELU_GRAD16) {                              // TOut == TE: 8 outputs per chunk, their 8 saved 16-bit pre-activations
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
-          pre16v[q] = *reinterpret_cast<const f32x4*>(static_cast<const TE*>(dln.pre16) + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
-        }
-      }
-      f32x4 pre[EPI == EPI_GELU_GRAD ? SQ : 1][2];
-      if constexpr (EPI == EPI_GELU_GRAD) {                                // TOut == TE: 8 outputs per chunk, their 8 saved f32 pre-activations
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          const int row = q * ROWS_PER_INST + row0;
-          const int m = min(mrow0 + SLAB_ROWS * j + row, M - 1);
-          const f32x4* ip = reinterpret_cast<const f32x4*>(dln.aux32 + (size_t)m * N + nbase + (sl ^ (row & (CHUNKS - 1))) * OPC);
-          pre[q][0] = ip[0];
-          pre[q][1] = ip[1];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < SQ; ++q) {
-        const int row = q * ROWS_PER_INST + row0;
-        const int c = sl ^ (row & (CHUNKS - 1));
-        const int m = mrow0 + SLAB_ROWS * j + row;
-        f32x4 raw = *reinterpret_cast<const f32x4*>(slab + row * OUT_ROW + (sl << 4));
-        if (ABL == 1) { asm volatile("" ::"v"(raw)); continue; }
-        if constexpr (EPI == EPI_GELU_GRAD) {
-          e16x8 d = __builtin_bit_cast(e16x8, raw);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast(pre[q][e >> 2][e & 3]));
-          raw = __builtin_bit_cast(f32x4, d);
-        }
-        if constexpr (EPI == EPI_GELU_GRAD16) {
-          e16x8 d = __builtin_bit_cast(e16x8, raw);
-          const e16x8 pv = __builtin_bit_cast(e16x8, pre16v[q]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[e] = (TE)((float)d[e] * gelu_grad_fast((float)pv[e]));
-          raw = __builtin_bit_cast(f32x4, d);
-        }
-        if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) raw[e] += (float)res[q][e];
-        }
-        if (EPI == EPI_BIAS_RES_F32) {
-          if (dln.drop_thr != 0) {                                   // dropout on the GEMM output, then the residual (r = dropout(y) + x)
-            const uint64_t di = (uint64_t)(dln.drop_rowmap ? dln.drop_rowmap[min(m, M - 1)] : m) * N + (nbase + c * OPC);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) raw[e] = drop_bits(dln.drop_seed, dln.drop_site, di + e) >= dln.drop_thr ? raw[e] * dln.drop_scale : 0.f;
-          }
-          raw += resf[q];
-        }
-        if (m < M) {
-          f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Y) + ((size_t)m * N + nbase + c * OPC) * sizeof(TOut));
-          // the big streaming outputs (Q|K|V 302 MB, FFN intermediate 403 MB per launch) are written non-temporally so
-          // that they do not push the weight tiles, re-read by every row panel, out of the XCD's 4 MB L2
-          if (NORM && ABL != 5 && !dln.plain_stores) __builtin_nontemporal_store(raw, dst);
-          else *dst = raw;
-          if constexpr (EPI == EPI_BIAS_GELU_DUAL) {                       // TOut == float: 4 pre-activations -> 4 gelu values, 8-byte store
-            e16x4 gv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gv[e] = (TE)gelu_erf_fast(raw[e]);
-            *reinterpret_cast<e16x4*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
-          }
-          if constexpr (EPI == EPI_BIAS_GELU_DUAL16) {                     // TOut == TE: 8 rounded pre-activations -> their 8 gelu values
-            const e16x8 pv = __builtin_bit_cast(e16x8, raw);
-            e16x8 gv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = (TE)gelu_erf_fast((float)pv[e]);
-            *reinterpret_cast<e16x8*>(static_cast<TE*>(dln.aux16) + (size_t)m * N + nbase + c * OPC) = gv;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
+    {
+      int ew = wave;
+      asm volatile("" : "+s"(ew));
+      x16_epilogue<TE, TOut, EPI, ABL, MBT>(acc, lds + XB + xfree * G_OP_BYTES + ew * 4096, lds + last * G_OP_BYTES + ew * 4096, lane, ew, mt, nt, M, N,
+                                             bias, R, Y, dln);
     }
     if (!has_next) break;
     t = tn;
@@ -1474,6 +1486,139 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
     }
   }
   gemm_tn_x16_body<TE, TOut, EPI, ABL, 8>(lds, X, W, bias, R, Y, N, K, M, n_tiles, dln);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6 — the 4-wave form of the 16-bit production GEMM (the one work-removing design left).  Same 256 x 256
+// tile, same persistent tile walk, same LDS image, the SAME matrix instruction over K in the same order per output element and the
+// epilogues of the 8-wave kernel called unchanged (x16_epilogue, once per 64-column half of a wave's 128 x 128 block) — so the
+// outputs are the bits of gemm_tn_x16_kernel (tests/test_gpu_parity.py holds the two to torch.equal), and what changes is the work
+// per FLOP: four waves per CU (one per SIMD, 128 x 128 wave tiles, 256 accumulator registers in AGPRs) read 16 operand fragments
+// per 64 MFMAs instead of 12 per 32 (-33 % LDS fragment traffic), synchronise four waves instead of eight per K-step, and stage
+// operands through registers (global_load_dwordx4 -> ds_write_b128: with one wave per SIMD every LDS-DMA piece's 60-100 issue cycles
+// would come out of the matrix pipe's issue time).  Lab A/B of the main loops on one box (tools/gemm4w_lab.hip,
+// profiles/r6_final/lab4w_time.txt): Q|K|V 197 -> 160 us, out-projection 66 -> 54, FFN1 250 -> 212, FFN2 243 -> 228.
+// The K-loop of a tile is ONE inline-asm block with explicit registers (tools/gen_gemm_w4.py -> gemm_w4_asm.inc: hipcc cannot
+// allocate this kernel); its state across tiles lives in the operands below and in LDS:
+//   stage P = K-step 0 of the tile, stage Q = K-step 1 (both staged by the previous tile's last steps / by the prologue here);
+//   LDS: 2 stages x [W 32 KiB | X 32 KiB] at 0 and 64 KiB (the stage is bit 16 of an LDS address), epilogue slabs at 128 KiB.
+// Loads run two K-steps ahead of their use ACROSS tiles (the last two steps of a tile fetch the next tile's first two), so a tile
+// never opens with an exposed HBM round trip.  256-row panels only: the host launches this kernel where panel_rows() picks 256.
+template <typename TE, typename TOut, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
+    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles, DlnAux dln) {
+  typedef typename E16<TE>::v8 e16x8;
+  __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
+  constexpr int BK = 64;
+  const int M = *m_total;
+  const int G = gridDim.x, blk = blockIdx.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = blk & 7;
+  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
+  const int m_tiles = (M + G_BM - 1) / G_BM;
+  const int valid_tiles = m_tiles * n_tiles;
+  const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? dln.col_group : n_tiles;      // the 8-wave kernel's tile order
+  const int per_group = m_tiles * gsz;
+  auto decode = [&](int tile, int& mt_, int& nt_) {
+    const int g = tile / per_group;
+    const int r = tile - g * per_group;
+    const int width = min(gsz, n_tiles - g * gsz);
+    mt_ = r / width;
+    nt_ = g * gsz + (r - mt_ * width);
+  };
+  int t = slot;
+  if (t >= valid_tiles) return;
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wn = wave & 1, wm = wave >> 1;             // the wave's 128 x 128 block: columns 128 wn .., rows 128 wm ..
+  const int op = wave >> 1, hf = wave & 1;             // staging role: waves 0 / 1 the weight tile's row halves, 2 / 3 the activation tile's
+  const int l15 = lane & 15, lq = lane >> 4, lrow = lane >> 3, lc = lane & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(lds);
+  if (lds0 & 0x1ffffu) __builtin_trap();               // the stage bit is bit 16 of an absolute LDS address
+  // fragment read addresses (the production LDS image: 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
+  const uint32_t swz = (l15 >> 1) & 7;
+  uint32_t rw0 = lds0 + (128 * wn + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  uint32_t rw1 = lds0 + (128 * wn + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  uint32_t rx0 = lds0 + G_OP_BYTES + (128 * wm + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  uint32_t rx1 = lds0 + G_OP_BYTES + (128 * wm + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  // staging: piece p (8 rows x 128 B) of the wave's operand half goes to row 128 hf + 8 p + lrow, chunk lc ^ ((row >> 1) & 7)
+  const uint32_t wrow = lds0 + op * G_OP_BYTES + (128 * hf + lrow) * ROW_BYTES;
+  uint32_t wa0 = 0x10000u + wrow + ((lc ^ (((lrow >> 1)) & 7)) << 4);          // even pieces; -> stage Q (1)
+  uint32_t wa1 = 0x10000u + wrow + ((lc ^ ((4 + (lrow >> 1)) & 7)) << 4);      // odd pieces
+  const uint32_t rowb = (uint32_t)K * 2u;
+  const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
+  uint32_t g0 = lane_off + 0 * 8 * rowb, g1 = lane_off + 1 * 8 * rowb, g2 = lane_off + 2 * 8 * rowb, g3 = lane_off + 3 * 8 * rowb,
+           g4 = lane_off + 4 * 8 * rowb, g5 = lane_off + 5 * 8 * rowb, g6 = lane_off + 6 * 8 * rowb, g7 = lane_off + 7 * 8 * rowb,
+           g8 = lane_off + 8 * 8 * rowb, g9 = lane_off + 9 * 8 * rowb, g10 = lane_off + 10 * 8 * rowb, g11 = lane_off + 11 * 8 * rowb,
+           g12 = lane_off + 12 * 8 * rowb, g13 = lane_off + 13 * 8 * rowb, g14 = lane_off + 14 * 8 * rowb, g15 = lane_off + 15 * 8 * rowb;
+  // this wave's operand half of a tile, as a wave-uniform byte pointer
+  auto tile_base = [&](int tile) -> const char* {
+    int mt_, nt_;
+    decode(tile, mt_, nt_);
+    const TE* p_ = op == 0 ? W + (size_t)(nt_ * G_BN + 128 * hf) * K : X + (size_t)(mt_ * G_BM + 128 * hf) * K;
+    return reinterpret_cast<const char*>(p_);
+  };
+  // ---- prologue (once per workgroup): K-step 0 -> stage 0, K-step 1 -> stage 1
+  {
+    const char* cb = tile_base(t);
+    const uint32_t go[16] = {g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      e16x8 v[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + go[p] + kt * (BK * 2));
+#pragma unroll
+      for (int p = 0; p < 16; ++p)
+        *reinterpret_cast<e16x8*>(lds + (((p & 1) ? wa1 : wa0) - lds0 - (kt == 0 ? 0x10000u : 0u)) + p * 1024) = v[p];
+    }
+    g0 += 256; g1 += 256; g2 += 256; g3 += 256; g4 += 256; g5 += 256; g6 += 256; g7 += 256;
+    g8 += 256; g9 += 256; g10 += 256; g11 += 256; g12 += 256; g13 += 256; g14 += 256; g15 += 256;      // the load stream stands at K-step 2
+    __syncthreads();
+  }
+  const int nk = K / BK;
+  char* slab = lds + 4 * G_OP_BYTES + wave * 8192;     // two wave-private 4 KiB epilogue slabs in the 32 KiB behind the stages
+  while (true) {
+    int mt, nt;
+    decode(t, mt, nt);
+    const int tn = t + G;
+    const bool has_next = tn < valid_tiles;
+    const char* cbase = tile_base(t);
+    const char* nbase = tile_base(has_next ? tn : t);  // (no next tile: the last two steps re-read this one — legal, unused)
+    int cnt = nk - 3;
+#define MANNER_W4_RUN_TILE(MFMA_STR)                                                                                                       \
+  asm volatile(MANNER_W4_TILE_ASM(MFMA_STR)                                                                                                \
+               : [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5), [g6] "+v"(g6), [g7] "+v"(g7),   \
+                 [g8] "+v"(g8), [g9] "+v"(g9), [g10] "+v"(g10), [g11] "+v"(g11), [g12] "+v"(g12), [g13] "+v"(g13), [g14] "+v"(g14),        \
+                 [g15] "+v"(g15), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1),    \
+                 [cnt] "+s"(cnt)                                                                                                           \
+               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb)                                                                   \
+               : MANNER_W4_CLOBBERS)
+    if constexpr (E16<TE>::dtype == DT_BF16) {
+      MANNER_W4_RUN_TILE("v_mfma_f32_16x16x32_bf16");
+    } else {
+      MANNER_W4_RUN_TILE("v_mfma_f32_16x16x32_f16");
+    }
+#undef MANNER_W4_RUN_TILE
+    // the accumulators sit in a[0:255]; the 8-wave kernel's epilogue runs on each 64-column half with the virtual wave index
+    // 4 wm + (2 wn + half): column group (2 wn + half), row half wm — the same expressions, the same bits
+    {
+      f32x4 acc[4][8];
+      MANNER_W4_READ_HALF0(acc)
+      int ew = 4 * wm + 2 * wn;
+      asm volatile("" : "+s"(ew));
+      x16_epilogue<TE, TOut, EPI, 0, 8>(acc, slab, slab + 4096, lane, ew, mt, nt, M, N, bias, R, Y, dln);
+    }
+    {
+      f32x4 acc[4][8];
+      MANNER_W4_READ_HALF1(acc)
+      int ew = 4 * wm + 2 * wn + 1;
+      asm volatile("" : "+s"(ew));
+      x16_epilogue<TE, TOut, EPI, 0, 8>(acc, slab, slab + 4096, lane, ew, mt, nt, M, N, bias, R, Y, dln);
+    }
+    if (!has_next) break;
+    t = tn;
+  }
 }
 
 // Persistent grid of an x16 launch and the panel fields of its DlnAux: one workgroup per CU (160 KiB LDS each), fewer only when even
@@ -1592,11 +1737,29 @@ int pool_logits_mfma(const float* x, const float* W, const float* bias, const fl
 
 template <typename TE>
 static int launch_dln(Epilogue epi, const void* X, const void* W, const float* bias, void* Y, int N, int K, const int* m_total,
-                      int n_tiles, dim3 g, const DlnAux& aux, hipStream_t stream) {
+                      int n_tiles, dim3 g, const DlnAux& aux, hipStream_t stream, bool w4) {
   const dim3 b(512);
   const TE* x = static_cast<const TE*>(X);
   const TE* w = static_cast<const TE*>(W);
   TE* y = static_cast<TE*>(Y);
+  if (w4) {                                            // round 6: the 4-wave kernel (same bits; 256-row panels)
+    const dim3 b4(256);
+    switch (epi) {
+      case EPI_NORM:
+        hipLaunchKernelGGL((gemm_tn_w4_kernel<TE, TE, EPI_NORM>), g, b4, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+        break;
+      case EPI_NORM_GELU:
+        hipLaunchKernelGGL((gemm_tn_w4_kernel<TE, TE, EPI_NORM_GELU>), g, b4, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+        break;
+      case EPI_NRES:
+        hipLaunchKernelGGL((gemm_tn_w4_kernel<TE, TE, EPI_NRES>), g, b4, 0, stream, x, w, bias, y, y, N, K, m_total, n_tiles, aux);
+        break;
+      default:
+        return fail(MANNER_HIP_E_INVALID, "gemm_dln: epilogue %d", (int)epi);
+    }
+    MANNER_LAUNCH_CHECK();
+    return MANNER_HIP_OK;
+  }
   switch (epi) {
     case EPI_NORM:
       hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TE, EPI_NORM>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
@@ -1657,9 +1820,17 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
     split = split_panels(mp, n_tiles, (int)cus) < mp;
   }
   if (split) { aux.split_cus = (int)cus; aux.panel_mode = 1; }     // the round-aware split cuts at 256-row panels
+  // Round 6: the 4-wave kernel (gemm_tn_w4_kernel: the same bits from 17 % less main-loop time) where the panel height is 256 rows by
+  // what the host knows of the token count (m_exact, else its bound) — 192-row launches and the A/B forms stay on the 8-wave kernel.
+  // MANNER_HIP_GEMM_W4=0: the 8-wave kernel everywhere (A/B; read per launch: the equality test flips it).
+  const char* w4_env = getenv("MANNER_HIP_GEMM_W4");
+  const int64_t m_est = m_exact >= 0 ? m_exact : m_bound;
+  const bool w4 = !(w4_env && atoi(w4_env) == 0) && !split && stagger == 0 && K % 64 == 0 && K >= 192 && aux.panel_mode != 2 &&
+                  panel_rows((int)m_est, n_tiles, (int)cus, aux.panel_mode) == 256;
+  if (w4) g = dim3((unsigned)(tiles < cus ? tiles : cus));
   int rc;
-  if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
-  else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream);
+  if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, w4);
+  else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, w4);
   if (rc || !split) return rc;
   const Drop none{0, 0, 0, 1.f};
   const SmallAux sa{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, (int)cus};

@@ -1412,3 +1412,43 @@ def test_f16x3_attention_with_four_key_tiles_matches_the_oracle(preset, monkeypa
     e_new, e_old, d = np.abs(got[None] - ref).max(), np.abs(got["0"] - ref).max(), np.abs(got[None] - got["0"]).max()
     print(f"{preset}: lengths up to {max_len}: x3 attention vs oracle {e_new:.3e}, f32-MFMA attention {e_old:.3e}, A/B {d:.3e}")
     assert e_new < FP32_TOL and e_old < FP32_TOL and d < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("n_news,with_lengths", [(200, True), (131, False), (700, True), (1100, True)])
+def test_the_four_wave_gemm_gives_the_bits_of_the_eight_wave_gemm(precision, n_news, with_lengths, monkeypatch):
+    """Round 6: `gemm_tn_w4_kernel` — four waves per CU, 128 x 128 wave tiles with the accumulators in AGPRs, the K-loop of a tile as one
+    hand-scheduled asm block (tools/gen_gemm_w4.py) — issues, per output element, the same matrix instruction over K in the same order
+    as `gemm_tn_x16_kernel` and calls its epilogues unchanged, so a deferred-LayerNorm GEMM gives the same BITS from either
+    (MANNER_HIP_GEMM_W4=0 pins the 8-wave kernel).  Held here on [CLS] embeddings and layer-2 hidden states of a 3-layer bert-base:
+    one tile per workgroup (200 / 131 news), two to eight tiles per workgroup — the cross-tile operand pipeline — (700 / 1100 news),
+    with 256-row panels pinned so that the 4-wave kernel takes every launch, and with the panel choice left to the library."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS["bert-base-uncased"], layers=3)
+    w = make_plm_weights(cfg, seed=96, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=96, max_len=96, profile="title_abstract")
+    lens = mask_np.sum(1) if with_lengths else None
+    tokens = int(mask_np.sum())
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")          # the persistent kernels for every shape of this test
+    got = {}
+    for panel in ("256", None):
+        if panel is None:
+            monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_GEMM_PANEL", panel)
+        for w4 in ("0", "1"):
+            monkeypatch.setenv("MANNER_HIP_GEMM_W4", w4)
+            got[(panel, w4)] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
+                                enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens).clone())
+    enc.status()
+    monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+    monkeypatch.delenv("MANNER_HIP_GEMM_W4", raising=False)
+    cls, hid = got[("256", "0")]
+    assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1, tokens
+    for key, (c, h) in got.items():
+        assert torch.equal(c, cls), (key, tokens, float((c - cls).abs().max()))
+        assert torch.equal(h, hid), (key, tokens)
+    enc.close()
