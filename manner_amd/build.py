@@ -27,7 +27,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(PKG, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train_common.h"), os.path.join(CSRC, "gemm_w4_asm.inc"), os.path.join(ROOT, "include", "manner_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train_common.h"), os.path.join(CSRC, "gemm_w4_asm.inc"), os.path.join(CSRC, "gemm_w8_asm.inc"), os.path.join(ROOT, "include", "manner_hip.h")]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")

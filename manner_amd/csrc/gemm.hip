@@ -25,6 +25,7 @@
 
 #include "train_common.h"
 #include "gemm_w4_asm.inc"
+#include "gemm_w8_asm.inc"
 
 namespace manner {
 namespace {
@@ -901,8 +902,8 @@ __host__ __device__ inline int panel_rows(int M, int n_tiles, int cus, int mode)
 // The epilogue of one wave's 128(m) x 64(n) accumulator block acc[a][bb] (a = 16-column block 0..3, bb = 16-row block) of the tile
 // (mt, nt): shared by the 8-wave kernel (ew = its wave: column group ew & 3, row half ew >> 2) and by the 4-wave kernel (round 6), whose
 // waves own 128 x 128 and call it once per 64-column half with the virtual wave index 4 wm + 2 wn + half — the same expressions in the
-// same order, hence the same bits.  slab / rslab1: two wave-private 4 KiB LDS slabs (rslab1: EPI_NRES only).
-template <typename TE, typename TOut, int EPI, int ABL, int MBT>
+// same order, hence the same bits.  slab / rslab1: two wave-private 4 KiB LDS slabs (rslab1: EPI_NRES only; ONE_SLAB: it has one).
+template <typename TE, typename TOut, int EPI, int ABL, int MBT, bool ONE_SLAB = false>
 __device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, char* rslab1, int lane, int ew, int mt, int nt, int M, int N,
                                              const float* __restrict__ bias, const TE* __restrict__ R, TOut* __restrict__ Y, const DlnAux& dln) {
   typedef typename E16<TE>::v8 e16x8;
@@ -956,26 +957,48 @@ __device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, c
           }
 #pragma unroll
         for (int b4 = 0; b4 < nb4; ++b4) ms[b4] = dln.mr[min(mrow0 + 16 * (4 * hb + b4) + l15, M - 1)];
-#pragma unroll
-        for (int sb = 0; sb < nsb; ++sb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 8 * q + rrow0;
-            *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
-          }
-        __builtin_amdgcn_wave_barrier();
         e16x4 res[4][4];
+        if constexpr (!ONE_SLAB) {                     // two slabs: both 32-row sub-blocks go through LDS at once
 #pragma unroll
-        for (int b4 = 0; b4 < nb4; ++b4) {
-          const int row = 16 * (b4 & 1) + l15;
-          const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
+          for (int sb = 0; sb < nsb; ++sb)
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int c = (16 * a + 4 * lq) / 8;
-            res[b4][a] = *reinterpret_cast<const e16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+            for (int q = 0; q < 4; ++q) {
+              const int row = 8 * q + rrow0;
+              *reinterpret_cast<f32x4*>((sb ? rslab1 : rslab0) + row * 128 + (rsl << 4)) = rawres[sb][q];
+            }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int b4 = 0; b4 < nb4; ++b4) {
+            const int row = 16 * (b4 & 1) + l15;
+            const char* rs_ = (b4 >> 1) ? rslab1 : rslab0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const int c = (16 * a + 4 * lq) / 8;
+              res[b4][a] = *reinterpret_cast<const e16x4*>(rs_ + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {                                       // one slab (the 8-wave register-staged kernel has 4 KiB per wave to spare): the
+#pragma unroll                                         // sub-blocks take turns — a wave's LDS operations execute in program order
+          for (int sb = 0; sb < nsb; ++sb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = 8 * q + rrow0;
+              *reinterpret_cast<f32x4*>(rslab0 + row * 128 + (rsl << 4)) = rawres[sb][q];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+              const int row = 16 * b2 + l15;
+#pragma unroll
+              for (int a = 0; a < 4; ++a) {
+                const int c = (16 * a + 4 * lq) / 8;
+                res[2 * sb + b2][a] = *reinterpret_cast<const e16x4*>(rslab0 + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (lq & 1));
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
           }
         }
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int b4 = 0; b4 < nb4; ++b4) {
           const int bb = 4 * hb + b4;
@@ -1489,6 +1512,141 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x16_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6 — the production 16-bit GEMM with a HAND-SCHEDULED K-loop (gemm_tn_w8_kernel).  Geometry, tile walk, LDS image, the matrix
+// instruction and its order over K per output element and the epilogues (x16_epilogue, called unchanged) are those of
+// gemm_tn_x16_kernel, so the outputs are its bits (tests/test_gpu_parity.py holds the two to torch.equal).  What changes is the
+// pipeline: operands are staged through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA — the lab had priced
+// the DMA's issue cost at a fifth of the main loop —, requested two K-steps ahead ACROSS tiles, with every s_waitcnt counted, one
+// barrier per K-step and the fragment reads placed one per matrix-instruction gap; the K-loop of a tile is one inline-asm block
+// with explicit registers (tools/gen_gemm_w.py -> gemm_w8_asm.inc), because the compiler's schedule of the same loop is what it
+// replaces.  Same-box lab A/B of the main loops (tools/gemm4w_lab.hip, profiles/r6_final/lab_w4_w8_time.txt): Q|K|V 195 -> 152 us,
+// out-projection 67 -> 52.5, FFN1 243 -> 201, FFN2 240 -> 216.  (The 4-wave / 128 x 128-wave-tile form below has the same main
+// loop speed and loses it in the epilogue: one wave per SIMD issues vector instructions at half the rate of two.)
+// State across tiles: the "+v" operands (piece offsets, LDS addresses) and LDS — stage P = K-step 0 of the tile, stage Q = K-step 1
+// (staged by the previous tile's last steps / by the prologue here); 2 stages x [W 32 KiB | X 32 KiB] at 0 and 64 KiB (the stage is
+// bit 16 of an LDS address), one 4 KiB epilogue slab per wave at 128 KiB.  256-row panels only (the host launches this kernel where
+// panel_rows() picks 256; 192-row launches keep the LDS-DMA kernel).
+template <typename TE, typename TOut, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
+    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles, DlnAux dln) {
+  typedef typename E16<TE>::v8 e16x8;
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(1024))) char lds[5 * G_OP_BYTES];       // 160 KiB
+  constexpr int BK = 64;
+  if constexpr (EPI == EPI_BIAS) {
+    X += (size_t)blockIdx.y * dln.batch_x;
+    W += (size_t)blockIdx.y * dln.batch_w;
+    Y += (size_t)blockIdx.y * dln.batch_y;
+  }
+  const int M = *m_total;
+  const int G = gridDim.x, blk = blockIdx.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = blk & 7;
+  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
+  const int m_tiles = (M + G_BM - 1) / G_BM;
+  const int valid_tiles = m_tiles * n_tiles;
+  const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? dln.col_group : n_tiles;      // the tile order of gemm_tn_x16_kernel
+  const int per_group = m_tiles * gsz;
+  auto decode = [&](int tile, int& mt_, int& nt_) {
+    const int g = tile / per_group;
+    const int r = tile - g * per_group;
+    const int width = min(gsz, n_tiles - g * gsz);
+    mt_ = r / width;
+    nt_ = g * gsz + (r - mt_ * width);
+  };
+  int t = slot;
+  if (t >= valid_tiles) return;
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wn = wave & 3, wm = wave >> 2;             // the wave's 128 x 64 block: columns 64 wn .., rows 128 wm ..
+  const int op = wave >> 2, qf = wave & 3;             // staging role: waves 0..3 the weight tile's 64-row quarters, 4..7 the activation tile's
+  const int l15 = lane & 15, lq = lane >> 4, lrow = lane >> 3, lc = lane & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(lds);
+  if (lds0 & 0x1ffffu) __builtin_trap();               // the stage bit is bit 16 of an absolute LDS address
+  // fragment read addresses (the production LDS image: 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
+  const uint32_t swz = (l15 >> 1) & 7;
+  uint32_t rw0 = lds0 + (64 * wn + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  uint32_t rw1 = lds0 + (64 * wn + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  uint32_t rx0 = lds0 + G_OP_BYTES + (128 * wm + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  uint32_t rx1 = lds0 + G_OP_BYTES + (128 * wm + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  // staging: piece p (8 rows x 128 B) of the wave's operand quarter goes to row 64 qf + 8 p + lrow, chunk lc ^ ((row >> 1) & 7)
+  const uint32_t wrow = lds0 + op * G_OP_BYTES + (64 * qf + lrow) * ROW_BYTES;
+  uint32_t wa0 = 0x10000u + wrow + ((lc ^ (((lrow >> 1)) & 7)) << 4);          // even pieces; -> stage Q (1)
+  uint32_t wa1 = 0x10000u + wrow + ((lc ^ ((4 + (lrow >> 1)) & 7)) << 4);      // odd pieces
+  // the same image by LDS-DMA (linear 1 KiB per piece): the lane that fills slot lc of its row fetches chunk lc ^ ((row >> 1) & 7)
+  const uint32_t d0 = (uint32_t)(((lc ^ ((lrow >> 1) & 7)) - lc) * 16), d1 = (uint32_t)(((lc ^ ((4 + (lrow >> 1)) & 7)) - lc) * 16);
+  const uint32_t rowb = (uint32_t)K * 2u;
+  const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
+  uint32_t g0 = lane_off + 0 * 8 * rowb, g1 = lane_off + 1 * 8 * rowb, g2 = lane_off + 2 * 8 * rowb, g3 = lane_off + 3 * 8 * rowb,
+           g4 = lane_off + 4 * 8 * rowb, g5 = lane_off + 5 * 8 * rowb, g6 = lane_off + 6 * 8 * rowb, g7 = lane_off + 7 * 8 * rowb;
+  // this wave's operand quarter of a tile, as a wave-uniform byte pointer
+  auto tile_base = [&](int tile) -> const char* {
+    int mt_, nt_;
+    decode(tile, mt_, nt_);
+    const TE* p_ = op == 0 ? W + (size_t)(nt_ * G_BN + 64 * qf) * K : X + (size_t)(mt_ * G_BM + 64 * qf) * K;
+    return reinterpret_cast<const char*>(p_);
+  };
+  // ---- prologue (once per workgroup): K-step 0 -> stage 0, K-step 1 -> stage 1
+  {
+    const char* cb = tile_base(t);
+    const uint32_t go[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      e16x8 v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + go[p] + kt * (BK * 2));
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        *reinterpret_cast<e16x8*>(lds + (((p & 1) ? wa1 : wa0) - lds0 - (kt == 0 ? 0x10000u : 0u)) + p * 1024) = v[p];
+    }
+    g0 += 256; g1 += 256; g2 += 256; g3 += 256; g4 += 256; g5 += 256; g6 += 256; g7 += 256;      // the load stream stands at K-step 2
+    __syncthreads();
+  }
+  const int nk = K / BK;
+  char* slab = lds + 4 * G_OP_BYTES + wave * 4096;     // one wave-private 4 KiB epilogue slab in the 32 KiB behind the stages
+  while (true) {
+    int mt, nt;
+    decode(t, mt, nt);
+    const int tn = t + G;
+    const bool has_next = tn < valid_tiles;
+    const char* cbase = tile_base(t);
+    const char* nbase = tile_base(has_next ? tn : t);  // (no next tile: the last two steps re-read this one — legal, unused)
+    int cnt = nk - 3;
+    f32x16 o[8];
+#define MANNER_W8_RUN_TILE(MFMA_STR)                                                                                                       \
+  asm volatile(MANNER_W8_TILE_ASM(MFMA_STR)                                                                                                \
+               : MANNER_W8_ACC_OUTPUTS(o), [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5),       \
+                 [g6] "+v"(g6), [g7] "+v"(g7), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0),        \
+                 [rx1] "+v"(rx1), [cnt] "+s"(cnt)                                                                                          \
+               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1)                                       \
+               : MANNER_W8_CLOBBERS)
+    if constexpr (E16<TE>::dtype == DT_BF16) {
+      MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_bf16");
+    } else {
+      MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_f16");
+    }
+#undef MANNER_W8_RUN_TILE
+    {
+      f32x4 acc[4][8];                                 // acc[a][b] = v[4 (8 a + b) ..] = o[2 a + (b >> 2)][4 (b & 3) ..]
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const f32x16& s16 = o[2 * a + (b >> 2)];
+          const int k4 = 4 * (b & 3);
+          acc[a][b] = f32x4{s16[k4], s16[k4 + 1], s16[k4 + 2], s16[k4 + 3]};
+        }
+      int ew = wave;
+      asm volatile("" : "+s"(ew));
+      x16_epilogue<TE, TOut, EPI, ABL, 8, true>(acc, slab, slab, lane, ew, mt, nt, M, N, bias, R, Y, dln);
+    }
+    if (!has_next) break;
+    t = tn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Round 6 — the 4-wave form of the 16-bit production GEMM (the one work-removing design left).  Same 256 x 256
 // tile, same persistent tile walk, same LDS image, the SAME matrix instruction over K in the same order per output element and the
 // epilogues of the 8-wave kernel called unchanged (x16_epilogue, once per 64-column half of a wave's 128 x 128 block) — so the
@@ -1546,6 +1704,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
   const uint32_t wrow = lds0 + op * G_OP_BYTES + (128 * hf + lrow) * ROW_BYTES;
   uint32_t wa0 = 0x10000u + wrow + ((lc ^ (((lrow >> 1)) & 7)) << 4);          // even pieces; -> stage Q (1)
   uint32_t wa1 = 0x10000u + wrow + ((lc ^ ((4 + (lrow >> 1)) & 7)) << 4);      // odd pieces
+  // the same image by LDS-DMA (linear 1 KiB per piece): the lane that fills slot lc of its row fetches chunk lc ^ ((row >> 1) & 7)
+  const uint32_t d0 = (uint32_t)(((lc ^ ((lrow >> 1) & 7)) - lc) * 16), d1 = (uint32_t)(((lc ^ ((4 + (lrow >> 1)) & 7)) - lc) * 16);
   const uint32_t rowb = (uint32_t)K * 2u;
   const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
   uint32_t g0 = lane_off + 0 * 8 * rowb, g1 = lane_off + 1 * 8 * rowb, g2 = lane_off + 2 * 8 * rowb, g3 = lane_off + 3 * 8 * rowb,
@@ -1592,7 +1752,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
                  [g8] "+v"(g8), [g9] "+v"(g9), [g10] "+v"(g10), [g11] "+v"(g11), [g12] "+v"(g12), [g13] "+v"(g13), [g14] "+v"(g14),        \
                  [g15] "+v"(g15), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1),    \
                  [cnt] "+s"(cnt)                                                                                                           \
-               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb)                                                                   \
+               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1)                                       \
                : MANNER_W4_CLOBBERS)
     if constexpr (E16<TE>::dtype == DT_BF16) {
       MANNER_W4_RUN_TILE("v_mfma_f32_16x16x32_bf16");
@@ -1737,12 +1897,29 @@ int pool_logits_mfma(const float* x, const float* W, const float* bias, const fl
 
 template <typename TE>
 static int launch_dln(Epilogue epi, const void* X, const void* W, const float* bias, void* Y, int N, int K, const int* m_total,
-                      int n_tiles, dim3 g, const DlnAux& aux, hipStream_t stream, bool w4) {
+                      int n_tiles, dim3 g, const DlnAux& aux, hipStream_t stream, int asm_mode) {
   const dim3 b(512);
   const TE* x = static_cast<const TE*>(X);
   const TE* w = static_cast<const TE*>(W);
   TE* y = static_cast<TE*>(Y);
-  if (w4) {                                            // round 6: the 4-wave kernel (same bits; 256-row panels)
+  if (asm_mode == 8) {                                 // round 6: the hand-scheduled 8-wave kernel (same bits; 256-row panels)
+    switch (epi) {
+      case EPI_NORM:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TE, EPI_NORM>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+        break;
+      case EPI_NORM_GELU:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TE, EPI_NORM_GELU>), g, b, 0, stream, x, w, bias, nullptr, y, N, K, m_total, n_tiles, aux);
+        break;
+      case EPI_NRES:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TE, EPI_NRES>), g, b, 0, stream, x, w, bias, y, y, N, K, m_total, n_tiles, aux);
+        break;
+      default:
+        return fail(MANNER_HIP_E_INVALID, "gemm_dln: epilogue %d", (int)epi);
+    }
+    MANNER_LAUNCH_CHECK();
+    return MANNER_HIP_OK;
+  }
+  if (asm_mode == 4) {                                 // the 4-wave form (A/B only: same bits, slower behind the epilogues)
     const dim3 b4(256);
     switch (epi) {
       case EPI_NORM:
@@ -1820,17 +1997,20 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
     split = split_panels(mp, n_tiles, (int)cus) < mp;
   }
   if (split) { aux.split_cus = (int)cus; aux.panel_mode = 1; }     // the round-aware split cuts at 256-row panels
-  // Round 6: the 4-wave kernel (gemm_tn_w4_kernel: the same bits from 17 % less main-loop time) where the panel height is 256 rows by
-  // what the host knows of the token count (m_exact, else its bound) — 192-row launches and the A/B forms stay on the 8-wave kernel.
-  // MANNER_HIP_GEMM_W4=0: the 8-wave kernel everywhere (A/B; read per launch: the equality test flips it).
-  const char* w4_env = getenv("MANNER_HIP_GEMM_W4");
+  // Round 6: the hand-scheduled kernels (gemm_tn_w8_kernel: the same bits from a 17-22 % shorter main loop) where the panel height is
+  // 256 rows by what the host knows of the token count (m_exact, else its bound) — 192-row launches and the A/B forms stay on the
+  // compiler-scheduled LDS-DMA kernel.  MANNER_HIP_GEMM_ASM = 8 (default) | 4 (the 4-wave form) | 0 (gemm_tn_x16_kernel everywhere);
+  // read per launch: the equality test flips it.
+  const char* asm_env = getenv("MANNER_HIP_GEMM_ASM");
+  const int asm_req = asm_env ? atoi(asm_env) : 8;
   const int64_t m_est = m_exact >= 0 ? m_exact : m_bound;
-  const bool w4 = !(w4_env && atoi(w4_env) == 0) && !split && stagger == 0 && K % 64 == 0 && K >= 192 && aux.panel_mode != 2 &&
-                  panel_rows((int)m_est, n_tiles, (int)cus, aux.panel_mode) == 256;
-  if (w4) g = dim3((unsigned)(tiles < cus ? tiles : cus));
+  const bool asm_ok = (asm_req == 8 || asm_req == 4) && !split && stagger == 0 && K % 64 == 0 && K >= 192 && aux.panel_mode != 2 &&
+                      panel_rows((int)m_est, n_tiles, (int)cus, aux.panel_mode) == 256;
+  const int asm_mode = asm_ok ? asm_req : 0;
+  if (asm_mode) g = dim3((unsigned)(tiles < cus ? tiles : cus));
   int rc;
-  if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, w4);
-  else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, w4);
+  if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, asm_mode);
+  else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, asm_mode);
   if (rc || !split) return rc;
   const Drop none{0, 0, 0, 1.f};
   const SmallAux sa{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, (int)cus};

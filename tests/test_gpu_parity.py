@@ -1417,13 +1417,14 @@ def test_f16x3_attention_with_four_key_tiles_matches_the_oracle(preset, monkeypa
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
 @pytest.mark.parametrize("n_news,with_lengths", [(200, True), (131, False), (700, True), (1100, True)])
-def test_the_four_wave_gemm_gives_the_bits_of_the_eight_wave_gemm(precision, n_news, with_lengths, monkeypatch):
-    """Round 6: `gemm_tn_w4_kernel` — four waves per CU, 128 x 128 wave tiles with the accumulators in AGPRs, the K-loop of a tile as one
-    hand-scheduled asm block (tools/gen_gemm_w4.py) — issues, per output element, the same matrix instruction over K in the same order
-    as `gemm_tn_x16_kernel` and calls its epilogues unchanged, so a deferred-LayerNorm GEMM gives the same BITS from either
-    (MANNER_HIP_GEMM_W4=0 pins the 8-wave kernel).  Held here on [CLS] embeddings and layer-2 hidden states of a 3-layer bert-base:
-    one tile per workgroup (200 / 131 news), two to eight tiles per workgroup — the cross-tile operand pipeline — (700 / 1100 news),
-    with 256-row panels pinned so that the 4-wave kernel takes every launch, and with the panel choice left to the library."""
+def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(precision, n_news, with_lengths, monkeypatch):
+    """Round 6: `gemm_tn_w8_kernel` (the production geometry with a hand-scheduled, register-staged K-loop: one asm block per tile,
+    tools/gen_gemm_w.py) and `gemm_tn_w4_kernel` (four waves per CU, 128 x 128 wave tiles in AGPRs) issue, per output element, the same
+    matrix instruction over K in the same order as `gemm_tn_x16_kernel` and call its epilogues unchanged, so a deferred-LayerNorm GEMM
+    gives the same BITS from all three (MANNER_HIP_GEMM_ASM = 0 | 8 | 4).  Held here on [CLS] embeddings and layer-2 hidden states of
+    a 3-layer bert-base: one tile per workgroup (200 / 131 news), two to eight tiles per workgroup — the cross-tile operand pipeline —
+    (700 / 1100 news), with 256-row panels pinned so that the asm kernels take every launch, and with the panel choice left to the
+    library."""
     import dataclasses
     cfg = dataclasses.replace(PRESETS["bert-base-uncased"], layers=3)
     w = make_plm_weights(cfg, seed=96, std=0.03)
@@ -1439,13 +1440,13 @@ def test_the_four_wave_gemm_gives_the_bits_of_the_eight_wave_gemm(precision, n_n
             monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
         else:
             monkeypatch.setenv("MANNER_HIP_GEMM_PANEL", panel)
-        for w4 in ("0", "1"):
-            monkeypatch.setenv("MANNER_HIP_GEMM_W4", w4)
-            got[(panel, w4)] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
-                                enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens).clone())
+        for mode in ("0", "8", "4"):
+            monkeypatch.setenv("MANNER_HIP_GEMM_ASM", mode)
+            got[(panel, mode)] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
+                                  enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens).clone())
     enc.status()
     monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
-    monkeypatch.delenv("MANNER_HIP_GEMM_W4", raising=False)
+    monkeypatch.delenv("MANNER_HIP_GEMM_ASM", raising=False)
     cls, hid = got[("256", "0")]
     assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1, tokens
     for key, (c, h) in got.items():

@@ -271,10 +271,11 @@ struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   int* table = nullptr;
-  int stride = 0, grid = 0;
-  bool load(const char* path) {
+  int stride = 0, grid = 0, threads = 256;
+  bool load(const char* path, const char* name, int nthreads) {
+    threads = nthreads;
     if (hipModuleLoad(&mod, path) != hipSuccess) { fprintf(stderr, "cannot load %s (build it: see tools/gen_gemm4w_asm.py)\n", path); return false; }
-    CK(hipModuleGetFunction(&fn, mod, "gemm4w_asm"));
+    CK(hipModuleGetFunction(&fn, mod, name));
     return true;
   }
   // the production walk: persistent grid of G workgroups, XCD-remapped slot, tile = slot + r G, row-panel-major (mt = tile / n_tiles)
@@ -301,7 +302,7 @@ struct AsmKernel {
     struct { const void* x; const void* w; void* y; const void* t; int k, n, stride, store; } args{X, W, Y, table, K, N, stride, store};
     size_t sz = sizeof(args);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    CK(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, nullptr, cfg));
+    CK(hipModuleLaunchKernel(fn, grid, 1, 1, threads, 1, 1, 0, 0, nullptr, cfg));
   }
 };
 
@@ -325,23 +326,26 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(W, hw.data(), we * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 3072 * 4));
   CK(hipMemcpy(mtot, &M, 4, hipMemcpyHostToDevice));
-  AsmKernel ak;
+  AsmKernel ak, ak8;
   const char* co = getenv("GEMM4W_CO") ? getenv("GEMM4W_CO") : "tools/bin/gemm4w.co";
-  const bool have_asm = ak.load(co);
+  const bool have_asm = ak.load(co, "gemm4w_asm", 256);
+  const bool have_asm8 = ak8.load(getenv("GEMM8W_CO") ? getenv("GEMM8W_CO") : "tools/bin/gemm8w.co", "gemm8w_asm", 512);
 
   if (argc > 2 && !strcmp(argv[2], "debug") && have_asm) {   // register dump of the epilogue's address path (see the generator): first tile of every workgroup
     const Shape& s = shapes[0];
-    ak.plan(M, s.N / 256);
-    CK(hipMemset(Y, 0, 256 * 256 * 64));
-    ak.launch(X, W, Y, s.K, s.N, (int)(0x80000000u | (unsigned)M));
+    AsmKernel& dk = (argc > 3 && !strcmp(argv[3], "asm8") && have_asm8) ? ak8 : ak;
+    dk.plan(M, s.N / 256);
+    CK(hipMemset(Y, 0, 256 * 512 * 64));
+    dk.launch(X, W, Y, s.K, s.N, (int)(0x80000000u | (unsigned)M));
     CK(hipDeviceSynchronize());
-    std::vector<uint32_t> d(256 * 256 * 16);
+    std::vector<uint32_t> d(256 * 512 * 16);
     CK(hipMemcpy(d.data(), Y, d.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long y = (unsigned long long)Y;
     printf("Y = 0x%llx  N = %d\n", y, s.N);
     for (int wg : {0, 1, 9, 143})
-      for (int t : {0, 1, 63, 64, 128, 192, 255}) {
-        const uint32_t* r = &d[((size_t)wg * 256 + t) * 16];
+      for (int t : {0, 1, 63, 64, 128, 192, 255, 256, 320, 511}) {
+        if (t >= dk.threads) continue;
+        const uint32_t* r = &d[((size_t)wg * 512 + t) * 16];
         printf("wg %3d tid %3d: v176 %10u  s40:41 (Y + %lld)  N %u | at start: s26 %u s27 %u s28 %u v0 0x%x | at end: s26 %u s27 %u s28 %u mt %d\n", wg, t, r[0],
                (long long)(((unsigned long long)r[2] << 32 | r[1]) - y), r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], (int)r[11]);
       }
@@ -351,6 +355,7 @@ int main(int argc, char** argv) {
     int bad = 0;
     std::vector<int> vars;
     if (have_asm) vars.push_back(2);
+    if (have_asm8) vars.push_back(3);
     if (hipcc_vars) { vars.push_back(0); vars.push_back(1); }
     for (const auto& s : shapes)
       for (int var : vars) {
@@ -359,7 +364,8 @@ int main(int argc, char** argv) {
         CK(hipMemset(Y, 0xff, (size_t)M * s.N * 4));
         if (var == 0) hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
         else if (var == 1) hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, true>), g, b, 0, 0, X, W, Y, s.N, s.K, M, n_tiles);
-        else { ak.plan(M, n_tiles); ak.launch(X, W, Y, s.K, s.N, M); }     // store = rows of Y: the epilogue's address guard
+        else if (var == 2) { ak.plan(M, n_tiles); ak.launch(X, W, Y, s.K, s.N, M); }     // store = rows of Y: the epilogue's address guard
+        else { ak8.plan(M, n_tiles); ak8.launch(X, W, Y, s.K, s.N, M); }
         CK(hipDeviceSynchronize());
         std::vector<float> hy((size_t)M * s.N);
         CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
@@ -379,7 +385,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < hy.size(); i += 97) { uint32_t u; memcpy(&u, &hy[i], 4); if (u == 0xffffffffu) ++unwritten; }
         const bool ok = worst < 2e-3 && !nan && !unwritten;
         printf("check %-4s %s: worst rel err %.3e over 20000 sampled outputs, NaN %zu, unwritten (sampled) %zu  %s\n", s.name,
-               var == 2 ? "asm 4-wave" : var == 0 ? "hipcc VAR 0" : "hipcc VAR 1", worst, nan, unwritten, ok ? "ok" : "WRONG");
+               var == 2 ? "asm 4-wave" : var == 3 ? "asm 8-wave" : var == 0 ? "hipcc VAR 0" : "hipcc VAR 1", worst, nan, unwritten, ok ? "ok" : "WRONG");
         if (!ok) bad = 1;
       }
     return bad;
@@ -395,19 +401,32 @@ int main(int argc, char** argv) {
       dim3 g(tiles < 256 ? tiles : 256);
       DlnAux aux{};
       aux.panel_mode = 1; aux.x_rows = M;
-      double tp = 0, ta = 0, t0 = 0, t1 = 0;
+      double tp = 0, ta = 0, ta8 = 0, t0 = 0, t1 = 0;
       if (want("prod"))
         tp = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 1>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
       if (have_asm && want("asm")) {
         ak.plan(M, n_tiles);
         ta = time_us([&] { ak.launch(X, W, Y, s.K, s.N, 0); }, iters);
       }
+      if (have_asm8 && want("asm8")) {
+        ak8.plan(M, n_tiles);
+        ta8 = time_us([&] { ak8.launch(X, W, Y, s.K, s.N, 0); }, iters);
+      }
+      double tw8 = 0, tw8f = 0, tpf = 0;
+      if (want("w8abl"))
+        tw8 = time_us([&] { hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_BIAS, 1>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
+      if (want("w8full"))
+        tw8f = time_us([&] { hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_BIAS, 0>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
+      if (want("prodfull"))
+        tpf = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 0, false>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
       if (hipcc_vars && want("v0"))
         t0 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
       if (hipcc_vars && want("v1"))
         t1 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 1, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
       printf("rep %d %-4s N=%4d K=%4d  production %7.1f us %6.0f TF | 4-wave asm %7.1f us %6.0f TF (%+5.1f %%)", rep, s.name, s.N, s.K, tp,
              tp ? fl / tp / 1e6 : 0, ta, ta ? fl / ta / 1e6 : 0, tp && ta ? 100 * (ta / tp - 1) : 0);
+      printf(" | 8-wave asm %7.1f us %6.0f TF (%+5.1f %%)", ta8, ta8 ? fl / ta8 / 1e6 : 0, tp && ta8 ? 100 * (ta8 / tp - 1) : 0);
+      printf(" | integrated W8: K-loops only %7.1f us, with the bias epilogue %7.1f us; production with the bias epilogue %7.1f us", tw8, tw8f, tpf);
       if (hipcc_vars) printf(" | hipcc VAR 0 %7.1f us (%+5.1f %%) | hipcc VAR 1 %7.1f us (%+5.1f %%)", t0, tp && t0 ? 100 * (t0 / tp - 1) : 0, t1, tp && t1 ? 100 * (t1 / tp - 1) : 0);
       printf("\n");
     }
