@@ -1610,8 +1610,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     decode(t, mt, nt);
     const int tn = t + G;
     const bool has_next = tn < valid_tiles;
-    const char* cbase = tile_base(t);
-    const char* nbase = tile_base(has_next ? tn : t);  // (no next tile: the last two steps re-read this one — legal, unused)
+    // (readfirstlane: the asm block takes them as SGPR pairs — "s" — and the compiler must not doubt that they are wave-uniform)
+    auto uniform = [](const char* p_) -> const char* {
+      const uint64_t v = reinterpret_cast<uint64_t>(p_);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+      return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* cbase = uniform(tile_base(t));
+    const char* nbase = uniform(tile_base(has_next ? tn : t));  // (no next tile: the last two steps re-read this one — legal, unused)
     int cnt = nk - 3;
     f32x16 o[8];
 #define MANNER_W8_RUN_TILE(MFMA_STR)                                                                                                       \
@@ -1743,8 +1749,14 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
     decode(t, mt, nt);
     const int tn = t + G;
     const bool has_next = tn < valid_tiles;
-    const char* cbase = tile_base(t);
-    const char* nbase = tile_base(has_next ? tn : t);  // (no next tile: the last two steps re-read this one — legal, unused)
+    // (readfirstlane: the asm block takes them as SGPR pairs — "s" — and the compiler must not doubt that they are wave-uniform)
+    auto uniform = [](const char* p_) -> const char* {
+      const uint64_t v = reinterpret_cast<uint64_t>(p_);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+      return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* cbase = uniform(tile_base(t));
+    const char* nbase = uniform(tile_base(has_next ? tn : t));  // (no next tile: the last two steps re-read this one — legal, unused)
     int cnt = nk - 3;
 #define MANNER_W4_RUN_TILE(MFMA_STR)                                                                                                       \
   asm volatile(MANNER_W4_TILE_ASM(MFMA_STR)                                                                                                \
@@ -1795,6 +1807,18 @@ static int x16_grid(int64_t m_bound, int n_tiles, DlnAux& aux, dim3& g) {
   return MANNER_HIP_OK;
 }
 
+// Which kernel takes a 16-bit persistent launch (round 6): 8 = gemm_tn_w8_kernel (hand-scheduled K-loop, the default), 4 =
+// gemm_tn_w4_kernel (A/B, deferred-LayerNorm launches only), 0 = gemm_tn_x16_kernel.  The asm kernels run 256-row panels: they take a
+// launch where panel_rows() picks 256 for the best estimate of the token count the host has.  MANNER_HIP_GEMM_ASM is read per launch
+// (the equality tests flip it).
+static int pick_asm(int64_t m_est, int n_tiles, int K, const DlnAux& aux) {
+  const char* e = getenv("MANNER_HIP_GEMM_ASM");
+  const int req = e ? atoi(e) : 8;
+  if (req != 8 && req != 4) return 0;
+  if (aux.stagger != 0 || aux.split_cus > 0 || K % 64 || K < 192 || aux.panel_mode == 2) return 0;
+  return panel_rows((int)m_est, n_tiles, device_cus(), aux.panel_mode) == 256 ? req : 0;
+}
+
 template <typename TE, typename TOut>
 int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
@@ -1806,6 +1830,38 @@ int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, co
   const TE* w = static_cast<const TE*>(W);
   const TE* r = static_cast<const TE*>(R);
   TOut* y = static_cast<TOut*>(Y);
+  if (pick_asm(m_bound, n_tiles, K, aux0) == 8) {      // the same bits from the hand-scheduled K-loop
+    const int64_t tiles = (m_bound / G_BM) * n_tiles;
+    const int64_t cus = device_cus();
+    g = dim3((unsigned)(tiles < cus ? tiles : cus));
+    switch (epi) {
+      case EPI_BIAS:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
+        break;
+      case EPI_BIAS_GELU:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TOut, EPI_BIAS_GELU>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
+        break;
+      case EPI_BIAS_RES:
+        hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TOut, EPI_BIAS_RES>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
+        break;
+      case EPI_BIAS_GELU_SPLIT3:
+        if constexpr (sizeof(TOut) == 2) {
+          hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TOut, EPI_BIAS_GELU_SPLIT3>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
+          break;
+        }
+        return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_GELU_SPLIT3 writes the 16-bit split operand");
+      case EPI_BIAS_RES_F32:
+        if constexpr (sizeof(TOut) == 4) {
+          hipLaunchKernelGGL((gemm_tn_w8_kernel<TE, TOut, EPI_BIAS_RES_F32>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
+          break;
+        }
+        return fail(MANNER_HIP_E_INVALID, "EPI_BIAS_RES_F32 writes f32");
+      default:
+        return fail(MANNER_HIP_E_INVALID, "gemm epilogue %d has its own entry point", (int)epi);
+    }
+    MANNER_LAUNCH_CHECK();
+    return MANNER_HIP_OK;
+  }
   switch (epi) {
     case EPI_BIAS:
       hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI_BIAS>), g, b, 0, stream, x, w, bias, r, y, N, K, m_total, n_tiles, aux0);
@@ -2001,12 +2057,7 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   // 256 rows by what the host knows of the token count (m_exact, else its bound) — 192-row launches and the A/B forms stay on the
   // compiler-scheduled LDS-DMA kernel.  MANNER_HIP_GEMM_ASM = 8 (default) | 4 (the 4-wave form) | 0 (gemm_tn_x16_kernel everywhere);
   // read per launch: the equality test flips it.
-  const char* asm_env = getenv("MANNER_HIP_GEMM_ASM");
-  const int asm_req = asm_env ? atoi(asm_env) : 8;
-  const int64_t m_est = m_exact >= 0 ? m_exact : m_bound;
-  const bool asm_ok = (asm_req == 8 || asm_req == 4) && !split && stagger == 0 && K % 64 == 0 && K >= 192 && aux.panel_mode != 2 &&
-                      panel_rows((int)m_est, n_tiles, (int)cus, aux.panel_mode) == 256;
-  const int asm_mode = asm_ok ? asm_req : 0;
+  const int asm_mode = split ? 0 : pick_asm(m_exact >= 0 ? m_exact : m_bound, n_tiles, K, aux);
   if (asm_mode) g = dim3((unsigned)(tiles < cus ? tiles : cus));
   int rc;
   if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, asm_mode);
