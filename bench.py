@@ -1535,7 +1535,7 @@ def main():
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs; bench.py cannot collect counters itself): the newest profiles/r*_final/pmc_traffic.json
         traffic, traffic_src = None, None
-        for rdir in ("r5_final", "r4_final", "r3_final", "r2_final", "r1_final"):
+        for rdir in ("r6_final", "r5_final", "r4_final", "r3_final", "r2_final", "r1_final"):
             tpath = os.path.join(ROOT, "profiles", rdir, "pmc_traffic.json")
             if os.path.exists(tpath) and args.chunk_tokens == 65536 and model == "bert-base-uncased" and args.precision in ("bf16", "f16"):
                 with open(tpath) as f:
@@ -1546,7 +1546,8 @@ def main():
                     break
         result["kernels"] = kern
         result["roofline"] = {
-            "kernel": dom + (" (gemm_tn_x16_kernel)" if args.precision != "fp32" else " (gemm_tn_big_kernel)"), "bound": "mfma",
+            "kernel": dom + ((" (gemm_tn_w8_kernel)" if os.environ.get("MANNER_HIP_GEMM_ASM", "8") == "8" else " (gemm_tn_x16_kernel)")
+                             if args.precision != "fp32" else " (gemm_tn_big_kernel)"), "bound": "mfma",
             "achieved": kern[dom]["tflops"], "peak": peak,
             "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
             "mfma_only_ceiling_tflops": 2040.0 if args.precision in ("bf16", "f16") else None,

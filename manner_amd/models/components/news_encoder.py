@@ -25,6 +25,24 @@ from manner_amd.weights import plm_param_shapes
 
 _warned_eval_graph = False
 
+# Optimiser steps taken in this process.  The inference handle keys its packed weight copies on (storage address, version counter) of
+# the parameters — but a FUSED optimiser (torch.optim.AdamW(fused=True), with or without a GradScaler) rewrites them without bumping
+# Parameter._version (measured on torch 2.10 / ROCm: 0 -> 0 while the values change, tools/version_probe.py; the foreach and the
+# single-tensor forms bump it).  So ANY optimiser step — the global post-step hook below counts them — makes the next eval() forward
+# repack: at most one repack per (step, eval forward) pair, i.e. nothing inside a training epoch and one rebuild when validation starts.
+_OPT_STEPS = [0]
+
+
+def _count_optimizer_step(*_args, **_kwargs) -> None:
+    _OPT_STEPS[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step
+    _register_post_step(_count_optimizer_step)
+except ImportError:                                      # torch < 2.0: the sampled fingerprint (weight_fingerprint) is the only tripwire
+    pass
+
 
 def autocast_mode(device_type: str = "cuda") -> Optional[str]:
     """The 16-bit mode the CALLER's autocast state asks for: "f16" under ``torch.autocast("cuda", torch.float16)`` — what Lightning's
@@ -271,7 +289,7 @@ class MannerTextEncoder(nn.Module):
         # the handle packs the weights once per mode it has been asked for: a caller that alternates autocast states (a 16-mixed fit
         # whose sanity check ran outside autocast, an A/B) grows the set instead of rebuilding the engine at every flip
         mode = precision if precision is not None else self.resolved_precision()
-        key = (device, state)
+        key = (device, state, _OPT_STEPS[0])
         packed = self.__dict__.get("_hip_modes", ())
         if self._hip is None or self._hip_key != key or mode not in packed:
             same_weights = self._hip is not None and self._hip_key == key

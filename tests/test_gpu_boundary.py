@@ -188,3 +188,31 @@ def test_eval_handle_notices_parameter_writes_through_p_data():
         p.mul_(2.0)
         assert torch.equal(enc(x), out2)
     enc.check_inputs()
+
+
+def test_a_fused_optimizer_step_reaches_the_eval_handle():
+    """torch.optim.AdamW(fused=True) rewrites the parameters WITHOUT bumping Parameter._version (tools/version_probe.py: 0 -> 0 on
+    torch 2.10 / ROCm) — the (address, version) key of the inference handle cannot see it.  The global optimiser post-step hook can:
+    the eval() forward after a fused step computes with the new values, and nothing raises."""
+    enc, cfg = _text_encoder("tiny-bert", 9, 0.05)
+    ids, mask = synth_news_tokens(8, cfg, seed=9, max_len=20)
+    x = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    enc.eval()
+    with torch.no_grad():
+        out0 = enc(x).clone()
+    p = dict(enc.named_parameters())["plm_model.encoder.layer.1.output.dense.weight"]
+    opt = torch.optim.AdamW([p], lr=1e-2, fused=True)
+    v0 = p._version
+    p.grad = torch.ones_like(p)
+    opt.step()
+    fused_bumps = p._version != v0                          # False on torch 2.10: exactly the case this test is about
+    with torch.no_grad():
+        out1 = enc(x).clone()
+        out2 = enc(x).clone()                               # and no tripwire error on the forward after
+    assert not torch.equal(out1, out0) and torch.equal(out2, out1), fused_bumps
+    fresh, _ = _text_encoder("tiny-bert", 9, 0.05)
+    fresh.eval()
+    with torch.no_grad():
+        dict(fresh.named_parameters())["plm_model.encoder.layer.1.output.dense.weight"].copy_(p)
+        assert torch.equal(fresh(x), out1)
+    enc.check_inputs()

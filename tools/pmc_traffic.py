@@ -28,12 +28,19 @@ CLASSES = [   # (class, substrings that must all occur in the kernel name)
 ]
 # rocprofv3 prints some instantiations half-demangled; EPI_NRES appears as "<bool _Accum, int, ELi0E>"
 # (round 5: the kernel has a fifth template argument — `, 3, 0, true>` / `Li3ELi0ELb1E`; the mangled substrings still match)
-TEMPLATE_HINTS = {"Li3ELi0E": (", 3, 0>", ", 3, 0, true>"), "Li4ELi0E": (", 4, 0>", ", 4, 0, true>"), "Li5ELi0E": ("int, ELi0E>", ", 5, 0, true>", "int, ELi0ELb1E>")}
+TEMPLATE_HINTS = {"Li3ELi0E": (", 3, 0>", ", 3, 0, true>"), "Li4ELi0E": (", 4, 0>", ", 4, 0, true>"), "Li5ELi0E": ("int, ELi0E>", ", 5, 0, true>", "int, ELi0ELb1E>", ", 5, 0>")}
 
 
 def classify(name):
+    # round 6: the hand-scheduled kernels gemm_tn_w8_kernel / gemm_tn_w4_kernel take the 256-row launches of the same three classes
+    # (same EPI template argument; w8 carries the lab's ABL argument too: <.., EPI, 0>, w4 ends at <.., EPI>)
+    name_x = name.replace("gemm_tn_w8_kernel", "gemm_tn_x16_kernel")
+    if "gemm_tn_w4_kernel" in name_x:
+        name_x = name_x.replace("gemm_tn_w4_kernel", "gemm_tn_x16_kernel")
+        for epi in (3, 4, 5):
+            name_x = name_x.replace(f"Li{epi}EEE", f"Li{epi}ELi0EEE").replace(f", {epi}>", f", {epi}, 0>")
     for cls, subs in CLASSES:
-        if all(s in name or any(h in name for h in TEMPLATE_HINTS.get(s, ())) for s in subs):
+        if all(s in name_x or any(h in name_x for h in TEMPLATE_HINTS.get(s, ())) for s in subs):
             return cls
     return None
 
