@@ -560,7 +560,7 @@ def test_training_buffer_sizes_follow_the_documented_rule():
 
 def test_every_environment_switch_is_documented():
     """The library's A/B switches are read with getenv() in csrc/ and os.environ in the package: each one has a line in DESIGN.md
-    (the table of switches in section 4) or INTEGRATION.md, so that a measured alternative cannot hide in the build."""
+    (the table of switches, section 7) or INTEGRATION.md, so that a measured alternative cannot hide in the build."""
     import re
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = set()
