@@ -1456,6 +1456,9 @@ __device__ __forceinline__ void gemm_tn_x16_body(
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // residual variant: the last half slab's 4 stores
     }
     first = false;
+#ifdef MANNER_W8_STAMPS   // lab build only: the same shader-clock split as gemm_tn_w8_kernel's
+    const uint64_t xst0 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();    // also: every wave has left the previous epilogue's LDS slabs
     read_w(lds + buf * G_OP_BYTES, 0, w0);
     read_x(lds + XB + xs * G_OP_BYTES, 0, 0, xa);
@@ -1472,6 +1475,9 @@ __device__ __forceinline__ void gemm_tn_x16_body(
     kstep(last, xs, gsrc, 0, 0, gnext, has_next, Mode2{});
     const int xfree = xs;              // activation stage of the last step: free for the epilogue slabs
     xs = xs == 2 ? 0 : xs + 1;
+#ifdef MANNER_W8_STAMPS
+    const uint64_t xst1 = __builtin_amdgcn_s_memtime();
+#endif
 
     {
       int ew = wave;
@@ -1479,6 +1485,13 @@ __device__ __forceinline__ void gemm_tn_x16_body(
       x16_epilogue<TE, TOut, EPI, ABL, MBT>(acc, lds + XB + xfree * G_OP_BYTES + ew * 4096, lds + last * G_OP_BYTES + ew * 4096, lane, ew, mt, nt, M, N,
                                              bias, R, Y, dln);
     }
+#ifdef MANNER_W8_STAMPS
+    if (dln.aux32) {
+      const uint64_t xst2 = __builtin_amdgcn_s_memtime();
+      uint64_t* dst = reinterpret_cast<uint64_t*>(const_cast<float*>(dln.aux32)) + ((size_t)blockIdx.x * 8 + wave) * 3;
+      if (lane == 0) { dst[0] += xst1 - xst0; dst[1] += xst2 - xst1; dst[2] += 1; }
+    }
+#endif
     if (!has_next) break;
     t = tn;
     gsrc = gnext;
@@ -1578,8 +1591,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
   const uint32_t d0 = (uint32_t)(((lc ^ ((lrow >> 1) & 7)) - lc) * 16), d1 = (uint32_t)(((lc ^ ((4 + (lrow >> 1)) & 7)) - lc) * 16);
   const uint32_t rowb = (uint32_t)K * 2u;
   const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
-  uint32_t g0 = lane_off + 0 * 8 * rowb, g1 = lane_off + 1 * 8 * rowb, g2 = lane_off + 2 * 8 * rowb, g3 = lane_off + 3 * 8 * rowb,
-           g4 = lane_off + 4 * 8 * rowb, g5 = lane_off + 5 * 8 * rowb, g6 = lane_off + 6 * 8 * rowb, g7 = lane_off + 7 * 8 * rowb;
+  uint32_t g = lane_off;                               // the lane's byte offset of piece 0; piece p adds the wave-uniform p * 8 * rowb
+  const uint32_t c1 = 8 * rowb, c2 = 16 * rowb, c3 = 24 * rowb, c4 = 32 * rowb, c5 = 40 * rowb, c6 = 48 * rowb, c7 = 56 * rowb;
   // this wave's operand quarter of a tile, as a wave-uniform byte pointer
   auto tile_base = [&](int tile) -> const char* {
     int mt_, nt_;
@@ -1587,23 +1600,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     const TE* p_ = op == 0 ? W + (size_t)(nt_ * G_BN + 64 * qf) * K : X + (size_t)(mt_ * G_BM + 64 * qf) * K;
     return reinterpret_cast<const char*>(p_);
   };
-  // ---- prologue (once per workgroup): K-step 0 -> stage 0, K-step 1 -> stage 1
+  // Where the next tile's K-step 1 waits out the epilogue: in 32 registers `sa` (requested by the tile's last step like any other
+  // step's operands, written to LDS by the next tile's first step — nothing has to land before the epilogue may start) where the
+  // epilogue leaves 32 registers (the deferred-LayerNorm consumers), else by LDS-DMA behind the tile's last barrier.
+  constexpr bool AGPR = EPI == EPI_NORM || EPI == EPI_NORM_GELU;
+  e16x8 sa[8];
+  // ---- prologue (once per workgroup): K-step 0 -> stage 0, K-step 1 -> stage 1 (-> sa where the operands ride in registers, as every later tile finds them)
   {
     const char* cb = tile_base(t);
-    const uint32_t go[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       e16x8 v[8];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + go[p] + kt * (BK * 2));
+      for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + g + (uint32_t)p * 8u * rowb + kt * (BK * 2));
 #pragma unroll
-      for (int p = 0; p < 8; ++p)
-        *reinterpret_cast<e16x8*>(lds + (((p & 1) ? wa1 : wa0) - lds0 - (kt == 0 ? 0x10000u : 0u)) + p * 1024) = v[p];
+      for (int p = 0; p < 8; ++p) {
+        if (AGPR && kt == 1) sa[p] = v[p];
+        else *reinterpret_cast<e16x8*>(lds + (((p & 1) ? wa1 : wa0) - lds0 - (kt == 0 ? 0x10000u : 0u)) + p * 1024) = v[p];
+      }
     }
-    g0 += 256; g1 += 256; g2 += 256; g3 += 256; g4 += 256; g5 += 256; g6 += 256; g7 += 256;      // the load stream stands at K-step 2
+    g += 256;                                          // the load stream stands at K-step 2
     __syncthreads();
   }
   const int nk = K / BK;
+#ifdef MANNER_W8_STAMPS
+  uint64_t stamp_k = 0, stamp_e = 0, stamp_n = 0;
+#endif
   char* slab = lds + 4 * G_OP_BYTES + wave * 4096;     // one wave-private 4 KiB epilogue slab in the 32 KiB behind the stages
   while (true) {
     int mt, nt;
@@ -1620,19 +1642,43 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     const char* nbase = uniform(tile_base(has_next ? tn : t));  // (no next tile: the last two steps re-read this one — legal, unused)
     int cnt = nk - 3;
     f32x16 o[8];
+#ifdef MANNER_W8_STAMPS   // lab build only (tools/gemm4w_lab.hip): shader-clock stamps around the K-loop and the epilogue of every tile
+    const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
+#define MANNER_W8_STATE [g] "+v"(g), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1), [cnt] "+s"(cnt)
+#define MANNER_W8_CONSTS                                                                                                                   \
+  [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3), [c4] "s"(c4), [c5] "s"(c5),          \
+      [c6] "s"(c6), [c7] "s"(c7)
 #define MANNER_W8_RUN_TILE(MFMA_STR)                                                                                                       \
   asm volatile(MANNER_W8_TILE_ASM(MFMA_STR)                                                                                                \
-               : MANNER_W8_ACC_OUTPUTS(o), [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5),       \
-                 [g6] "+v"(g6), [g7] "+v"(g7), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0),        \
-                 [rx1] "+v"(rx1), [cnt] "+s"(cnt)                                                                                          \
-               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1)                                       \
+               : MANNER_W8_ACC_OUTPUTS(o), MANNER_W8_STATE                                                                                 \
+               : MANNER_W8_CONSTS, [d0] "v"(d0), [d1] "v"(d1)                                                                              \
                : MANNER_W8_CLOBBERS)
-    if constexpr (E16<TE>::dtype == DT_BF16) {
-      MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_bf16");
+#define MANNER_W8_RUN_TILE_REGS(MFMA_STR)                                                                                                  \
+  asm volatile(MANNER_W8_TILE_ASM_REGS(MFMA_STR)                                                                                           \
+               : MANNER_W8_ACC_OUTPUTS(o), MANNER_W8_REGS_OPERANDS(sa), MANNER_W8_STATE                                                    \
+               : MANNER_W8_CONSTS                                                                                                          \
+               : MANNER_W8_CLOBBERS)
+    if constexpr (AGPR) {
+      if constexpr (E16<TE>::dtype == DT_BF16) {
+        MANNER_W8_RUN_TILE_REGS("v_mfma_f32_16x16x32_bf16");
+      } else {
+        MANNER_W8_RUN_TILE_REGS("v_mfma_f32_16x16x32_f16");
+      }
     } else {
-      MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_f16");
+      if constexpr (E16<TE>::dtype == DT_BF16) {
+        MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_bf16");
+      } else {
+        MANNER_W8_RUN_TILE("v_mfma_f32_16x16x32_f16");
+      }
     }
 #undef MANNER_W8_RUN_TILE
+#undef MANNER_W8_RUN_TILE_REGS
+#undef MANNER_W8_STATE
+#undef MANNER_W8_CONSTS
+#ifdef MANNER_W8_STAMPS
+    const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
     {
       f32x4 acc[4][8];                                 // acc[a][b] = v[4 (8 a + b) ..] = o[2 a + (b >> 2)][4 (b & 3) ..]
 #pragma unroll
@@ -1647,9 +1693,21 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
       asm volatile("" : "+s"(ew));
       x16_epilogue<TE, TOut, EPI, ABL, 8, true>(acc, slab, slab, lane, ew, mt, nt, M, N, bias, R, Y, dln);
     }
+#ifdef MANNER_W8_STAMPS
+    {
+      const uint64_t st2 = __builtin_amdgcn_s_memtime();
+      stamp_k += st1 - st0; stamp_e += st2 - st1; stamp_n += 1;
+    }
+#endif
     if (!has_next) break;
     t = tn;
   }
+#ifdef MANNER_W8_STAMPS
+  if (lane == 0 && dln.aux32) {                        // {cycles in K-loops, cycles in epilogues, tiles} per wave
+    uint64_t* dst = reinterpret_cast<uint64_t*>(const_cast<float*>(dln.aux32)) + ((size_t)blk * 8 + wave) * 3;
+    dst[0] = stamp_k; dst[1] = stamp_e; dst[2] = stamp_n;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1714,10 +1772,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
   const uint32_t d0 = (uint32_t)(((lc ^ ((lrow >> 1) & 7)) - lc) * 16), d1 = (uint32_t)(((lc ^ ((4 + (lrow >> 1)) & 7)) - lc) * 16);
   const uint32_t rowb = (uint32_t)K * 2u;
   const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
-  uint32_t g0 = lane_off + 0 * 8 * rowb, g1 = lane_off + 1 * 8 * rowb, g2 = lane_off + 2 * 8 * rowb, g3 = lane_off + 3 * 8 * rowb,
-           g4 = lane_off + 4 * 8 * rowb, g5 = lane_off + 5 * 8 * rowb, g6 = lane_off + 6 * 8 * rowb, g7 = lane_off + 7 * 8 * rowb,
-           g8 = lane_off + 8 * 8 * rowb, g9 = lane_off + 9 * 8 * rowb, g10 = lane_off + 10 * 8 * rowb, g11 = lane_off + 11 * 8 * rowb,
-           g12 = lane_off + 12 * 8 * rowb, g13 = lane_off + 13 * 8 * rowb, g14 = lane_off + 14 * 8 * rowb, g15 = lane_off + 15 * 8 * rowb;
+  uint32_t g = lane_off;                               // the lane's byte offset of piece 0; piece p adds the wave-uniform p * 8 * rowb
+  const uint32_t c1 = 8 * rowb, c2 = 16 * rowb, c3 = 24 * rowb, c4 = 32 * rowb, c5 = 40 * rowb, c6 = 48 * rowb, c7 = 56 * rowb, c8 = 64 * rowb,
+                 c9 = 72 * rowb, c10 = 80 * rowb, c11 = 88 * rowb, c12 = 96 * rowb, c13 = 104 * rowb, c14 = 112 * rowb, c15 = 120 * rowb;
   // this wave's operand half of a tile, as a wave-uniform byte pointer
   auto tile_base = [&](int tile) -> const char* {
     int mt_, nt_;
@@ -1728,18 +1785,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
   // ---- prologue (once per workgroup): K-step 0 -> stage 0, K-step 1 -> stage 1
   {
     const char* cb = tile_base(t);
-    const uint32_t go[16] = {g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       e16x8 v[16];
 #pragma unroll
-      for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + go[p] + kt * (BK * 2));
+      for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const e16x8*>(cb + g + (uint32_t)p * 8u * rowb + kt * (BK * 2));
 #pragma unroll
       for (int p = 0; p < 16; ++p)
         *reinterpret_cast<e16x8*>(lds + (((p & 1) ? wa1 : wa0) - lds0 - (kt == 0 ? 0x10000u : 0u)) + p * 1024) = v[p];
     }
-    g0 += 256; g1 += 256; g2 += 256; g3 += 256; g4 += 256; g5 += 256; g6 += 256; g7 += 256;
-    g8 += 256; g9 += 256; g10 += 256; g11 += 256; g12 += 256; g13 += 256; g14 += 256; g15 += 256;      // the load stream stands at K-step 2
+    g += 256;                                          // the load stream stands at K-step 2
     __syncthreads();
   }
   const int nk = K / BK;
@@ -1760,11 +1815,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
     int cnt = nk - 3;
 #define MANNER_W4_RUN_TILE(MFMA_STR)                                                                                                       \
   asm volatile(MANNER_W4_TILE_ASM(MFMA_STR)                                                                                                \
-               : [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5), [g6] "+v"(g6), [g7] "+v"(g7),   \
-                 [g8] "+v"(g8), [g9] "+v"(g9), [g10] "+v"(g10), [g11] "+v"(g11), [g12] "+v"(g12), [g13] "+v"(g13), [g14] "+v"(g14),        \
-                 [g15] "+v"(g15), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1),    \
+               : [g] "+v"(g), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1),        \
                  [cnt] "+s"(cnt)                                                                                                           \
-               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1)                                       \
+               : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1), [c1] "s"(c1), [c2] "s"(c2),         \
+                 [c3] "s"(c3), [c4] "s"(c4), [c5] "s"(c5), [c6] "s"(c6), [c7] "s"(c7), [c8] "s"(c8), [c9] "s"(c9), [c10] "s"(c10),         \
+                 [c11] "s"(c11), [c12] "s"(c12), [c13] "s"(c13), [c14] "s"(c14), [c15] "s"(c15)                                            \
                : MANNER_W4_CLOBBERS)
     if constexpr (E16<TE>::dtype == DT_BF16) {
       MANNER_W4_RUN_TILE("v_mfma_f32_16x16x32_bf16");

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <vector>
 #include <random>
+#define MANNER_W8_STAMPS 1
 #include "../manner_amd/csrc/gemm.hip"
 namespace manner { int fail(int code, const char* fmt, ...) { fprintf(stderr, "fail %d: %s\n", code, fmt); return code; } }
 using namespace manner;
@@ -419,6 +420,32 @@ int main(int argc, char** argv) {
         tw8f = time_us([&] { hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_BIAS, 0>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
       if (want("prodfull"))
         tpf = time_us([&] { hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 0, false>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, aux); }, iters);
+      if (want("stamps")) {                              // in-kernel shader-clock split of the integrated kernel: K-loops vs epilogues, per tile
+        uint64_t* st; CK(hipMalloc(&st, 256 * 8 * 3 * 8)); CK(hipMemset(st, 0, 256 * 8 * 3 * 8));
+        DlnAux ax = aux; ax.aux32 = reinterpret_cast<const float*>(st);
+        std::vector<float2> hm(M, float2{0.01f, 1.0f});
+        float2* mr; float* vec; CK(hipMalloc(&mr, (size_t)M * 8)); CK(hipMalloc(&vec, 3072 * 4));
+        CK(hipMemcpy(mr, hm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+        std::vector<float> hv(3072, 1.0f); CK(hipMemcpy(vec, hv.data(), 3072 * 4, hipMemcpyHostToDevice));
+        ax.vec = vec; ax.mr = mr; ax.part_stride = M;
+        for (int e = 0; e < 6; ++e) {
+          CK(hipMemset(st, 0, 256 * 8 * 3 * 8));
+          if (e == 3) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_BIAS, 0, false>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          else if (e == 4) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_NORM, 0, false>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          else if (e == 5) hipLaunchKernelGGL((gemm_tn_x16_kernel<bf16_t, bf16_t, EPI_NORM_GELU, 0, false>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          else if (e == 0) hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_BIAS, 0>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          else if (e == 1) hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_NORM, 0>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          else hipLaunchKernelGGL((gemm_tn_w8_kernel<bf16_t, bf16_t, EPI_NORM_GELU, 0>), g, dim3(512), 0, 0, X, W, bias, (const bf16_t*)nullptr, Y16, s.N, s.K, mtot, n_tiles, ax);
+          CK(hipDeviceSynchronize());
+          std::vector<uint64_t> h(256 * 8 * 3);
+          CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+          double sk = 0, se = 0, sn = 0;
+          for (size_t i = 0; i < h.size(); i += 3) { sk += h[i]; se += h[i + 1]; sn += h[i + 2]; }
+          printf("stamps %-4s %s %-9s: per tile and wave: K-loop %.0f cycles, epilogue %.0f cycles (shader clock), %.0f tiles x waves\n", s.name, e < 3 ? "w8 " : "x16",
+                 e % 3 == 0 ? "BIAS" : e % 3 == 1 ? "NORM" : "NORM_GELU", sk / sn, se / sn, sn);
+        }
+        CK(hipFree(st)); CK(hipFree(mr)); CK(hipFree(vec));
+      }
       if (hipcc_vars && want("v0"))
         t0 = time_us([&] { hipLaunchKernelGGL((lab4::gemm4w_kernel<bf16_t, 0, false>), g, dim3(256), 0, 0, X, W, Y, s.N, s.K, M, n_tiles); }, 20);
       if (hipcc_vars && want("v1"))

@@ -20,12 +20,13 @@ here as one inline-asm block with explicit registers; tile walk, prologue and th
 
 Registers of the block (clobbered): a[0:255] acc[a][b] (a = 16-column block 0..7, b = 16-row block 0..7 of the wave tile), v[0:63]
 S[16] staging pieces, v[64:127] wf[2][8] weight fragments of the two k32 halves, v[128:143] xf[4] activation fragments.
-Operands: g0..g15 (+v) per-piece global byte offsets (advance 128 B per K-step, net change over a tile: 0), wa0 / wa1 (+v) staging
+Operands: g (+v) the lane's global byte offset of piece 0 (advances 128 B per K-step, net change over a tile: 0; piece p adds the
+wave-uniform c<p> = p * 8 * rowbytes through one address temporary), wa0 / wa1 (+v) staging
 write addresses, rw0 / rw1 / rx0 / rx1 (+v) fragment read addresses (LDS stage = bit 16, toggled by v_xor), base / nbase (s, 64-bit)
 this tile's / the next tile's operand base of the wave, rowb (s) bytes per operand row, cnt (+s) K-steps of the middle loop (nk - 3).
 
 State at block entry (= at exit, for the next tile): K-step 0 of the tile in stage P, K-step 1 in the other stage Q, both visible
-(a barrier has passed), S free, nothing in flight; rw0, rw1, rx0, rx1 -> P; wa0, wa1 -> Q; g_p = lane offset + 2 * 128.
+(a barrier has passed), S free, nothing in flight; rw0, rw1, rx0, rx1 -> P; wa0, wa1 -> Q; g = lane offset + 2 * 128.
 K-step s: 16 clusters of 8 MFMAs (one activation fragment x 8 weight fragments).  Clusters 0..12 carry, one per MFMA gap, the 16
 pieces' (wait vmcnt(15), ds_write S[p] -> other stage, global_load S[p] <- K-step s + 2) and the fragment reads (activation fragment
 two clusters ahead, weight fragment of the second k32 half); s_barrier after cluster 13; clusters 14 / 15 compute from registers and
@@ -46,6 +47,7 @@ L = []
 NW = 4
 NA = 8            # weight fragments per wave (16-column blocks)
 NP = 16           # staging pieces per wave and K-step
+VTMP = 144        # the block's address temporary
 
 
 def e(s):
@@ -100,9 +102,22 @@ def entry_reads():
     e("v_xor_b32 %[rw0], 0x10000, %[rw0]")
 
 
-def kstep(first, last, base):
+def addr_of(p):
+    """Global byte offset of piece p: %[g] (+ the wave-uniform p * 8 * rowbytes in %[c<p>]) through the block's one address temporary."""
+    if p == 0:
+        return [], "%[g]"
+    return [("alu", f"v_add_u32 v{VTMP}, %[c{p}], %[g]", None)], f"v{VTMP}"
+
+
+def kstep(first, last, base, stage="dma", early=False):
     q = LdsQueue(post_reads("w0", "x"))
     h = NA // 2
+    if early and stage == "regs":
+        for p in range(NP):                          # the next tile's K-step 1 (g stands at its K-step 0: + 128 bytes) -> sa
+            pre, ad = addr_of(p)
+            for _, text, _ in pre:
+                e(text)
+            e(f"global_load_dwordx4 %[sa{p}], {ad}, %[{base}] offset:128")
     for c in range(16):
         s2, b = c >> 3, c & 7
         slot = c & 3
@@ -120,24 +135,67 @@ def kstep(first, last, base):
         for p in range(NP):
             if piece_cluster(p) == c:
                 grp = []
+                if stage == "regs":
+                    # the next tile's K-step 1 rides through the epilogue in the operands sa0.. (registers of the COMPILER's choosing,
+                    # live across the epilogue).  They are free from the tile's first step on, so the request goes out EARLY: at the head
+                    # of the second-to-last step (`early`), two K-steps before the epilogue, which therefore never waits behind them
+                    # (vector-memory operations complete in order: a request issued late stalls the epilogue's own first loads — 3.5 k
+                    # cycles per tile by the in-kernel stamps).  (AGPRs would be free of charge — VMEM loads and DS writes address them
+                    # directly — but hipcc halves the VGPR budget of a 256-register kernel to 128 the moment it sees one.)
+                    if first:                              # sa landed long ago (the last step's counted waits on younger loads cover it)
+                        grp.append(("lds", f"ds_write_b128 %[wa{p & 1}], %[sa{p}] offset:{p * 1024}", ("s", p)))
+                    else:
+                        # `early` step: the NP requests into sa are in the queue too (younger than S[p]'s load of the step before)
+                        grp.append(("wait", f"s_waitcnt vmcnt({NP - 1 - p if last else (2 * NP - 1 if early else NP - 1)})", None))
+                        grp.append(("lds", f"ds_write_b128 %[wa{p & 1}], {vr(S0 + 4 * p)} offset:{p * 1024}", ("s", p)))
+                    if not last:
+                        pre, ad = addr_of(p)
+                        grp.extend(pre)
+                        grp.append(("vm", f"global_load_dwordx4 {vr(S0 + 4 * p)}, {ad}, %[{base}]", None))
+                    if p == NP - 1:
+                        grp.append(("alu", "v_add_u32 %[g], 0x80, %[g]", None))
+                    mem.append(("group", grp, None))
+                    continue
+                if stage == "regs_unused":
+                    # the next tile's K-step 1 rides through the epilogue in the operands sa0.. (registers of the COMPILER's choosing,
+                    # live across the epilogue): requested by the last step right behind each piece's write (as every step requests two
+                    # ahead), written to LDS by the next tile's first step.  (AGPRs would be free of charge — VMEM loads and DS writes
+                    # address them directly — but hipcc halves the VGPR budget of a 256-register kernel to 128 the moment it sees one.)
+                    grp.append(("wait", f"s_waitcnt vmcnt({NP - 1})", None))
+                    src = f"%[sa{p}]" if first else vr(S0 + 4 * p)
+                    grp.append(("lds", f"ds_write_b128 %[wa{p & 1}], {src} offset:{p * 1024}", ("s", p)))
+                    dst = f"%[sa{p}]" if last else vr(S0 + 4 * p)
+                    pre, ad = addr_of(p)
+                    grp.extend(pre)
+                    grp.append(("vm", f"global_load_dwordx4 {dst}, {ad}, %[{base}]", None))
+                    if p == NP - 1:
+                        grp.append(("alu", "v_add_u32 %[g], 0x80, %[g]", None))
+                    mem.append(("group", grp, None))
+                    continue
                 if not first:
                     # (the last step requests nothing into S: its loads in flight shrink with every piece written)
                     grp.append(("wait", f"s_waitcnt vmcnt({NP - 1 - p if last else NP - 1})", None))
                     grp.append(("lds", f"ds_write_b128 %[wa{p & 1}], {vr(S0 + 4 * p)} offset:{p * 1024}", ("s", p)))
                 if not last:
-                    grp.append(("vm", f"global_load_dwordx4 {vr(S0 + 4 * p)}, %[g{p}], %[{base}]", None))
-                    grp.append(("alu", f"v_add_u32 %[g{p}], 0x80, %[g{p}]", None))
+                    pre, ad = addr_of(p)
+                    grp.extend(pre)
+                    grp.append(("vm", f"global_load_dwordx4 {vr(S0 + 4 * p)}, {ad}, %[{base}]", None))
+                    if p == NP - 1:
+                        grp.append(("alu", "v_add_u32 %[g], 0x80, %[g]", None))
                 mem.append(("group", grp, None))
-        if last and c >= 14 and not os.environ.get("W_LAB_NO_DMA"):      # (W_LAB_NO_DMA=1: timing experiment only — wrong results)
+        if last and c >= 14 and stage == "dma":
             # behind the last barrier of the tile the stage it has finished with is free: the NEXT tile's K-step 1 goes there by LDS-DMA
             # (no register holds it, so it lands while the epilogue runs: the one place where the DMA's issue cost buys something).
             # Linear 1 KiB destination per piece (M0), the row swizzle of the LDS image applied to the SOURCE chunk (d0 / d1).
             for p in range((NP // 2) * (c - 14), (NP // 2) * (c - 14) + NP // 2):
-                grp = [("alu", f"v_add_u32 v{S0 + p}, %[d{p & 1}], %[g{p}]", None),
-                       ("alu", f"s_add_u32 m0, %[cnt], {p * 1024}", None),
-                       ("alu", "s_nop 0", None),
-                       ("vm", f"global_load_lds_dwordx4 v{S0 + p}, %[{base}]", None),
-                       ("alu", f"v_add_u32 %[g{p}], 0x80, %[g{p}]", None)]
+                grp = [("alu", f"v_add_u32 v{S0 + p}, %[d{p & 1}], %[g]", None)]
+                if p:
+                    grp.append(("alu", f"v_add_u32 v{S0 + p}, %[c{p}], v{S0 + p}", None))
+                grp += [("alu", f"s_add_u32 m0, %[cnt], {p * 1024}", None),
+                        ("alu", "s_nop 0", None),
+                        ("vm", f"global_load_lds_dwordx4 v{S0 + p}, %[{base}]", None)]
+                if p == NP - 1:
+                    grp.append(("alu", "v_add_u32 %[g], 0x80, %[g]", None))
                 mem.append(("group", grp, None))
         if c == 8:
             mem.append(("alu", "v_xor_b32 %[rx0], 0x10000, %[rx0]", None))
@@ -162,10 +220,10 @@ def kstep(first, last, base):
         if c == NPRE - 1:
             # first step of a tile: the K-step 1 operands came by LDS-DMA behind the previous tile's last barrier — everything older than
             # this step's own NP loads has to have landed before the barrier that publishes it
-            e(f"s_waitcnt vmcnt({NP}) lgkmcnt(0)" if first else "s_waitcnt lgkmcnt(0)")
+            e(f"s_waitcnt vmcnt({NP}) lgkmcnt(0)" if (first and stage == "dma") else "s_waitcnt lgkmcnt(0)")
             e("s_barrier")
             q.drain()
-            if last:
+            if last and stage == "dma":
                 e("v_readfirstlane_b32 %[cnt], %[wa0]")      # lane 0's staging address = the wave's piece 0 in the freed stage (cnt is dead: reused)
         if c == 14:
             e("v_xor_b32 %[rx1], 0x10000, %[rx1]")
@@ -178,36 +236,41 @@ def kstep(first, last, base):
         e("s_nop 7")
 
 
-def tile_block():
+def tile_block(stage="dma"):
     entry_reads()
-    kstep(True, False, "base")
+    kstep(True, False, "base", stage)
     e("s_cmp_eq_u32 %[cnt], 0")
     e("s_cbranch_scc1 .Lw4_switch_%=")
     e(".Lw4_mid_%=:")
     # (a per-tile L2 touch of the next tile's first K-steps — one 4-byte load per row, two passes before the load stream enters the next
     # tile — was built and measured: Q|K|V 202 -> 206 us, FFN1 307 -> 313: the tile boundary is not an HBM-latency problem.  Removed.)
-    kstep(False, False, "base")
+    kstep(False, False, "base", stage)
     e("s_sub_u32 %[cnt], %[cnt], 1")
     e("s_cmp_lg_u32 %[cnt], 0")
     e("s_cbranch_scc1 .Lw4_mid_%=")
     e(".Lw4_switch_%=:")
-    for p in range(NP):                              # the load stream enters the next tile: K-offset back to 0
-        e(f"v_subrev_u32 %[g{p}], %[rowb], %[g{p}]")
-    kstep(False, False, "nbase")
-    kstep(False, True, "nbase")
+    e("v_subrev_u32 %[g], %[rowb], %[g]")            # the load stream enters the next tile: K-offset back to 0
+    kstep(False, False, "nbase", stage, early=True)
+    kstep(False, True, "nbase", stage)
 
 
 def main():
-    global NW, NA, NP, S0, WF, XF
+    global NW, NA, NP, S0, WF, XF, VTMP
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for nw in (8, 4):
         NW, NA, NP = nw, (8 if nw == 4 else 4), (16 if nw == 4 else 8)
         # NW = 4: a[0:255] acc | v[0:63] S, v[64:127] wf, v[128:143] xf.   NW = 8: v[0:127] acc | v[128:159] S, v[160:191] wf, v[192:207] xf
         S0, WF, XF = (0, (64, 96), 128) if nw == 4 else (128, (160, 176), 192)
+        VTMP = 144 if nw == 4 else 208
         del L[:]
         out = os.path.join(root, "manner_amd", "csrc", f"gemm_w{nw}_asm.inc")
         tile_block()
         body = L[:]
+        body_a = None
+        if nw == 8:
+            del L[:]
+            tile_block("regs")
+            body_a = L[:]
         n_mfma = sum(x.startswith("@MFMA@") for x in body)
         H = []
         H.append("// GENERATED by tools/gen_gemm_w.py — do not edit; the design is described there and in gemm.hip.")
@@ -220,10 +283,23 @@ def main():
                 H.append(f'  "{ln}\\n" \\')
         H.append('  ""')
         H.append("")
+        if body_a is not None:
+            H.append("// the same K-loop with the next tile's K-step 1 carried through the epilogue in 32 registers (operands sa0..sa7) instead of by LDS-DMA")
+            H.append(f"#define MANNER_W{nw}_TILE_ASM_REGS(MFMA) \\")
+            for ln in body_a:
+                if ln.startswith("@MFMA@"):
+                    H.append(f'  MFMA "{ln[len("@MFMA@"):]}\\n" \\')
+                else:
+                    H.append(f'  "{ln}\\n" \\')
+            H.append('  ""')
+            H.append("")
+            H.append("#define MANNER_W8_REGS_OPERANDS(sa) \\")
+            H.append("  " + ", ".join(f'[sa{j}] "+v"(sa[{j}])' for j in range(8)))
+            H.append("")
         if nw == 4:
-            regs = [f'"v{i}"' for i in range(148)] + [f'"a{i}"' for i in range(256)]
+            regs = [f'"v{i}"' for i in range(145)] + [f'"a{i}"' for i in range(256)]
         else:
-            regs = [f'"v{i}"' for i in range(128, 210)]      # the accumulators v[0:127] are OUTPUTS of the block (8 x 16 registers)
+            regs = [f'"v{i}"' for i in range(128, 209)]      # the accumulators v[0:127] are OUTPUTS of the block (8 x 16 registers)
         H.append(f"#define MANNER_W{nw}_CLOBBERS \"memory\", \"scc\", \"m0\", \\")
         for i in range(0, len(regs), 16):
             H.append("  " + ", ".join(regs[i:i + 16]) + (", \\" if i + 16 < len(regs) else ""))
