@@ -1416,8 +1416,9 @@ def test_f16x3_attention_with_four_key_tiles_matches_the_oracle(preset, monkeypa
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("n_news,with_lengths", [(200, True), (131, False), (700, True), (1100, True)])
-def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(precision, n_news, with_lengths, monkeypatch):
+@pytest.mark.parametrize("n_news,with_lengths,preset", [(200, True, "bert-base-uncased"), (131, False, "bert-base-uncased"), (700, True, "bert-base-uncased"),
+                                                        (1100, True, "bert-base-uncased"), (500, True, "mini-roberta-large")])
+def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(precision, n_news, with_lengths, preset, monkeypatch):
     """Round 6: `gemm_tn_w8_kernel` (the production geometry with a hand-scheduled, register-staged K-loop: one asm block per tile,
     tools/gen_gemm_w.py) and `gemm_tn_w4_kernel` (four waves per CU, 128 x 128 wave tiles in AGPRs) issue, per output element, the same
     matrix instruction over K in the same order as `gemm_tn_x16_kernel` and call its epilogues unchanged, so a deferred-LayerNorm GEMM
@@ -1426,7 +1427,7 @@ def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(p
     (700 / 1100 news), with 256-row panels pinned so that the asm kernels take every launch, and with the panel choice left to the
     library."""
     import dataclasses
-    cfg = dataclasses.replace(PRESETS["bert-base-uncased"], layers=3)
+    cfg = dataclasses.replace(PRESETS[preset], layers=3) if preset == "bert-base-uncased" else PRESETS[preset]   # (roberta-large shape: K = 1024 / 4096, N = 3072 / 1024 / 4096)
     w = make_plm_weights(cfg, seed=96, std=0.03)
     ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=96, max_len=96, profile="title_abstract")
     lens = mask_np.sum(1) if with_lengths else None
@@ -1443,7 +1444,7 @@ def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(p
         for mode in ("0", "8", "4"):
             monkeypatch.setenv("MANNER_HIP_GEMM_ASM", mode)
             got[(panel, mode)] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
-                                  enc.encode_hidden(ids, mask, 2, precision=precision, host_lengths=lens).clone())
+                                  enc.encode_hidden(ids, mask, min(2, cfg.layers - 1), precision=precision, host_lengths=lens).clone())
     enc.status()
     monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
     monkeypatch.delenv("MANNER_HIP_GEMM_ASM", raising=False)
