@@ -1623,6 +1623,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     __syncthreads();
   }
   const int nk = K / BK;
+#ifdef MANNER_W8_SETPRIO  // lab: static priority for the later-dispatched half (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef MANNER_W8_STAMPS
   uint64_t stamp_k = 0, stamp_e = 0, stamp_n = 0;
 #endif
