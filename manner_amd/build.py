@@ -27,6 +27,9 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(PKG, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
+    # the hand-scheduled GEMM K-loops are generated text (tools/gen_gemm_w.py), committed; a checkout without them regenerates
+    if not all(os.path.exists(os.path.join(CSRC, f"gemm_w{nw}_asm.inc")) for nw in (8, 4)):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_w.py")], check=True, capture_output=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train_common.h"), os.path.join(CSRC, "gemm_w4_asm.inc"), os.path.join(CSRC, "gemm_w8_asm.inc"), os.path.join(ROOT, "include", "manner_hip.h")]
     jobs = []
     for s in SOURCES:
