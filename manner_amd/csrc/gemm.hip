@@ -1644,6 +1644,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     const char* cbase = uniform(tile_base(t));
     const char* nbase = uniform(tile_base(has_next ? tn : t));  // (no next tile: the last two steps re-read this one — legal, unused)
     int cnt = nk - 3;
+    int m0_saved;                                      // (the LDS-DMA form saves and restores M0 around its pieces)
+    (void)m0_saved;
     f32x16 o[8];
 #ifdef MANNER_W8_STAMPS   // lab build only (tools/gemm4w_lab.hip): shader-clock stamps around the K-loop and the epilogue of every tile
     const uint64_t st0 = __builtin_amdgcn_s_memtime();
@@ -1654,7 +1656,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
       [c6] "s"(c6), [c7] "s"(c7)
 #define MANNER_W8_RUN_TILE(MFMA_STR)                                                                                                       \
   asm volatile(MANNER_W8_TILE_ASM(MFMA_STR)                                                                                                \
-               : MANNER_W8_ACC_OUTPUTS(o), MANNER_W8_STATE                                                                                 \
+               : MANNER_W8_ACC_OUTPUTS(o), MANNER_W8_STATE, [m0s] "=&s"(m0_saved)                                                          \
                : MANNER_W8_CONSTS, [d0] "v"(d0), [d1] "v"(d1)                                                                              \
                : MANNER_W8_CLOBBERS)
 #define MANNER_W8_RUN_TILE_REGS(MFMA_STR)                                                                                                  \
@@ -1816,10 +1818,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
     const char* cbase = uniform(tile_base(t));
     const char* nbase = uniform(tile_base(has_next ? tn : t));  // (no next tile: the last two steps re-read this one — legal, unused)
     int cnt = nk - 3;
+    int m0_saved;
 #define MANNER_W4_RUN_TILE(MFMA_STR)                                                                                                       \
   asm volatile(MANNER_W4_TILE_ASM(MFMA_STR)                                                                                                \
                : [g] "+v"(g), [wa0] "+v"(wa0), [wa1] "+v"(wa1), [rw0] "+v"(rw0), [rw1] "+v"(rw1), [rx0] "+v"(rx0), [rx1] "+v"(rx1),        \
-                 [cnt] "+s"(cnt)                                                                                                           \
+                 [cnt] "+s"(cnt), [m0s] "=&s"(m0_saved)                                                                                    \
                : [base] "s"(cbase), [nbase] "s"(nbase), [rowb] "s"(rowb), [d0] "v"(d0), [d1] "v"(d1), [c1] "s"(c1), [c2] "s"(c2),         \
                  [c3] "s"(c3), [c4] "s"(c4), [c5] "s"(c5), [c6] "s"(c6), [c7] "s"(c7), [c8] "s"(c8), [c9] "s"(c9), [c10] "s"(c10),         \
                  [c11] "s"(c11), [c12] "s"(c12), [c13] "s"(c13), [c14] "s"(c14), [c15] "s"(c15)                                            \

@@ -237,6 +237,8 @@ def kstep(first, last, base, stage="dma", early=False):
 
 
 def tile_block(stage="dma"):
+    if stage == "dma":
+        e("s_mov_b32 %[m0s], m0")                    # M0 addresses the LDS-DMA pieces: saved and restored (it is not ours to clobber)
     entry_reads()
     kstep(True, False, "base", stage)
     e("s_cmp_eq_u32 %[cnt], 0")
@@ -252,6 +254,8 @@ def tile_block(stage="dma"):
     e("v_subrev_u32 %[g], %[rowb], %[g]")            # the load stream enters the next tile: K-offset back to 0
     kstep(False, False, "nbase", stage, early=True)
     kstep(False, True, "nbase", stage)
+    if stage == "dma":
+        e("s_mov_b32 m0, %[m0s]")
 
 
 def main():
@@ -300,7 +304,7 @@ def main():
             regs = [f'"v{i}"' for i in range(145)] + [f'"a{i}"' for i in range(256)]
         else:
             regs = [f'"v{i}"' for i in range(128, 209)]      # the accumulators v[0:127] are OUTPUTS of the block (8 x 16 registers)
-        H.append(f"#define MANNER_W{nw}_CLOBBERS \"memory\", \"scc\", \"m0\", \\")
+        H.append(f"#define MANNER_W{nw}_CLOBBERS \"memory\", \"scc\", \\")
         for i in range(0, len(regs), 16):
             H.append("  " + ", ".join(regs[i:i + 16]) + (", \\" if i + 16 < len(regs) else ""))
         H.append("")
