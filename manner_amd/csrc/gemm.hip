@@ -881,7 +881,27 @@ struct DlnAux {
   // last panel may reach past it, so its 8-row DMA pieces are clamped to the buffer (rows >= *m_total are computed and never stored).
   int panel_mode;
   int64_t x_rows;
+  // Round 6: 1 = every XCD walks a CONTIGUOUS range of the tile order (tile_walk) instead of every 8th slot of each round
+  int xcd_ranges;
 };
+
+// The tiles one workgroup of a persistent launch walks: {first, stride, end}.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx & 7), each with its own 4 MiB L2.  Interleaved (ranges == 0, rounds 1-5): XCD x takes slots [32 x, 32 x + 32) of EVERY
+// round of 256 tiles — the 32 tiles it runs together share their row panels, but from round to round it moves on across the whole
+// tile order and meets every weight tile again after 7/8 of the launch's operands have passed through its L2: FFN1 fetched 4.7 MB of
+// weights per XCD per round (8 x 12 x 4.7 = 453 MB of a 600 MB fetch for 105 MB of operands, profiles/r5_final/pmc_traffic.json).
+// Ranges (== 1): XCD x owns tiles [T x / 8, T (x + 1) / 8) of the order and its 32 workgroups walk them in rounds; with the order
+// column-group-major (col_group) the XCD then works on ONE group of weight tiles for the whole launch (or two, around a group boundary)
+// and they stay in its L2.  The number of rounds is the same (ceil(ceil(T / 8) / 32) = ceil(T / 256)); results do not depend on it.
+struct TileWalk { int first, stride, end; };
+__device__ __forceinline__ TileWalk tile_walk(int G, int b, int valid_tiles, int ranges) {
+  const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
+  const int first_slot = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  if (!ranges) return TileWalk{first_slot + (b >> 3), G, valid_tiles};
+  const int n_x = q8 + (xcd < r8 ? 1 : 0);             // workgroups on this XCD (>= 1: this one)
+  const int lo = (int)((int64_t)valid_tiles * first_slot / G), hi = (int)((int64_t)valid_tiles * (first_slot + n_x) / G);
+  return TileWalk{lo + (b >> 3), n_x, hi};
+}
 
 // Wave quantisation of a persistent launch (round 5).  tiles = ceil(M / rows) * n_tiles on `cus` workgroups last ceil(tiles / cus)
 // whole tile times, so 61 row panels x N = 768 (183 tiles of 256 rows) are ONE round with 73 of 256 CUs idle — while the same rows
@@ -1263,8 +1283,6 @@ __device__ __forceinline__ void gemm_tn_x16_body(
   constexpr int XB = 2 * G_OP_BYTES;                                        // base of the activation ring
 
   const int G = gridDim.x, b = blockIdx.x;
-  const int q8 = G >> 3, r8 = G & 7, xcd = b & 7;
-  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   const int m_tiles = (MBT == 8 && dln.split_cus > 0) ? split_panels((M + TM - 1) / TM, n_tiles, dln.split_cus) : (M + TM - 1) / TM;
   const int valid_tiles = m_tiles * n_tiles;
   // Tile order: column tiles are walked in groups of `gsz`; within a group the order is row-panel-major.  One pass
@@ -1279,10 +1297,11 @@ __device__ __forceinline__ void gemm_tn_x16_body(
     mt_ = r / width;
     nt_ = g * gsz + (r - mt_ * width);
   };
-  int t = slot;
-  if (t >= valid_tiles) return;
+  const TileWalk walk = tile_walk(G, b, valid_tiles, dln.xcd_ranges);
+  int t = walk.first;
+  if (t >= walk.end) return;
   if (dln.stagger > 0) {
-    const int phase = (slot / n_tiles) & 3;
+    const int phase = (walk.first / n_tiles) & 3;
     for (int i = 0; i < phase * dln.stagger; ++i) __builtin_amdgcn_s_sleep(64);
   }
 
@@ -1435,8 +1454,8 @@ __device__ __forceinline__ void gemm_tn_x16_body(
   while (true) {
     int mt, nt;
     decode(t, mt, nt);
-    const int tn = t + G;
-    const bool has_next = tn < valid_tiles;
+    const int tn = t + walk.stride;
+    const bool has_next = tn < walk.end;
     const Src gnext = tile_src(has_next ? tn : t);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -1555,8 +1574,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
   }
   const int M = *m_total;
   const int G = gridDim.x, blk = blockIdx.x;
-  const int q8 = G >> 3, r8 = G & 7, xcd = blk & 7;
-  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
   const int m_tiles = (M + G_BM - 1) / G_BM;
   const int valid_tiles = m_tiles * n_tiles;
   const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? dln.col_group : n_tiles;      // the tile order of gemm_tn_x16_kernel
@@ -1568,8 +1585,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
     mt_ = r / width;
     nt_ = g * gsz + (r - mt_ * width);
   };
-  int t = slot;
-  if (t >= valid_tiles) return;
+  const TileWalk walk = tile_walk(G, blk, valid_tiles, dln.xcd_ranges);
+  int t = walk.first;
+  if (t >= walk.end) return;
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wn = wave & 3, wm = wave >> 2;             // the wave's 128 x 64 block: columns 64 wn .., rows 128 wm ..
@@ -1633,8 +1651,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
   while (true) {
     int mt, nt;
     decode(t, mt, nt);
-    const int tn = t + G;
-    const bool has_next = tn < valid_tiles;
+    const int tn = t + walk.stride;
+    const bool has_next = tn < walk.end;
     // (readfirstlane: the asm block takes them as SGPR pairs — "s" — and the compiler must not doubt that they are wave-uniform)
     auto uniform = [](const char* p_) -> const char* {
       const uint64_t v = reinterpret_cast<uint64_t>(p_);
@@ -1741,8 +1759,6 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
   constexpr int BK = 64;
   const int M = *m_total;
   const int G = gridDim.x, blk = blockIdx.x;
-  const int q8 = G >> 3, r8 = G & 7, xcd = blk & 7;
-  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blk >> 3);
   const int m_tiles = (M + G_BM - 1) / G_BM;
   const int valid_tiles = m_tiles * n_tiles;
   const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? dln.col_group : n_tiles;      // the 8-wave kernel's tile order
@@ -1754,8 +1770,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
     mt_ = r / width;
     nt_ = g * gsz + (r - mt_ * width);
   };
-  int t = slot;
-  if (t >= valid_tiles) return;
+  const TileWalk walk = tile_walk(G, blk, valid_tiles, dln.xcd_ranges);
+  int t = walk.first;
+  if (t >= walk.end) return;
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wn = wave & 1, wm = wave >> 1;             // the wave's 128 x 128 block: columns 128 wn .., rows 128 wm ..
@@ -1807,8 +1824,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
   while (true) {
     int mt, nt;
     decode(t, mt, nt);
-    const int tn = t + G;
-    const bool has_next = tn < valid_tiles;
+    const int tn = t + walk.stride;
+    const bool has_next = tn < walk.end;
     // (readfirstlane: the asm block takes them as SGPR pairs — "s" — and the compiler must not doubt that they are wave-uniform)
     auto uniform = [](const char* p_) -> const char* {
       const uint64_t v = reinterpret_cast<uint64_t>(p_);
@@ -2073,8 +2090,10 @@ static int launch_dln(Epilogue epi, const void* X, const void* W, const float* b
 
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact) {
-  static const int col_group_env = getenv("MANNER_HIP_COL_GROUP") ? atoi(getenv("MANNER_HIP_COL_GROUP")) : -1;   // A/B switch
-  const int col_group = col_group_env >= 0 ? col_group_env : 0;
+  const char* cg_env = getenv("MANNER_HIP_COL_GROUP");                        // A/B switches, read per launch (the tests flip them)
+  const char* xr_env = getenv("MANNER_HIP_XCD_RANGES");
+  const int xcd_ranges = xr_env ? (atoi(xr_env) != 0) : 1;
+  int col_group = cg_env ? atoi(cg_env) : 0;
   if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
     return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
@@ -2097,7 +2116,22 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
   static const bool plain_stores = getenv("MANNER_HIP_NT_STORES") && atoi(getenv("MANNER_HIP_NT_STORES")) == 0;   // A/B switch
+  // Column groups (round 6, with the per-XCD tile ranges of tile_walk): all column tiles in one pass read the activations once but, when
+  // their weights (N K 2 bytes) exceed what an XCD's 4 MiB L2 keeps beside the streaming operands (~2.5 MiB), every XCD re-fetches
+  // them every round: 8 (rounds - 1) N K 2 bytes.  g passes over the rows in groups of ceil(n_tiles / g) column tiles keep a group
+  // resident and read the activations g times: (g - 1) M K 2 bytes more.  Take the cheaper by this count: FFN1 (12 tiles, 4.7 MB) and
+  // Q|K|V (9 tiles, 3.5 MB) walk two groups (+100 MB of activations for -430 / -230 MB of weights at 65 536 tokens), FFN2 (4.7 MB in
+  // 3 tiles of K = 3072, activations 400 MB) and the out-projection (1.2 MB) one.
+  if (!cg_env && xcd_ranges) {
+    const double w_bytes = 2.0 * N * K, x_bytes = 2.0 * (double)(m_exact >= 0 ? m_exact : m_bound) * K, l2_keep = 2.5 * 1048576.0;
+    const int64_t rounds = (((m_exact >= 0 ? m_exact : m_bound) + G_BM - 1) / G_BM * n_tiles + cus - 1) / cus;
+    if (w_bytes > l2_keep) {
+      const int groups = (int)((w_bytes + l2_keep - 1) / l2_keep);
+      if ((groups - 1) * x_bytes < 8.0 * (double)(rounds - 1) * w_bytes) col_group = (n_tiles + groups - 1) / groups;
+    }
+  }
   DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
+  aux.xcd_ranges = xcd_ranges;
   dim3 g;
   if (int rc0 = x16_grid(m_bound, n_tiles, aux, g)) return rc0;
   static const int stagger = getenv("MANNER_HIP_GEMM_STAGGER") ? atoi(getenv("MANNER_HIP_GEMM_STAGGER")) : 0;   // A/B switch
@@ -2113,7 +2147,8 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
     const int mp = (int)((m_exact + G_BM - 1) / G_BM);
     split = split_panels(mp, n_tiles, (int)cus) < mp;
   }
-  if (split) { aux.split_cus = (int)cus; aux.panel_mode = 1; }     // the round-aware split cuts at 256-row panels
+  if (split) { aux.split_cus = (int)cus; aux.panel_mode = 1; aux.xcd_ranges = 0; }     // the round-aware split cuts at 256-row panels
+  if (stagger > 0) aux.xcd_ranges = 0;
   // Round 6: the hand-scheduled kernels (gemm_tn_w8_kernel: the same bits from a 17-22 % shorter main loop) where the panel height is
   // 256 rows by what the host knows of the token count (m_exact, else its bound) — 192-row launches and the A/B forms stay on the
   // compiler-scheduled LDS-DMA kernel.  MANNER_HIP_GEMM_ASM = 8 (default) | 4 (the 4-wave form) | 0 (gemm_tn_x16_kernel everywhere);

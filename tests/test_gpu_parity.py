@@ -1454,3 +1454,39 @@ def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(p
         assert torch.equal(c, cls), (key, tokens, float((c - cls).abs().max()))
         assert torch.equal(h, hid), (key, tokens)
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,n_news,preset", [("f16", 1100, "bert-base-uncased"), ("bf16", 2300, "bert-base-uncased"), ("f16", 900, "mini-roberta-large")])
+def test_the_tile_order_of_a_persistent_gemm_does_not_change_its_bits(precision, n_news, preset, monkeypatch):
+    """Round 6: each XCD walks a contiguous range of the tile order (`tile_walk`, MANNER_HIP_XCD_RANGES, default 1) and the wide GEMMs walk
+    their column tiles in L2-sized groups chosen per launch (MANNER_HIP_COL_GROUP unset) — which workgroup computes a tile, and when, is
+    all that changes: the same bits as the interleaved order of rounds 1-5 (ranges 0, one group), for explicit group widths, on the
+    hand-scheduled and the compiler-scheduled kernel, over 2 - 9 rounds of tiles."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS[preset], layers=2) if preset == "bert-base-uncased" else PRESETS[preset]
+    w = make_plm_weights(cfg, seed=97, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=97, max_len=96, profile="title_abstract")
+    lens = mask_np.sum(1)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")
+    got = {}
+    for ranges, group, asm in (("0", "0", "0"), ("0", "0", "8"), ("1", "0", "8"), ("1", None, "8"), ("1", None, "0"), ("1", "1", "8"), ("1", "5", "0"),
+                               ("0", "2", "8"), ("1", "7", "8")):
+        monkeypatch.setenv("MANNER_HIP_XCD_RANGES", ranges)
+        monkeypatch.setenv("MANNER_HIP_GEMM_ASM", asm)
+        if group is None:
+            monkeypatch.delenv("MANNER_HIP_COL_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_COL_GROUP", group)
+        got[(ranges, group, asm)] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
+                                     enc.encode_hidden(ids, mask, cfg.layers - 1, precision=precision, host_lengths=lens).clone())
+    enc.status()
+    for k in ("MANNER_HIP_XCD_RANGES", "MANNER_HIP_GEMM_ASM", "MANNER_HIP_COL_GROUP"):
+        monkeypatch.delenv(k, raising=False)
+    cls, hid = got[("0", "0", "0")]
+    assert bool(torch.isfinite(cls).all()) and float(cls.abs().max()) > 0.1
+    for key, (c, h) in got.items():
+        assert torch.equal(c, cls) and torch.equal(h, hid), (key, int(lens.sum()))
+    enc.close()
