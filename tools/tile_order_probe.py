@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-class GEMM launch times of one encoder call under different tile orders of the persistent GEMMs (csrc/gemm.hip tile_walk:
-MANNER_HIP_XCD_RANGES, MANNER_HIP_COL_GROUP — both read per launch), interleaved in ONE process so that box and clock state are shared.
+MANNER_HIP_XCD_RANGES, MANNER_HIP_COL_GROUP — read per launch; profiles/r6_final/tile_rev_probe.txt came from a lab build with two more
+switches, back-to-front tile / news orders, that changed nothing and were not kept), interleaved in ONE process so that box and clock state are shared.
 Development aid of round 6.
 
     python tools/tile_order_probe.py [tokens ...]      # PROBE_PRECISION=f16|bf16, bert-base, title+abstract news"""
@@ -23,16 +24,21 @@ ids_np, mask_np = synth_news_tokens(4096, cfg, seed=3, max_len=96, profile="titl
 lens = mask_np.sum(1)
 cum = lens.cumsum()
 os.environ["MANNER_HIP_GEMM_SMALL_TILES"] = "0"
-MODES = [m.split(":") for m in os.environ.get("PROBE_MODES", "0:0,1:0,1:-,1:6,1:4,1:3,1:2").split(",")]   # ranges:col_group ("-" = chosen per launch)
+# settings to compare: comma-separated, each "VAR=value+VAR=value" ("base" = the library's defaults); every variable named anywhere is
+# unset for the settings that do not name it
+MODES = os.environ.get("PROBE_ENVS", "MANNER_HIP_XCD_RANGES=0+MANNER_HIP_COL_GROUP=0,MANNER_HIP_COL_GROUP=0,base,MANNER_HIP_COL_GROUP=6,"
+                       "MANNER_HIP_COL_GROUP=4,MANNER_HIP_COL_GROUP=3,MANNER_HIP_COL_GROUP=2").split(",")
+VARS = sorted({kv.split("=")[0] for m in MODES if m != "base" for kv in m.split("+")})
 ROUNDS, CALLS = int(os.environ.get("PROBE_ROUNDS", "4")), int(os.environ.get("PROBE_CALLS", "5"))
 
 
-def set_mode(ranges, group):
-    os.environ["MANNER_HIP_XCD_RANGES"] = ranges
-    if group == "-":
-        os.environ.pop("MANNER_HIP_COL_GROUP", None)
-    else:
-        os.environ["MANNER_HIP_COL_GROUP"] = group
+def set_mode(mode):
+    for v in VARS:
+        os.environ.pop(v, None)
+    if mode != "base":
+        for kv in mode.split("+"):
+            k, v = kv.split("=")
+            os.environ[k] = v
 
 
 for tokens in [int(a) for a in sys.argv[1:]] or [65536, 24000]:
@@ -40,8 +46,8 @@ for tokens in [int(a) for a in sys.argv[1:]] or [65536, 24000]:
     ids, mask = torch.from_numpy(ids_np[:n]).to(dev), torch.from_numpy(mask_np[:n]).to(dev)
     acc = {}
     for r in range(ROUNDS + 1):                                   # round 0 = warm-up
-        for ranges, group in MODES:
-            set_mode(ranges, group)
+        for mode in MODES:
+            set_mode(mode)
             enc.encode_cls(ids, mask, precision=prec, host_lengths=lens[:n])
             torch.cuda.synchronize()
             enc.profile(True)
@@ -51,7 +57,7 @@ for tokens in [int(a) for a in sys.argv[1:]] or [65536, 24000]:
             enc.profile(False)
             if r == 0:
                 continue
-            a = acc.setdefault(f"{ranges}:{group}", {})
+            a = acc.setdefault(mode, {})
             for k, (ms, cnt) in prof.items():
                 if cnt and (k.startswith("gemm") or k == "attention"):
                     s = a.setdefault(k, [0.0, 0])
@@ -60,4 +66,4 @@ for tokens in [int(a) for a in sys.argv[1:]] or [65536, 24000]:
     for mode, a in acc.items():
         row = {k: round(1e3 * ms / cnt, 1) for k, (ms, cnt) in a.items()}
         row["layer_us"] = round(sum(row.values()), 1)
-        print(f"  ranges:group {mode:>5}  " + "  ".join(f"{k} {v:7.1f}" for k, v in row.items()), flush=True)
+        print("  " + "  ".join(f"{k} {v:7.1f}" for k, v in row.items()) + "   " + mode.replace("MANNER_HIP_", ""), flush=True)
