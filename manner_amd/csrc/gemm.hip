@@ -1897,11 +1897,38 @@ static int pick_asm(int64_t m_est, int n_tiles, int K, const DlnAux& aux) {
   return panel_rows((int)m_est, n_tiles, device_cus(), aux.panel_mode) == 256 ? req : 0;
 }
 
+// Column groups (round 6, with the per-XCD tile ranges of tile_walk): all column tiles in one pass read the activations once but, when
+// their weights (N K 2 bytes) exceed what an XCD's 4 MiB L2 keeps beside the streaming operands (~2.5 MiB), every XCD re-fetches
+// them every round: 8 (rounds - 1) N K 2 bytes.  g passes over the rows in groups of ceil(n_tiles / g) column tiles keep a group
+// resident and read the activations g times: (g - 1) M K 2 bytes more.  Take the cheaper by this count: FFN1 (12 tiles, 4.7 MB) and
+// Q|K|V (9 tiles, 3.5 MB) walk two groups (+100 MB of activations for -430 / -230 MB of weights at 65 536 tokens), FFN2 (4.7 MB in
+// 3 tiles of K = 3072, activations 400 MB) and the out-projection (1.2 MB) one.  Returns the group width (0 = all tiles).
+static int pick_col_group(int64_t m_est, int N, int K, int cus) {
+  const int n_tiles = N / G_BN;
+  const double w_bytes = 2.0 * N * K, x_bytes = 2.0 * (double)m_est * K, l2_keep = 2.5 * 1048576.0;
+  const int64_t rounds = ((m_est + G_BM - 1) / G_BM * n_tiles + cus - 1) / cus;
+  if (w_bytes <= l2_keep) return 0;
+  const int groups = (int)((w_bytes + l2_keep - 1) / l2_keep);
+  return (groups - 1) * x_bytes < 8.0 * (double)(rounds - 1) * w_bytes ? (n_tiles + groups - 1) / groups : 0;
+}
+
+// The tile order of a persistent launch from the two switches (read per launch: the equality tests flip them)
+static void set_tile_order(DlnAux& aux, int64_t m_est, int N, int K) {
+  const char* cg_env = getenv("MANNER_HIP_COL_GROUP");
+  const char* xr_env = getenv("MANNER_HIP_XCD_RANGES");
+  aux.xcd_ranges = xr_env ? (atoi(xr_env) != 0) : 1;
+  aux.col_group = cg_env ? atoi(cg_env) : aux.xcd_ranges ? pick_col_group(m_est, N, K, device_cus()) : 0;
+}
+
 template <typename TE, typename TOut>
 int launch_x16(Epilogue epi, const void* X, const void* W, const float* bias, const void* R, void* Y,
                int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream) {
   const int n_tiles = N / G_BN;
   DlnAux aux0{};
+  set_tile_order(aux0, m_bound, N, K);
+  // measured (tools/tile_order_probe.py, f16x3, 65 k tokens): every x3 GEMM is indifferent to the order (+-0.3 %) except FFN1, whose
+  // 1.2 GB of split output rows and 302 MB operand run 3 % slower in ranges (877 -> 904 us); it keeps the interleaved order
+  if (epi == EPI_BIAS_GELU_SPLIT3 && !getenv("MANNER_HIP_XCD_RANGES")) aux0.xcd_ranges = aux0.col_group = 0;
   dim3 g, b(512);
   if (int rc = x16_grid(m_bound, n_tiles, aux0, g)) return rc;
   const TE* x = static_cast<const TE*>(X);
@@ -2090,10 +2117,6 @@ static int launch_dln(Epilogue epi, const void* X, const void* W, const float* b
 
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
                 void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact) {
-  const char* cg_env = getenv("MANNER_HIP_COL_GROUP");                        // A/B switches, read per launch (the tests flip them)
-  const char* xr_env = getenv("MANNER_HIP_XCD_RANGES");
-  const int xcd_ranges = xr_env ? (atoi(xr_env) != 0) : 1;
-  int col_group = cg_env ? atoi(cg_env) : 0;
   if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
     return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
@@ -2116,22 +2139,9 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   const int64_t tiles = (m_bound / G_BM) * n_tiles;
   const int64_t cus = device_cus();
   static const bool plain_stores = getenv("MANNER_HIP_NT_STORES") && atoi(getenv("MANNER_HIP_NT_STORES")) == 0;   // A/B switch
-  // Column groups (round 6, with the per-XCD tile ranges of tile_walk): all column tiles in one pass read the activations once but, when
-  // their weights (N K 2 bytes) exceed what an XCD's 4 MiB L2 keeps beside the streaming operands (~2.5 MiB), every XCD re-fetches
-  // them every round: 8 (rounds - 1) N K 2 bytes.  g passes over the rows in groups of ceil(n_tiles / g) column tiles keep a group
-  // resident and read the activations g times: (g - 1) M K 2 bytes more.  Take the cheaper by this count: FFN1 (12 tiles, 4.7 MB) and
-  // Q|K|V (9 tiles, 3.5 MB) walk two groups (+100 MB of activations for -430 / -230 MB of weights at 65 536 tokens), FFN2 (4.7 MB in
-  // 3 tiles of K = 3072, activations 400 MB) and the out-projection (1.2 MB) one.
-  if (!cg_env && xcd_ranges) {
-    const double w_bytes = 2.0 * N * K, x_bytes = 2.0 * (double)(m_exact >= 0 ? m_exact : m_bound) * K, l2_keep = 2.5 * 1048576.0;
-    const int64_t rounds = (((m_exact >= 0 ? m_exact : m_bound) + G_BM - 1) / G_BM * n_tiles + cus - 1) / cus;
-    if (w_bytes > l2_keep) {
-      const int groups = (int)((w_bytes + l2_keep - 1) / l2_keep);
-      if ((groups - 1) * x_bytes < 8.0 * (double)(rounds - 1) * w_bytes) col_group = (n_tiles + groups - 1) / groups;
-    }
-  }
-  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, col_group, plain_stores ? 1 : 0};
-  aux.xcd_ranges = xcd_ranges;
+  DlnAux aux{vec, static_cast<const float2*>(mr), static_cast<float2*>(part), m_bound, 0, plain_stores ? 1 : 0};
+  set_tile_order(aux, m_exact >= 0 ? m_exact : m_bound, N, K);
+  const int col_group = aux.col_group;
   dim3 g;
   if (int rc0 = x16_grid(m_bound, n_tiles, aux, g)) return rc0;
   static const int stagger = getenv("MANNER_HIP_GEMM_STAGGER") ? atoi(getenv("MANNER_HIP_GEMM_STAGGER")) : 0;   // A/B switch
@@ -2211,6 +2221,7 @@ int gemm_tn_drop_res(DType in, const void* X, const void* W, const float* bias, 
   DlnAux aux{};
   dim3 g, b(512);
   if (int rc = x16_grid(m_bound, n_tiles, aux, g)) return rc;
+  set_tile_order(aux, m_bound, N, K);
   aux.drop_seed = drop.seed; aux.drop_site = drop.site; aux.drop_thr = drop.thr; aux.drop_scale = drop.scale; aux.drop_rowmap = rowmap;
   if (in == DT_F16)
     hipLaunchKernelGGL((gemm_tn_x16_kernel<f16_t, float, EPI_BIAS_RES_F32>), g, b, 0, stream, static_cast<const f16_t*>(X), static_cast<const f16_t*>(W),
@@ -2232,6 +2243,7 @@ static int launch_gelu_fused(const void* X, const void* W, const float* bias, vo
   const int n_tiles = N / G_BN;
   dim3 g, b(512);
   if (int rc = x16_grid(m_bound, n_tiles, aux, g)) return rc;
+  set_tile_order(aux, m_bound, N, K);
   hipLaunchKernelGGL((gemm_tn_x16_kernel<TE, TOut, EPI>), g, b, 0, stream, static_cast<const TE*>(X), static_cast<const TE*>(W), bias,
                      static_cast<const TE*>(nullptr), static_cast<TOut*>(Y), N, K, m_total, n_tiles, aux);
   MANNER_LAUNCH_CHECK();
