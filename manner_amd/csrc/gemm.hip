@@ -26,6 +26,9 @@
 #include "train_common.h"
 #include "gemm_w4_asm.inc"
 #include "gemm_w8_asm.inc"
+#ifdef MANNER_P4_LAB
+#include "gemm_p4_asm.inc"
+#endif
 
 namespace manner {
 namespace {
@@ -1870,6 +1873,148 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(
     t = tn;
   }
 }
+
+#ifdef MANNER_P4_LAB
+// ---------------------------------------------------------------------------------------------
+// Round 6 — the PAIRED 4-wave form (tools/gen_gemm_p4.py -> gemm_p4_asm.inc).  LAB ONLY (MANNER_P4_LAB: tools/gemm_p4_lab.hip; not in
+// libmanner_hip.so): bit-identical to the 8-wave kernel and 13 - 23 % SLOWER (profiles/r6_final/lab_p4_time.txt) — one 4-wave workgroup
+// alone on a CU already runs at 0.95 of the pair's rate (lab_p4_single_vs_pair.txt): the second workgroup finds almost nothing to
+// fill, and starting it late changes nothing (lab_p4_dephase.txt).  The idea was: a CU holds TWO independent workgroups of four waves
+// (one per SIMD each: still two waves per SIMD, so the epilogues keep their VALU issue rate), each walking its own 256 x 128 tiles:
+// one workgroup's barriers, LDS write phase and epilogue are the other's matrix time.  Wave tile 128 x 64 and accumulators v[0:127] as
+// in the 8-wave kernel — the same fragments and the same matrix instruction per output element in the same order over K, and the same
+// x16_epilogue (virtual wave index 4 wm + 2 (column half of the 256-column tile) + wn): the same BITS.  LDS per workgroup: ONE stage
+// [W 128 rows | X 256 rows] x 128 B = 48 KiB + a 4 KiB epilogue slab per wave = 64 KiB.  Register staging, 12 pieces per wave and K-step
+// (weight rows 32 w.., activation rows 64 w..), requested one K-step before they are written; nothing is in flight across the epilogue.
+// dln.stagger (here: dephase) > 0: the workgroups in the second slot of their CU start that many ~4 us sleeps late, so that the two
+// workgroups of a CU do not reach their epilogues together.
+template <typename TE, typename TOut, int EPI, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_tn_p4_kernel(
+    const TE* __restrict__ X, const TE* __restrict__ W, const float* __restrict__ bias,
+    const TE* __restrict__ R, TOut* __restrict__ Y, int N, int K, const int* __restrict__ m_total,
+    int n_tiles, DlnAux dln) {
+  typedef typename E16<TE>::v8 e16x8;
+  constexpr int P4_W = 0, P4_X = 16384, P4_SLAB = 49152;
+  __shared__ __attribute__((aligned(1024))) char lds[65536];
+  constexpr int BK = 64;
+  const int M = *m_total;
+  const int G = gridDim.x, blk = blockIdx.x;
+  const int m_tiles = (M + G_BM - 1) / G_BM;
+  const int n_half = 2 * n_tiles;                       // 128-column tiles
+  const int valid_tiles = m_tiles * n_half;
+  const int gsz = dln.col_group > 0 && dln.col_group < n_tiles ? 2 * dln.col_group : n_half;      // the 8-wave kernel's tile order, in halves
+  const int per_group = m_tiles * gsz;
+  auto decode = [&](int tile, int& mt_, int& nh_) {
+    const int g_ = tile / per_group;
+    const int r = tile - g_ * per_group;
+    const int width = min(gsz, n_half - g_ * gsz);
+    mt_ = r / width;
+    nh_ = g_ * gsz + (r - mt_ * width);
+  };
+  const TileWalk walk = tile_walk(G, blk, valid_tiles, dln.xcd_ranges);
+  int t = walk.first;
+  if (t >= walk.end) return;
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l15 = lane & 15, lq = lane >> 4, lrow = lane >> 3, lc = lane & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(lds);
+  const uint32_t swz = (l15 >> 1) & 7;
+  const uint32_t rw0 = lds0 + P4_W + (64 * wn + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  const uint32_t rw1 = lds0 + P4_W + (64 * wn + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  const uint32_t rx0 = lds0 + P4_X + (128 * wm + l15) * ROW_BYTES + (((0 + lq) ^ swz) << 4);
+  const uint32_t rx1 = lds0 + P4_X + (128 * wm + l15) * ROW_BYTES + (((4 + lq) ^ swz) << 4);
+  // staging: piece p (8 rows x 128 B) of the wave's share goes to row r = share + 8 p + lrow, chunk lc ^ ((r >> 1) & 7)
+  const uint32_t sw0 = (lc ^ ((lrow >> 1) & 7)) << 4, sw1 = (lc ^ ((4 + (lrow >> 1)) & 7)) << 4;
+  const uint32_t ww0 = lds0 + P4_W + (32 * wave + lrow) * ROW_BYTES + sw0, ww1 = lds0 + P4_W + (32 * wave + lrow) * ROW_BYTES + sw1;
+  const uint32_t xw0 = lds0 + P4_X + (64 * wave + lrow) * ROW_BYTES + sw0, xw1 = lds0 + P4_X + (64 * wave + lrow) * ROW_BYTES + sw1;
+  const uint32_t rowb = (uint32_t)K * 2u;
+  const uint32_t lane_off = (uint32_t)lrow * rowb + (uint32_t)lc * 16u;
+  uint32_t g = lane_off;
+  const uint32_t c1 = 8 * rowb, c2 = 16 * rowb, c3 = 24 * rowb, c4 = 32 * rowb, c5 = 40 * rowb, c6 = 48 * rowb, c7 = 56 * rowb;
+  auto uniform = [](const char* p_) -> const char* {
+    const uint64_t v = reinterpret_cast<uint64_t>(p_);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto w_share = [&](int tile) -> const char* {
+    int mt_, nh_;
+    decode(tile, mt_, nh_);
+    return reinterpret_cast<const char*>(W + (size_t)(nh_ * 128 + 32 * wave) * K);
+  };
+  auto x_share = [&](int tile) -> const char* {
+    int mt_, nh_;
+    decode(tile, mt_, nh_);
+    return reinterpret_cast<const char*>(X + (size_t)(mt_ * G_BM + 64 * wave) * K);
+  };
+  if ((dln.stagger & 0xff) > 0) {                      // dephase: the second workgroup of a CU starts late (lab: which bit tells them apart)
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+    const int mode = dln.stagger >> 8;
+    const bool second = mode == 0 ? (hw >> 16) & 1 : mode == 1 ? hw & 1 : mode == 2 ? (blk >> 3) & 1 : (blk >> 3) >= (G >> 4);
+    if (second)
+      for (int i = 0; i < (dln.stagger & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  // ---- prologue (once per workgroup): K-step 0 of the first tile -> the stage
+  {
+    const char* wb = w_share(t);
+    const char* xb = x_share(t);
+    e16x8 v[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const e16x8*>(wb + g + (uint32_t)p * 8u * rowb);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[4 + p] = *reinterpret_cast<const e16x8*>(xb + g + (uint32_t)p * 8u * rowb);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<e16x8*>(lds + (((p & 1) ? ww1 : ww0) - lds0) + p * 1024) = v[p];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<e16x8*>(lds + (((p & 1) ? xw1 : xw0) - lds0) + p * 1024) = v[4 + p];
+    g += 128;                                          // the load stream stands at K-step 1
+    __syncthreads();
+  }
+  const int nk = K / BK;
+  char* slab = lds + P4_SLAB + wave * 4096;
+  while (true) {
+    int mt, nh;
+    decode(t, mt, nh);
+    const int tn = t + walk.stride;
+    const bool has_next = tn < walk.end;
+    const char* cbw = uniform(w_share(t));
+    const char* cbx = uniform(x_share(t));
+    const char* nbw = uniform(w_share(has_next ? tn : t));      // (no next tile: the last steps re-read this one — legal, unused)
+    const char* nbx = uniform(x_share(has_next ? tn : t));
+    int cnt = nk - 3;
+    f32x16 o[8];
+#define MANNER_P4_RUN_TILE(MFMA_STR)                                                                                                       \
+  asm volatile(MANNER_P4_TILE_ASM(MFMA_STR)                                                                                                \
+               : MANNER_P4_ACC_OUTPUTS(o), [g] "+v"(g), [cnt] "+s"(cnt)                                                                    \
+               : [ww0] "v"(ww0), [ww1] "v"(ww1), [xw0] "v"(xw0), [xw1] "v"(xw1), [rw0] "v"(rw0), [rw1] "v"(rw1), [rx0] "v"(rx0),            \
+                 [rx1] "v"(rx1), [basew] "s"(cbw), [basex] "s"(cbx), [nbasew] "s"(nbw), [nbasex] "s"(nbx), [rowb] "s"(rowb), [c1] "s"(c1), \
+                 [c2] "s"(c2), [c3] "s"(c3), [c4] "s"(c4), [c5] "s"(c5), [c6] "s"(c6), [c7] "s"(c7)                                        \
+               : MANNER_P4_CLOBBERS)
+    if constexpr (E16<TE>::dtype == DT_BF16) {
+      MANNER_P4_RUN_TILE("v_mfma_f32_16x16x32_bf16");
+    } else {
+      MANNER_P4_RUN_TILE("v_mfma_f32_16x16x32_f16");
+    }
+#undef MANNER_P4_RUN_TILE
+    {
+      f32x4 acc[4][8];                                 // acc[a][b] = v[4 (8 a + b) ..] = o[2 a + (b >> 2)][4 (b & 3) ..]
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const f32x16& s16 = o[2 * a + (b >> 2)];
+          const int k4 = 4 * (b & 3);
+          acc[a][b] = f32x4{s16[k4], s16[k4 + 1], s16[k4 + 2], s16[k4 + 3]};
+        }
+      int ew = 4 * wm + 2 * (nh & 1) + wn;             // the 8-wave kernel's wave that owns this 128 x 64 block of the 256 x 256 tile
+      asm volatile("" : "+s"(ew));
+      x16_epilogue<TE, TOut, EPI, ABL, 8, true>(acc, slab, slab, lane, ew, mt, nh >> 1, M, N, bias, R, Y, dln);
+    }
+    if (!has_next) break;
+    t = tn;
+  }
+}
+#endif  // MANNER_P4_LAB
 
 // Persistent grid of an x16 launch and the panel fields of its DlnAux: one workgroup per CU (160 KiB LDS each), fewer only when even
 // the finer (192-row) tiling of the host's row bound has fewer tiles.  MANNER_HIP_GEMM_PANEL=256|192 pins the panel height (A/B; read

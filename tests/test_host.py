@@ -781,22 +781,23 @@ def test_generated_gemm_asm_is_in_sync_with_its_generator(tmp_path):
     regenerating them must reproduce the committed files byte for byte, so that nobody edits the output instead of the schedule."""
     import importlib.util
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("gen_gemm_w", os.path.join(ROOT, "tools", "gen_gemm_w.py"))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
     csrc = os.path.join(ROOT, "manner_amd", "csrc")
-    committed = {n: open(os.path.join(csrc, n), encoding="utf-8").read() for n in ("gemm_w8_asm.inc", "gemm_w4_asm.inc")}
-    real_join = gen.os.path.join
+    committed = {n: open(os.path.join(csrc, n), encoding="utf-8").read() for n in ("gemm_w8_asm.inc", "gemm_w4_asm.inc", "gemm_p4_asm.inc")}
+    real_join = os.path.join
 
-    def redirect(*parts):                                   # the generator writes next to the sources: send its two outputs to tmp_path
+    def redirect(*parts):                                   # the generators write next to the sources: send their outputs to tmp_path
         path = real_join(*parts)
         return str(tmp_path / os.path.basename(path)) if path.endswith("_asm.inc") else path
-    gen.os.path.join = redirect
-    try:
-        gen.main()
-    finally:
-        gen.os.path.join = real_join
+    for script in ("gen_gemm_w.py", "gen_gemm_p4.py"):      # (gen_gemm_p4.py: the lab-only paired 4-wave form)
+        spec = importlib.util.spec_from_file_location(script[:-3], os.path.join(ROOT, "tools", script))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+        gen.os.path.join = redirect
+        try:
+            gen.main()
+        finally:
+            gen.os.path.join = real_join
     for n, text in committed.items():
-        assert (tmp_path / n).read_text(encoding="utf-8") == text, f"{n} differs from what tools/gen_gemm_w.py generates"
+        assert (tmp_path / n).read_text(encoding="utf-8") == text, f"{n} differs from what its generator in tools/ writes"
     # and the schedule's own invariants: every K-step body has 64 matrix instructions per wave (8-wave form), the LDS-queue simulation ran
     assert committed["gemm_w8_asm.inc"].count('MFMA "') == 2 * 4 * 64 and committed["gemm_w4_asm.inc"].count('MFMA "') == 4 * 128
