@@ -28,6 +28,8 @@ import sys
 L = []
 NW = 4
 NPRE = 14           # clusters in front of the barrier
+WD = 0              # lab (NW = 8, timing only — results are wrong): 1 = no weight traffic at all (weight waves stage nothing, no weight
+                    # fragment reads), 2 = weight fragments by direct contiguous global loads into the fragment registers
 
 
 def e(s):
@@ -102,6 +104,8 @@ class LdsQueue:
 def post_reads(tagw, tagx):
     """Issue order of the reads behind the barrier (and of the prologue): what a step finds in flight when it starts."""
     h = C.na // 2
+    if WD:
+        return [(tagx, 0), (tagx, 1)]
     return [(tagx, 0)] + [(tagw, a) for a in range(h)] + [(tagx, 1)] + [(tagw, a) for a in range(h, C.na)]
 
 
@@ -111,6 +115,8 @@ def kstep(first):
     (in front of the barrier), clusters 14 / 15 read the NEXT step's clusters 0 / 1 from the other stage."""
     q = LdsQueue(post_reads("w0", "x"))
     na, h = C.na, C.na // 2
+    if WD == 2:
+        e("s_waitcnt vmcnt(3)")                      # the weight fragments requested in the step before (3 staging requests are younger)
     for c in range(16):
         s2, b = c >> 3, c & 7
         slot = c & 3
@@ -121,16 +127,29 @@ def kstep(first):
             mem.append([("lds", f"ds_read_b128 {vr(C.XF + 4 * (cn & 3))}, v{C.RX1 if cn >> 3 else C.RX0} offset:{(cn & 7) * 2048}", ("x", cn))])
         else:
             mem.append([("lds", f"ds_read_b128 {vr(C.XF + 4 * (cn & 3))}, v{C.RX0} offset:{(cn & 7) * 2048}", ("nx", cn & 7))])
-        if c < na:
+        if c < na and not WD:
             mem.append([("lds", f"ds_read_b128 {vr(C.WF[1] + 4 * c)}, v{C.RW1} offset:{c * 2048}", ("w1", c))])
-        if c >= 14:
+        if c >= 14 and not WD:
             for a in range(h * (c - 14), h * (c - 14) + h):
                 mem.append([("lds", f"ds_read_b128 {vr(C.WF[0] + 4 * a)}, v{C.RW0} offset:{a * 2048}", ("nw", a))])
         for p in range(C.np):
             if piece_cluster(p) == c:
+                if WD:                               # the weight waves stage nothing: their staging instructions run with EXEC = 0
+                    mem.append([("alu", "s_mov_b64 exec, s[48:49]", None),
+                                ("wait", f"s_waitcnt vmcnt({C.np - 1 + (8 if WD == 2 else 0)})", None),
+                                ("lds", f"ds_write_b128 v{C.WA[p & 1]}, {vr(C.S0 + 4 * p)} offset:{p * 1024}", ("s", p)),
+                                ("vm", f"global_load_dwordx4 {vr(C.S0 + 4 * p)}, v{C.GOFF + p}, s[20:21]", None),
+                                ("alu", "s_mov_b64 exec, -1", None)])
+                    continue
                 mem.append([("wait", f"s_waitcnt vmcnt({C.np - 1})", None),
                             ("lds", f"ds_write_b128 v{C.WA[p & 1]}, {vr(C.S0 + 4 * p)} offset:{p * 1024}", ("s", p)),
                             ("vm", f"global_load_dwordx4 {vr(C.S0 + 4 * p)}, v{C.GOFF + p}, s[20:21]", None)])
+        if WD == 2 and c < 8:
+            # the NEXT step's weight fragment (k32 half c >> 2, block c & 3) straight from global memory: 1 KiB contiguous per wave and
+            # instruction (a fragment-ordered packed copy of the weights would be read like this); timing only — it lands in a live register
+            mem.append([("vm", f"global_load_dwordx4 {vr(C.WF[c >> 2] + 4 * (c & 3))}, v{248 + (c >> 2)}, s[50:51] offset:{(c & 3) * 1024}", None)])
+            if c == 7:
+                mem.append([("alu", "s_add_u32 s50, s50, 0x8000", None), ("alu", "s_addc_u32 s51, s51, 0", None)])
         # address / stream bookkeeping placed after the last use of each register (VALU / SALU fillers in MFMA gaps)
         if c == 8:
             mem.append([("alu", f"v_xor_b32 v{C.RX0}, 0x10000, v{C.RX0}", None), ("alu", f"v_xor_b32 v{C.RW1}, 0x10000, v{C.RW1}", None)])
@@ -203,9 +222,10 @@ def advance_load_stream(bump):
     lab(f".Lsame_tile_{n}")
 
 
-def main(out, nw):
-    global NW, C
+def main(out, nw, wd=0):
+    global NW, C, WD
     NW = nw
+    WD = wd
     C = Cfg(nw)
     na, h, npc = C.na, C.na // 2, C.np
     name = C.name
@@ -245,6 +265,15 @@ def main(out, nw):
     else:
         e("s_lshr_b32 s27, s26, 2")                  # staging operand = wave >> 2
         e("s_and_b32 s28, s26, 3")                   # staging share (64 rows) = wave & 3
+    if WD:
+        e("s_cmp_eq_u32 s27, 1")                     # staging EXEC: all lanes in the activation waves, none in the weight waves
+        e("s_cselect_b64 s[48:49], -1, 0")
+        e("s_mov_b32 s50, s6")
+        e("s_mov_b32 s51, s7")
+        e(f"v_lshlrev_b32 v248, 4, v{C.VLANE}")
+        e("s_lshl_b32 s36, s26, 13")
+        e("v_add_u32 v248, s36, v248")
+        e("v_add_u32 v249, 0x1000, v248")
     e("s_mov_b32 s29, s28")                          # wn: the wave tile's column block
     e("s_mov_b32 s30, s27")                          # wm: its 128-row block
     e(f"v_mov_b32 v{C.DBG}, s26")                    # debug copies (dumped by the store-bit-31 path)
@@ -470,4 +499,4 @@ amdhsa.version:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "tools/bin/gemm4w.s", int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    main(sys.argv[1] if len(sys.argv) > 1 else "tools/bin/gemm4w.s", int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
