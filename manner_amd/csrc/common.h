@@ -100,8 +100,14 @@ int gemm_tn_batched16(DType in, const void* X, const void* W, const float* bias,
 //   EPI_NRES (in place on Y) : Y = X W^T + bias + ((Y - mean) * rstd) * vec,  vec = gamma, bias = b + beta;
 //                              also writes part[N/64][m_bound] = per-wave {sum, sum of squares} of the new rows.
 // m_exact >= 0: the host knows *m_total (a launch whose rows fill whole rounds then skips the tail launch of the round-aware split)
+// fin (EPI_NRES, optional): the reduction of `part` to the NEXT {mean, rstd} inside the launch — the workgroup whose tile completes a
+// row panel last (an agent-scope arrival counter per panel, self-resetting; `arrive` >= m_bound / 192 + 1 zeroed ints owned by the
+// caller's stream) reduces that panel's partial sums exactly as dln_finalize does (dln_row_stats: the same bits).  `done` tells the
+// caller whether this launch took it (persistent kernels) or dln_finalize still has to run (128x128 kernel, round-aware split, A/B forms).
+struct DlnFinalize { void* mr_out; int32_t* arrive; float eps; bool done; };
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
-                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact = -1);
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact = -1,
+                DlnFinalize* fin = nullptr);
 
 // K11 logits[r] = sum_j tanh(x[r] . W[j] + b[j]) q[j] on the f32 MFMA (D % 32 == 0, Q <= 256); x [R, D], W [Q, D]
 int pool_logits_mfma(const float* x, const float* W, const float* bias, const float* query, int64_t R, int D, int Q,
@@ -132,6 +138,17 @@ int layernorm_rows(DType out, const float* pre, const float* gamma, const float*
 int embed_raw(DType dt, const int64_t* ids, int64_t n_news, int64_t padded_len, const int32_t* cu, const float* word,
               const float* pos, const float* type0, int H, float eps, int pos_offset, int vocab, int max_pos,
               void* raw, void* mr, int32_t* status, hipStream_t stream);
+// {mean, rstd} of a row from its (<= 16, zero-padded) partial {sum, sum of squares} in ascending group order: ONE definition for
+// dln_finalize_kernel and for the in-launch finalize of the producing GEMM (gemm.hip nres_fan_in), with the one contraction the
+// compiler had chosen for the kernel written out (var = fma(sum2, 1/H, -(mean * mean))), so that both give the same bits
+__device__ __forceinline__ float2 dln_row_stats(const float2 (&v)[16], float inv_h, float eps) {
+  float s1 = v[0].x, s2 = v[0].y;
+#pragma unroll
+  for (int g = 1; g < 16; ++g) { s1 += v[g].x; s2 += v[g].y; }
+  const float mean = s1 * inv_h;
+  const float var = fmaxf(fmaf(s2, inv_h, -(mean * mean)), 0.f);
+  return float2{mean, 1.0f / sqrtf(var + eps)};
+}
 // mr[m] = {mean, rstd} from the `groups` partial sums part[g][m] of row m (fixed summation order)
 int dln_finalize(const void* part, int groups, int H, float eps, void* mr, int64_t m_bound, const int* m_total,
                  hipStream_t stream);

@@ -58,6 +58,10 @@ struct manner_hip_encoder {
   std::vector<manner::LayerParams> params;
   std::vector<manner::LayerWeights> w[5];   // [MANNER_HIP_PREC_*]; BF16X3 / F16X3: 16-bit [out, 3*in] split weights
   int32_t* status = nullptr;                // device flag word
+  // arrival counters of the GEMMs' in-launch row-statistics finalize (gemm.hip nres_fan_in): ARRIVE_CAP zeroed ints per stream lane,
+  // one per row panel of the chunk in flight on that lane; the workgroup that completes a panel puts its counter back to 0
+  static constexpr int ARRIVE_CAP = 4096;
+  int32_t* arrive = nullptr;
   std::vector<void*> allocs;
   // chunks alternate between the caller's stream and a side stream (fork/join by events) so the
   // HBM-bound phases of one chunk overlap the MFMA-bound phases of the other (the side stream starts half
@@ -132,6 +136,7 @@ struct Workspace {
   void *x, *qkv, *ctx, *ffn;
   void *xcls, *qcls;                 // compact [CLS] rows of the last layer
   void *mr_in, *mr_mid, *part;       // deferred LayerNorm: {mean, rstd} per row (layer input / after attention), partial sums
+  int32_t* arrive = nullptr;         // this lane's arrival counters (handle-owned, not carved from the caller's workspace: they must start at 0)
   void* a3;                          // x3 modes: split copy [M, 3*max(H, I)] (16-bit) of an I-wide (or compact-row) f32 A operand
   void* a3h;                         // x3 modes: split copy [M, 3H] of the H-wide A operand (layer input / ctx / LN1 output), written by its producer
   // last layer, [CLS] rows only: the rows of several chunks are collected (acc_*) and the tail of the layer — output
@@ -231,12 +236,15 @@ int encode_chunk(manner_hip_encoder* e, const int64_t* ids, const int64_t* mask,
       }
       PROF_STEP(MANNER_HIP_PROF_GEMM_QKV, gemm_tn_dln(dt, EPI_NORM, ws.x, w.wqkv_f, p.cq2, w.cq1, ws.mr_in, nullptr, ws.qkv, m_bound, 3 * H, H, ws.m_total, s, expect_tokens))
       PROF_STEP(MANNER_HIP_PROF_ATTENTION, attention_varlen(dt, ws.qkv, ws.ctx, ws.cu, n_news, c.heads, H, (int)lp, s))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s, expect_tokens))
-      PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
+      // the next {mean, rstd} are finished inside the producing GEMM where its kernel carries the fan-in (fin.done), else by dln_finalize
+      const bool fan_in = ws.arrive && m_bound / 192 + 1 <= manner_hip_encoder::ARRIVE_CAP;
+      DlnFinalize fin_mid{ws.mr_mid, fan_in ? ws.arrive : nullptr, c.ln_eps, false}, fin_in{ws.mr_in, fan_in ? ws.arrive : nullptr, c.ln_eps, false};
+      PROF_STEP(MANNER_HIP_PROF_GEMM_OUT, gemm_tn_dln(dt, EPI_NRES, ws.ctx, w.wo, p.bo_res, g_in, ws.mr_in, ws.part, ws.x, m_bound, H, H, ws.m_total, s, expect_tokens, &fin_mid))
+      if (!fin_mid.done) PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_mid, m_bound, ws.m_total, s))
       if (l == 0) phase.mark();   // two-stream mode: the other stream starts half a layer later
       PROF_STEP(MANNER_HIP_PROF_GEMM_FFN1, gemm_tn_dln(dt, EPI_NORM_GELU, ws.x, w.w1_f, p.cf2, w.cf1, ws.mr_mid, nullptr, ws.ffn, m_bound, I, H, ws.m_total, s, expect_tokens))
-      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s, expect_tokens))
-      PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
+      PROF_STEP(MANNER_HIP_PROF_GEMM_FFN2, gemm_tn_dln(dt, EPI_NRES, ws.ffn, w.w2, p.b2_res, p.ln1g, ws.mr_mid, ws.part, ws.x, m_bound, H, I, ws.m_total, s, expect_tokens, &fin_in))
+      if (!fin_in.done) PROF_STEP(MANNER_HIP_PROF_LAYERNORM, dln_finalize(ws.part, groups, H, c.ln_eps, ws.mr_in, m_bound, ws.m_total, s))
     }
     if (hidden_layers >= 0) {   // the residual stream is still un-normalised: apply the LayerNorm that closes layer hidden_layers-1
       const float* g = hidden_layers == 0 ? e->embg : e->params[hidden_layers - 1].ln2g;
@@ -458,6 +466,9 @@ int manner_hip_encoder_create(const manner_hip_encoder_config* cfg, const float*
     if (!guard(dev_copy_f32(e, weights[MANNER_HIP_W_EMB_LN_B], H, &e->embb, s))) break;
     if (!guard(dev_alloc(e, 256, (void**)&e->status))) break;
     if (hipMemsetAsync(e->status, 0, 256, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
+    const size_t arrive_bytes = (size_t)manner_hip_encoder::MAX_STREAMS * manner_hip_encoder::ARRIVE_CAP * sizeof(int32_t);
+    if (!guard(dev_alloc(e, arrive_bytes, (void**)&e->arrive))) break;
+    if (hipMemsetAsync(e->arrive, 0, arrive_bytes, s) != hipSuccess) { rc = fail(MANNER_HIP_E_RUNTIME, "memset failed"); break; }
     if (const char* ev = getenv("MANNER_HIP_STREAMS")) {
       const int v = atoi(ev);
       e->n_streams = v < 1 ? 1 : (v > manner_hip_encoder::MAX_STREAMS ? manner_hip_encoder::MAX_STREAMS : v);
@@ -575,7 +586,10 @@ static int encode_impl(manner_hip_encoder_t enc, const int64_t* ids, const int64
   }
   if (m_cap < 256 || m_cap < padded_len) return fail(MANNER_HIP_E_WORKSPACE, "encode_cls: workspace of %zu bytes cannot hold one 256-token tile per stream", workspace_bytes);
   Workspace ws[manner_hip_encoder::MAX_STREAMS];
-  for (int i = 0; i < ns; ++i) carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace) + i * ws_each, &ws[i]);
+  for (int i = 0; i < ns; ++i) {
+    carve(enc, n_cap, m_cap, precision, static_cast<char*>(workspace) + i * ws_each, &ws[i]);
+    ws[i].arrive = enc->arrive + (size_t)i * manner_hip_encoder::ARRIVE_CAP;
+  }
   hipStream_t s0 = (hipStream_t)stream;
   int forked = 0;                                       // side streams in use so far
   // join: the caller's stream waits for every side stream — on EVERY exit path, so that work left on a side stream

@@ -886,6 +886,12 @@ struct DlnAux {
   int64_t x_rows;
   // Round 6: 1 = every XCD walks a CONTIGUOUS range of the tile order (tile_walk) instead of every 8th slot of each round
   int xcd_ranges;
+  // EPI_NRES, in-launch finalize (nres_fan_in): != nullptr -> the workgroup that completes a row panel last reduces its `part` to
+  // fin_mr[m] = {mean, rstd}; fin_arrive: one self-resetting arrival counter per row panel; fin_groups = N / 64
+  float2* fin_mr;
+  int32_t* fin_arrive;
+  float fin_inv_h, fin_eps;
+  int fin_groups;
 };
 
 // The tiles one workgroup of a persistent launch walks: {first, stride, end}.  Workgroups are dealt round-robin over the 8 XCDs
@@ -1041,7 +1047,9 @@ __device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, c
           p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
           const int m = mrow0 + 16 * bb + l15;
           if (ABL == 4) asm volatile("" ::"v"(p1), "v"(p2));
-          else if (ABL != 2 && lq == 0 && m < M) dln.part[(size_t)(4 * nt + wn) * dln.part_stride + m] = float2{p1, p2};
+          else if (ABL != 2 && lq == 0 && m < M)       // write-through (sc1): another XCD's workgroup may reduce them in this launch (nres_fan_in)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&dln.part[(size_t)(4 * nt + wn) * dln.part_stride + m]),
+                               __builtin_bit_cast(unsigned long long, float2{p1, p2}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -1269,6 +1277,49 @@ __device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, c
   }
 }
 
+
+// In-launch finalize of the deferred-LayerNorm row statistics (round 6; EPI_NRES with dln.fin_mr set).  Every tile of a row panel
+// publishes per-64-column partial {sum, sum of squares} of its rows (`part`, written through: sc1); when a workgroup has finished a
+// tile it drains its stores (every wave: s_waitcnt vmcnt(0)), meets at a barrier, and ONE lane adds 1 to the panel's arrival counter
+// at agent scope.  The workgroup whose add returns n_tiles - 1 came last: every other tile's partials were drained before their
+// workgroup's add, so its first wave reads them back (sc1 loads: past this CU's L1, which no other CU's store refreshes), reduces each
+// row in the fixed group order of dln_finalize_kernel (dln_row_stats: the same bits), writes {mean, rstd} for the NEXT kernel and
+// puts the counter back to 0 for the next launch.  Which workgroup reduces depends on timing; what it computes does not.  This is
+// the fan-in form of cdna_hip_programming.md Guideline 16 (sc1 payload, drained stores, a workgroup barrier between every wave's
+// drain and the one agent-scope add, sc1 loads by the last adder); nothing depends on workgroup -> XCD placement.
+// Price and gain (docs/rounds/r6.md 1k): the drain costs a launch 6 us (two forms that signal a tile's arrival later — where the next
+// tile's K-loop has ended and its stores are complete by the in-order rule — cost the same: the compiler fences the returned value
+// with a full vmcnt(0) wherever it is used), more than the 5 us finalize kernel; but with two streams the tiny finalize launches sat
+// in the queue behind the other stream's persistent GEMM and held their own stream's next GEMM back: the timed step is 0.5 - 1.1 %
+// shorter without them.
+template <int TM>
+__device__ __forceinline__ void nres_fan_in(const DlnAux& dln, int mt, int M, int n_tiles, int wave, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's partial sums (and everything before them) have left the CU
+  __syncthreads();                                     // ... every wave's
+  if (wave != 0) return;
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(dln.fin_arrive + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != n_tiles - 1) return;
+  // TM / 64 rows per lane, every partial of every row requested before the first is used: one memory round trip
+  constexpr int RPL = TM / 64;
+  float2 v[RPL][16];
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int m = min(mt * TM + 64 * q + lane, M - 1);
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      v[q][g] = g < dln.fin_groups ? __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&dln.part[(size_t)g * dln.part_stride + m]),
+                                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                   : float2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int m = mt * TM + 64 * q + lane;
+    if (m < M) dln.fin_mr[m] = dln_row_stats(v[q], dln.fin_inv_h, dln.fin_eps);
+  }
+  if (lane == 0) __hip_atomic_store(dln.fin_arrive + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // MBT = 16-row MFMA token blocks per wave: 8 (256-row tile, wave tile 128 x 64) or 6 (192-row tile, wave tile 96 x 64).  The weight
 // half of a tile (256 columns: 4 waves x 64) is the same for both; the activation stage keeps its 32 KiB stride and holds 24 KiB.
@@ -1507,6 +1558,8 @@ __device__ __forceinline__ void gemm_tn_x16_body(
       x16_epilogue<TE, TOut, EPI, ABL, MBT>(acc, lds + XB + xfree * G_OP_BYTES + ew * 4096, lds + last * G_OP_BYTES + ew * 4096, lane, ew, mt, nt, M, N,
                                              bias, R, Y, dln);
     }
+    if constexpr (EPI == EPI_NRES && ABL == 0)
+      if (dln.fin_mr) nres_fan_in<TM>(dln, mt, M, n_tiles, wave, lane);
 #ifdef MANNER_W8_STAMPS
     if (dln.aux32) {
       const uint64_t xst2 = __builtin_amdgcn_s_memtime();
@@ -1719,6 +1772,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_w8_kernel(
       asm volatile("" : "+s"(ew));
       x16_epilogue<TE, TOut, EPI, ABL, 8, true>(acc, slab, slab, lane, ew, mt, nt, M, N, bias, R, Y, dln);
     }
+    if constexpr (EPI == EPI_NRES && ABL == 0)
+      if (dln.fin_mr) nres_fan_in<G_BM>(dln, mt, M, n_tiles, wave, lane);
 #ifdef MANNER_W8_STAMPS
     {
       const uint64_t st2 = __builtin_amdgcn_s_memtime();
@@ -2261,7 +2316,8 @@ static int launch_dln(Epilogue epi, const void* X, const void* W, const float* b
 }
 
 int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const float* bias, const float* vec, const void* mr,
-                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact) {
+                void* part, void* Y, int64_t m_bound, int N, int K, const int* m_total, hipStream_t stream, int64_t m_exact, DlnFinalize* fin) {
+  if (fin) fin->done = false;
   if (N % G_BN || (K * 2) % ROW_BYTES || K < 128 || m_bound % G_BM)
     return fail(MANNER_HIP_E_INVALID, "gemm_dln shape m_bound=%lld N=%d K=%d not tileable", (long long)m_bound, N, K);
   if (!vec || !mr || (epi == EPI_NRES && !part)) return fail(MANNER_HIP_E_INVALID, "gemm_dln: missing operand");
@@ -2310,6 +2366,19 @@ int gemm_tn_dln(DType dt, Epilogue epi, const void* X, const void* W, const floa
   // read per launch: the equality test flips it.
   const int asm_mode = split ? 0 : pick_asm(m_exact >= 0 ? m_exact : m_bound, n_tiles, K, aux);
   if (asm_mode) g = dim3((unsigned)(tiles < cus ? tiles : cus));
+  // the row statistics finished inside the launch (nres_fan_in) by the persistent kernels that carry the fan-in: w8 and x16
+  // (MANNER_HIP_DLN_FANIN=0: the separate dln_finalize launch, A/B; read per launch)
+  if (fin && epi == EPI_NRES && !split && asm_mode != 4 && fin->mr_out && fin->arrive && N / 64 <= 16) {
+    const char* fe = getenv("MANNER_HIP_DLN_FANIN");
+    if (!fe || atoi(fe) != 0) {
+      aux.fin_mr = static_cast<float2*>(fin->mr_out);
+      aux.fin_arrive = fin->arrive;
+      aux.fin_inv_h = 1.0f / (float)N;
+      aux.fin_eps = fin->eps;
+      aux.fin_groups = N / 64;
+      fin->done = true;
+    }
+  }
   int rc;
   if (dt == DT_F16) rc = launch_dln<f16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, asm_mode);
   else rc = launch_dln<bf16_t>(epi, X, W, bias, Y, N, K, m_total, n_tiles, g, aux, stream, asm_mode);

@@ -271,12 +271,7 @@ __global__ __launch_bounds__(256) void dln_finalize_kernel(const float2* __restr
   float2 v[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) v[g] = g < groups ? part[(size_t)g * stride + m] : float2{0.f, 0.f};
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) { s1 += v[g].x; s2 += v[g].y; }
-  const float mean = s1 * inv_h;
-  const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
-  mr[m] = float2{mean, 1.0f / sqrtf(var + eps)};
+  mr[m] = dln_row_stats(v, inv_h, eps);
 }
 
 template <typename TE>

@@ -1457,6 +1457,45 @@ def test_the_hand_scheduled_gemms_give_the_bits_of_the_compiler_scheduled_gemm(p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,n_news,preset", [("f16", 131, "bert-base-uncased"), ("bf16", 257, "bert-base-uncased"), ("f16", 700, "bert-base-uncased"),
+                                                     ("bf16", 2300, "bert-base-uncased"), ("f16", 600, "mini-roberta-large")])
+def test_row_statistics_finished_inside_the_gemm_are_those_of_the_finalize_kernel(precision, n_news, preset, monkeypatch):
+    """Round 6: the deferred-LayerNorm producers (out-projection, FFN2) finish the next {mean, rstd} inside their own launch — the
+    workgroup that completes a row panel last reduces the panel's partial sums (csrc/gemm.hip nres_fan_in: write-through partials,
+    drained stores, one agent-scope arrival per tile, self-resetting counters) with the arithmetic of dln_finalize_kernel
+    (dln_row_stats).  Which workgroup reduces depends on timing; the result must not: the same BITS as the separate finalize launch
+    (MANNER_HIP_DLN_FANIN=0), call after call (the counters come back to zero), on the hand-scheduled and the compiler-scheduled kernel,
+    with 256- and 192-row panels, one chunk and several chunks on two streams."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS[preset], layers=3) if preset == "bert-base-uncased" else PRESETS[preset]
+    w = make_plm_weights(cfg, seed=98, std=0.03)
+    ids_np, mask_np = synth_news_tokens(n_news, cfg, seed=98, max_len=96, profile="title_abstract")
+    lens = mask_np.sum(1)
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    enc = hip.HipEncoder(cfg, w, precisions=(precision,), device=DEV)
+    monkeypatch.setenv("MANNER_HIP_GEMM_SMALL_TILES", "0")          # the persistent kernels for every shape of this test
+    got = {}
+    for fan_in, asm, panel in (("0", "8", None), ("1", "8", None), ("1", "0", None), ("1", "8", "256"), ("1", "0", "192"), ("1", "8", None)):
+        monkeypatch.setenv("MANNER_HIP_DLN_FANIN", fan_in)
+        monkeypatch.setenv("MANNER_HIP_GEMM_ASM", asm)
+        if panel is None:
+            monkeypatch.delenv("MANNER_HIP_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("MANNER_HIP_GEMM_PANEL", panel)
+        for rep in range(2):
+            got[(fan_in, asm, panel, rep, len(got))] = (enc.encode_cls(ids, mask, precision=precision, host_lengths=lens).clone(),
+                                                        enc.encode_hidden(ids, mask, cfg.layers - 1, precision=precision, host_lengths=lens).clone())
+    enc.status()
+    for k in ("MANNER_HIP_DLN_FANIN", "MANNER_HIP_GEMM_ASM", "MANNER_HIP_GEMM_PANEL"):
+        monkeypatch.delenv(k, raising=False)
+    ref = next(v for k, v in got.items() if k[0] == "0")
+    assert bool(torch.isfinite(ref[0]).all()) and float(ref[0].abs().max()) > 0.1
+    for key, (c, h) in got.items():
+        assert torch.equal(c, ref[0]) and torch.equal(h, ref[1]), (key, int(lens.sum()), float((c - ref[0]).abs().max()))
+    enc.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision,n_news,preset", [("f16", 1100, "bert-base-uncased"), ("bf16", 2300, "bert-base-uncased"), ("f16", 900, "mini-roberta-large")])
 def test_the_tile_order_of_a_persistent_gemm_does_not_change_its_bits(precision, n_news, preset, monkeypatch):
     """Round 6: each XCD walks a contiguous range of the tile order (`tile_walk`, MANNER_HIP_XCD_RANGES, default 1) and the wide GEMMs walk
