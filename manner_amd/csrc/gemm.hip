@@ -1287,11 +1287,12 @@ __device__ __forceinline__ void x16_epilogue(f32x4 (&acc)[4][MBT], char* slab, c
 // puts the counter back to 0 for the next launch.  Which workgroup reduces depends on timing; what it computes does not.  This is
 // the fan-in form of cdna_hip_programming.md Guideline 16 (sc1 payload, drained stores, a workgroup barrier between every wave's
 // drain and the one agent-scope add, sc1 loads by the last adder); nothing depends on workgroup -> XCD placement.
-// Price and gain (docs/rounds/r6.md 1k): the drain costs a launch 6 us (two forms that signal a tile's arrival later — where the next
-// tile's K-loop has ended and its stores are complete by the in-order rule — cost the same: the compiler fences the returned value
-// with a full vmcnt(0) wherever it is used), more than the 5 us finalize kernel; but with two streams the tiny finalize launches sat
-// in the queue behind the other stream's persistent GEMM and held their own stream's next GEMM back: the timed step is 0.5 - 1.1 %
-// shorter without them.
+// Price and gain (docs/rounds/r6.md 1k): a launch is 6 us longer — the add's return from the memory side (~2 us) holds the first wave
+// and, at the next tile's first barrier, the workgroup; signalling a tile's arrival later (where the next tile's K-loop has ended and
+// its stores are complete by the in-order rule), issuing the add before the epilogue and reading it after, or leaving the tile's
+// output stores in flight behind a counted wait all measured the same — more than the 5 us finalize kernel; but with two streams the
+// tiny finalize launches sat in the queue behind the other stream's persistent GEMM and held their own stream's next GEMM back: the
+// timed step is 0.5 - 1.3 % shorter without them.
 template <int TM>
 __device__ __forceinline__ void nres_fan_in(const DlnAux& dln, int mt, int M, int n_tiles, int wave, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's partial sums (and everything before them) have left the CU
